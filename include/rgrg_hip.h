@@ -1,0 +1,164 @@
+/* rgrg_hip.h - C ABI of librgrg_hip.so: the MI355X (gfx950) kernels behind the RGRG
+ * inference hot path (ttanida/rgrg ReportGenerationModel.generate).
+ *
+ * The reference has no FFI of its own: its hot path sits behind a Python nn.Module
+ * API and delegates the arithmetic to torch / torchvision /
+ * transformers ops.  Each entry point below replaces the op (or op group) the
+ * reference reaches at the cited file:line.  All pointers are DEVICE pointers
+ * (fp32 unless stated), all tensors are dense row-major with the layout written
+ * next to them, `stream` is a hipStream_t passed as void*, every function returns
+ * 0 on success (RGRG_OK) or a negative RGRG_E* code and never allocates or
+ * synchronises unless its comment says so.  Activations are NHWC ("channels
+ * last"); weight repacking into the layouts named here is done once at load time
+ * by the host side (rgrg_amd/weights.py).
+ */
+#ifndef RGRG_HIP_H_
+#define RGRG_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGRG_OK 0
+#define RGRG_EINVAL (-1) /* bad shape / argument */
+#define RGRG_EHIP (-2)   /* a HIP call failed; see rgrg_last_error() */
+#define RGRG_ESTATE (-3) /* handle used in the wrong state */
+
+/* activation codes for the GEMM epilogue */
+#define RGRG_ACT_NONE 0
+#define RGRG_ACT_RELU 1
+#define RGRG_ACT_GELU_NEW 2 /* 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3))) - HF NewGELUActivation */
+
+const char* rgrg_last_error(void);
+int rgrg_abi_version(void);
+/* gfx arch name of device `dev` into buf (e.g. "gfx950"); RGRG_EHIP if no device. */
+int rgrg_device_arch(int dev, char* buf, int buflen);
+
+/* ---------------------------------------------------------------------------------
+ * Dense / implicit-GEMM fp32 contraction on the f32 MFMA (v_mfma_f32_32x32x2_f32).
+ *   Y[m,n] = act( (sum_k A(m,k) * W[n,k]) * scale[n] + shift[n] + R[m,n] )
+ * scale may be NULL (=1), shift may be NULL (=0; it carries either the bias or the
+ * folded BatchNorm shift), R may be NULL.  K % 32 == 0.  `ws` is only needed when
+ * splitk > 1 (splitk*M*N floats).
+ *
+ * rgrg_linear_f32: A is [M,K] row-major (lda = K), W is [N,K] (nn.Linear layout).
+ *   replaces F.linear / torch.addmm at: box_head fc6/fc7, box_predictor
+ *   (src/object_detector/custom_roi_heads.py:235-236), dim_reduction (:264),
+ *   BinaryClassifierRegionSelection.classifier
+ *   (src/binary_classifier/binary_classifier_region_selection.py:32), and - when
+ *   more than 32 sequences decode together - Conv1DWithTrainedWeights.forward
+ *   (src/language_model/language_model.py:25-29), GPT2MLP, uk/uv (:142-143),
+ *   feature_space_transformation_nn (:284) and lm_head (:366).
+ * rgrg_conv2d_nhwc_f32: A is the im2col view of X[B,H,W,Cin]; W is
+ *   [Cout][KH][KW][Cin]; Y is [B,OH,OW,Cout]; Cin % 32 == 0.
+ *   replaces nn.Conv2d + eval BatchNorm2d + ReLU (+ residual add) of the ResNet-50
+ *   trunk (src/object_detector/object_detector.py:51-62,219) and the RPNHead convs
+ *   (src/object_detector/custom_rpn.py:61).
+ * --------------------------------------------------------------------------------- */
+int rgrg_linear_f32(const float* A, const float* W, const float* scale, const float* shift, const float* R,
+                    float* Y, int M, int N, int K, int ldy, int act, int splitk, float* ws, void* stream);
+int rgrg_conv2d_nhwc_f32(const float* X, const float* W, const float* scale, const float* shift, const float* R,
+                         float* Y, int B, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                         int act, int splitk, float* ws, void* stream);
+
+/* ResNet stem: Conv2d(1,64,7,stride 2,pad 3,bias=False) + eval BN + ReLU
+ * (object_detector.py:54), X [B,H,W] (1 channel), Wt [49][64] (tap-major), Y [B,H/2,W/2,64]. */
+int rgrg_stem_conv7x7_f32(const float* X, const float* Wt, const float* scale, const float* shift, float* Y,
+                          int B, int H, int Wd, void* stream);
+/* nn.MaxPool2d(3, stride 2, pad 1) on NHWC (resnet50 child 3).  C % 4 == 0. */
+int rgrg_maxpool3x3s2_nhwc_f32(const float* X, float* Y, int B, int H, int Wd, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * RPN proposal generation for a single 16x16 feature level (custom_rpn.py:62-71 +
+ * torchvision 0.13.1 AnchorGenerator / BoxCoder(1,1,1,1).decode / filter_proposals):
+ * per image top-`pre_nms` of the A*H*W objectness logits (ties: lower index first),
+ * sigmoid, decode, clip to [0,img_w]x[0,img_h], drop w/h < min_size, greedy NMS
+ * (IoU > nms_thresh), first `post_nms` survivors in score order.
+ *   head_out [B, HW, 5*A]: per location A objectness logits then A*4 deltas (a*4+c)
+ *   anchors  [HW*A, 4] (x1,y1,x2,y2), index = loc*A + a
+ *   proposals [B, post_nms, 4] (rows >= count are zero), counts int32 [B],
+ *   offsets int32 [B+1] = exclusive prefix sum of counts.
+ * pre_nms <= 1000, post_nms <= pre_nms, HW*A <= 65536.
+ * --------------------------------------------------------------------------------- */
+int rgrg_rpn_proposals_f32(const float* head_out, const float* anchors, float* proposals, int32_t* counts,
+                           int32_t* offsets, int B, int HW, int A, int pre_nms, int post_nms, float nms_thresh,
+                           float min_size, float img_w, float img_h, void* stream);
+
+/* torchvision.ops.roi_align(aligned=False, sampling_ratio=2, output 8x8) fused with
+ * AvgPool2d(8) (custom_roi_heads.py:232,253): feat NHWC [B,FH,FW,C] (C % 128 == 0,
+ * FH*FW*128*4 bytes of LDS <= 128 KiB), RoIs = rows [offsets[b], offsets[b+1]) of
+ * image b taken from proposals[b].  out [R, 64, C] (bin-major, channel-minor: the
+ * fc6 weight is repacked to match), pooled [R, C].  R_total = offsets[B] (host copy). */
+int rgrg_roi_align_avgpool_f32(const float* feat, const float* proposals, const int32_t* offsets, float* out,
+                               float* pooled, int B, int FH, int FW, int C, int max_props, int R_total,
+                               float spatial_scale, void* stream);
+
+/* CustomRoIHeads.get_top_region_features_detections_class_detected
+ * (custom_roi_heads.py:63-208), eval: pred [R, ldp] holds 30 class logits then 120
+ * box deltas per RoI; outputs class_detected uint8 [B,29], top_scores [B,29],
+ * top_boxes [B,29,4], top_feats [B,29,C] (gathered rows of pooled). */
+int rgrg_top1_per_class_f32(const float* pred, int ldp, const float* proposals, const int32_t* offsets,
+                            const float* pooled, uint8_t* class_detected, float* top_scores, float* top_boxes,
+                            float* top_feats, int B, int C, int max_props, float img_w, float img_h, void* stream);
+
+/* BinaryClassifierRegionSelection threshold + mask + row-major compaction
+ * (binary_classifier_region_selection.py:53-61): selected = (logit > thr) & detected;
+ * sel_rows int32 [n] lists the selected flat (image*29+region) indices in order,
+ * *n_selected (device int32) their number; feats_out [S,D] = feats[sel_rows]. */
+int rgrg_select_regions_f32(const float* logits, const uint8_t* class_detected, float thr, uint8_t* selected,
+                            int32_t* sel_rows, int32_t* n_selected, int n, void* stream);
+int rgrg_gather_rows_f32(const float* src, const int32_t* rows, float* dst, int n_rows, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Greedy decoder (LanguageModel.generate num_beams=1 -> greedy_search,
+ * src/language_model/language_model.py:401-447,609-652, with forward :258-366 and
+ * GPT2PseudoAttention :124-180).  The decoder object keeps pointers to the (caller
+ * owned, device resident) weights, owns its KV cache / activations workspace and a
+ * captured hipGraph of one decode step per sequence count.
+ * --------------------------------------------------------------------------------- */
+typedef struct rgrg_decoder_layer_weights {
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    const float *c_attn_w, *c_attn_b;     /* [3072,1024] (transposed Conv1D), [3072] */
+    const float *attn_proj_w, *attn_proj_b; /* [1024,1024], [1024] */
+    const float *c_fc_w, *c_fc_b;         /* [4096,1024], [4096] */
+    const float *mlp_proj_w, *mlp_proj_b; /* [1024,4096], [1024] */
+} rgrg_decoder_layer_weights;
+
+typedef struct rgrg_decoder_weights {
+    int n_layer, d_model, n_head, vocab; /* 24, 1024, 16, 50257 */
+    const float* wte;                    /* [vocab,1024]; also the tied lm_head */
+    const float *lnf_g, *lnf_b;
+    const float *fst0_w, *fst0_b, *fst2_w, *fst2_b; /* feature_space_transformation_nn */
+    const float *ukv_w, *ukv_b; /* [n_layer*2*1024, 1024] rows = (layer, uk|uv, out), [n_layer*2*1024] */
+    const rgrg_decoder_layer_weights* layers; /* host array of n_layer entries */
+} rgrg_decoder_weights;
+
+typedef struct rgrg_decoder rgrg_decoder;
+
+/* Allocates device memory (weights repacked into MFMA-fragment tiles for the
+ * <=32-sequence path, workspace for max_seqs sequences x max_len positions).  May
+ * synchronise.  Not on the hot loop. */
+int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, int max_len, rgrg_decoder** out);
+void rgrg_decoder_destroy(rgrg_decoder* d);
+/* feats [S,1024] (selected region features); out_ids int64 [S,max_length] is filled
+ * with the leading BOS, the generated ids, and PAD (50256) after a row finished;
+ * *out_len (host) = L' = 1 + number of forward passes the reference would have run
+ * (stops when every row has emitted EOS or at max_length).  max_length <= 0 means
+ * "until all rows finished" bounded by the decoder's max_len.  Synchronises `stream`
+ * before returning.  use_graph=0 launches the kernels eagerly (debug/profiling). */
+int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S, int max_length, int64_t* out_ids,
+                          int out_ld, int* out_len, int use_graph, void* stream);
+/* Debug/parity taps: logits of the LAST executed step [S, vocab] -> dst (device). */
+int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S, void* stream);
+/* Times `iters` replays of one decode step's weight-streaming GEMM launches with HIP
+ * events on the decoder's stream; returns total ms and the algorithmic weight bytes
+ * of those launches (bench.py roofline). */
+int rgrg_decoder_time_gemms(rgrg_decoder* d, int S, int iters, float* ms_total, double* bytes_per_iter,
+                            int* launches_per_iter);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGRG_HIP_H_ */

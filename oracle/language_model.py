@@ -1,0 +1,123 @@
+"""CPU restatement of the reference's GPT-2 decoder with pseudo self-attention
+and its greedy loop.  TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
+
+Follows ``src/language_model/language_model.py`` of ttanida/rgrg:
+``Conv1DWithTrainedWeights`` :11-29, ``GPT2PseudoAttention`` :32-180,
+``LanguageModel.forward`` :258-399, ``generate`` :401-447,
+``prepare_inputs_for_generation`` :498-520, ``greedy_search`` :609-652.
+HF ``GPT2MLP``/``NewGELUActivation``/``LayerNorm(eps=1e-5)`` (transformers
+4.19.2, third-party) are restated from their published definitions.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+N_LAYER, N_HEAD, D_MODEL, HEAD_DIM, VOCAB = 24, 16, 1024, 64, 50257
+BOS = EOS = PAD = 50256  # language_model.py:200-202
+LN_EPS = 1e-5
+MASK_VALUE = -1e4  # language_model.py:70
+
+
+def gelu_new(x: Tensor) -> Tensor:
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
+
+
+def conv1d(sd: SD, p: str, x: Tensor) -> Tensor:
+    """HF Conv1D / Conv1DWithTrainedWeights: weight is [in,out] (:22,27)."""
+    w = sd[p + "weight"]
+    return torch.addmm(sd[p + "bias"], x.reshape(-1, x.shape[-1]), w).view(*x.shape[:-1], w.shape[-1])
+
+
+def _heads(t: Tensor) -> Tensor:
+    return t.view(*t.shape[:-1], N_HEAD, HEAD_DIM).permute(0, 2, 1, 3)
+
+
+def pseudo_attention(sd: SD, p: str, x: Tensor, img: Tensor, add_mask: Tensor,
+                     past: Optional[Tuple[Tensor, Tensor]]) -> Tuple[Tensor, Tuple[Tensor, Tensor]]:
+    """GPT2PseudoAttention.forward (:124-180).  x [S,T,1024]; img [S,1024] (already
+    through feature_space_transformation_nn); add_mask [S,1,1,1+T_total]."""
+    q, k, v = conv1d(sd, p + "c_attn.", x).split(D_MODEL, dim=2)
+    if past is None:
+        k_img = F.linear(img[:, None, :], sd[p + "uk.weight"], sd[p + "uk.bias"])
+        v_img = F.linear(img[:, None, :], sd[p + "uv.weight"], sd[p + "uv.bias"])
+        K = _heads(torch.cat((k_img, k), dim=1))
+        V = _heads(torch.cat((v_img, v), dim=1))
+    else:
+        K = torch.cat((past[0], _heads(k)), dim=-2)
+        V = torch.cat((past[1], _heads(v)), dim=-2)
+    Q = _heads(q)
+    w = torch.matmul(Q, K.transpose(-1, -2)) / (HEAD_DIM ** 0.5)
+    ql, kl = Q.shape[-2], K.shape[-2]
+    # causal mask rows [kl-ql, kl), cols [0, kl): the image column is never masked (:96-99)
+    causal = torch.tril(torch.ones((kl, kl), dtype=torch.bool))[kl - ql:kl, :kl]
+    w = torch.where(causal, w, torch.tensor(MASK_VALUE, dtype=w.dtype))
+    w = F.softmax(w + add_mask, dim=-1)
+    o = torch.matmul(w, V).permute(0, 2, 1, 3).reshape(x.shape[0], ql, D_MODEL)
+    return conv1d(sd, p + "c_proj.", o), (K, V)
+
+
+def lm_forward(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_states: Tensor,
+               past: Optional[List[Tuple[Tensor, Tensor]]], position_ids: Tensor, p: str = "language_model."):
+    """LanguageModel.forward(return_loss=False, use_cache=True) (:258-366)."""
+    g = p + "gpt_with_lm_head.transformer."
+    f = p + "feature_space_transformation_nn."
+    img = F.linear(F.relu(F.linear(image_hidden_states, sd[f + "0.weight"], sd[f + "0.bias"])),
+                   sd[f + "2.weight"], sd[f + "2.bias"])  # :284
+    wte = sd[g + "wte.weight"]
+    x = wte[input_ids] + wte[position_ids]  # quirk: positions are embedded with wte, not wpe (:307)
+    S = input_ids.shape[0]
+    am = torch.cat((torch.ones((S, 1), dtype=torch.int64), attention_mask), dim=-1)[:, None, None, :]
+    add_mask = (1.0 - am.to(x.dtype)) * -10000.0  # :325-334
+    presents = []
+    for l in range(N_LAYER):
+        b = f"{g}h.{l}."
+        h = F.layer_norm(x, (D_MODEL,), sd[b + "ln_1.weight"], sd[b + "ln_1.bias"], LN_EPS)
+        a, present = pseudo_attention(sd, b + "attn.", h, img, add_mask, None if past is None else past[l])
+        x = a + x
+        h = F.layer_norm(x, (D_MODEL,), sd[b + "ln_2.weight"], sd[b + "ln_2.bias"], LN_EPS)
+        h = conv1d(sd, b + "mlp.c_proj.", gelu_new(conv1d(sd, b + "mlp.c_fc.", h)))
+        x = h + x
+        presents.append(present)
+    x = F.layer_norm(x, (D_MODEL,), sd[g + "ln_f.weight"], sd[g + "ln_f.bias"], LN_EPS)
+    logits = F.linear(x, sd[p + "gpt_with_lm_head.lm_head.weight"])  # [S,T,50257]
+    return logits, presents
+
+
+@torch.no_grad()
+def greedy_generate(sd: SD, image_hidden_states: Tensor, max_length: Optional[int], p: str = "language_model.",
+                    return_logits: bool = False):
+    """LanguageModel.generate(num_beams=1) -> greedy_search (:401-447, :609-652).
+    Returns int64 [S, L'] incl. the leading BOS; L' = 1 + number of forward passes."""
+    S = image_hidden_states.shape[0]
+    ids = torch.full((S, 1), BOS, dtype=torch.int64)
+    attn = torch.ones((S, 1), dtype=torch.int64)
+    unfinished = torch.ones((S,), dtype=torch.int64)
+    past, cur_len, all_logits = None, 1, []
+    while True:
+        pos = attn.long().cumsum(-1) - 1  # :509-512
+        pos.masked_fill_(attn == 0, 1)
+        inp = ids if past is None else ids[:, -1:]
+        if past is not None:
+            pos = pos[:, -1:]
+        logits, past = lm_forward(sd, inp, attn, image_hidden_states, past, pos, p)
+        nxt_logits = logits[:, -1, :]
+        if return_logits:
+            all_logits.append(nxt_logits.clone())
+        nxt = torch.argmax(nxt_logits, dim=-1)
+        nxt = nxt * unfinished + PAD * (1 - unfinished)
+        ids = torch.cat([ids, nxt[:, None]], dim=-1)
+        attn = torch.cat([attn, attn.new_ones((S, 1))], dim=-1)
+        cur_len += 1
+        unfinished = unfinished * (nxt != EOS).long()
+        if unfinished.max() == 0 or (max_length and cur_len >= max_length):
+            break
+    if return_logits:
+        return ids, torch.stack(all_logits, dim=1)
+    return ids

@@ -1,0 +1,99 @@
+"""ctypes binding of ``librgrg_hip.so`` (C ABI declared in ``include/rgrg_hip.h``).
+
+There is deliberately NO fallback: if the library is missing or fails to load the
+product raises; if a call fails the HIP error string is raised.  torch only supplies
+device memory (``tensor.data_ptr()``) and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from . import build as _build
+
+c_float_p = C.c_void_p  # device pointers travel as void*
+_i, _f, _p = C.c_int, C.c_float, C.c_void_p
+
+ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
+
+
+class RgrgHipError(RuntimeError):
+    pass
+
+
+class DecoderLayerWeights(C.Structure):
+    _fields_ = [(n, _p) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "c_attn_w", "c_attn_b", "attn_proj_w",
+                                  "attn_proj_b", "c_fc_w", "c_fc_b", "mlp_proj_w", "mlp_proj_b")]
+
+
+class DecoderWeights(C.Structure):
+    _fields_ = [("n_layer", _i), ("d_model", _i), ("n_head", _i), ("vocab", _i), ("wte", _p), ("lnf_g", _p),
+                ("lnf_b", _p), ("fst0_w", _p), ("fst0_b", _p), ("fst2_w", _p), ("fst2_b", _p), ("ukv_w", _p),
+                ("ukv_b", _p), ("layers", C.POINTER(DecoderLayerWeights))]
+
+
+# name -> (restype, argtypes); mirrors include/rgrg_hip.h one to one
+SIGNATURES = {
+    "rgrg_last_error": (C.c_char_p, []),
+    "rgrg_abi_version": (_i, []),
+    "rgrg_device_arch": (_i, [_i, C.c_char_p, _i]),
+    "rgrg_linear_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "rgrg_conv2d_nhwc_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "rgrg_stem_conv7x7_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "rgrg_maxpool3x3s2_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "rgrg_rpn_proposals_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p]),
+    "rgrg_roi_align_avgpool_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "rgrg_top1_per_class_f32": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p]),
+    "rgrg_select_regions_f32": (_i, [_p, _p, _f, _p, _p, _p, _i, _p]),
+    "rgrg_gather_rows_f32": (_i, [_p, _p, _p, _i, _i, _p]),
+    "rgrg_decoder_create": (_i, [C.POINTER(DecoderWeights), _i, _i, C.POINTER(_p)]),
+    "rgrg_decoder_destroy": (None, [_p]),
+    "rgrg_decoder_generate": (_i, [_p, _p, _i, _i, _p, _i, C.POINTER(_i), _i, _p]),
+    "rgrg_decoder_copy_last_logits": (_i, [_p, _p, _i, _p]),
+    "rgrg_decoder_time_gemms": (_i, [_p, _i, _i, C.POINTER(_f), C.POINTER(C.c_double), C.POINTER(_i)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def library_path() -> str:
+    return _build.LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the in-tree shared library (building it first if hipcc is available and it
+    is missing/stale).  Raises RgrgHipError when it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        try:
+            _build.build_library()
+        except Exception as e:  # noqa: BLE001
+            raise RgrgHipError(f"librgrg_hip.so is missing and could not be built: {e}") from e
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise RgrgHipError(f"cannot load {path}: {e} (the RGRG HIP path has no CPU fallback)") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().rgrg_last_error()
+        raise RgrgHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "rgrg_hip expects dense tensors"
+    return t.data_ptr()

@@ -1,0 +1,647 @@
+// Greedy decoder of the RGRG language model (GPT-2 medium with pseudo self-attention)
+// for gfx950.  Replaces LanguageModel.generate(num_beams=1) -> greedy_search ->
+// forward -> GPT2PseudoAttention (src/language_model/language_model.py:401-447,
+// :609-652, :258-366, :124-180 of ttanida/rgrg).
+//
+// Design (MI355X-first):
+//  * KV cache pre-allocated [layer][k|v][seq][head][slot][64]; slot 0 holds the image
+//    key/value (uk/uv of the transformed region feature), slot t+1 the token of step t.
+//    Nothing is re-allocated or concatenated per step.
+//  * One decode step = a fixed kernel sequence whose only step-dependent inputs live in
+//    DEVICE memory (step counter, finished flags, id buffer), so the step is captured
+//    once per sequence count into a hipGraph and replayed; EOS bookkeeping, PAD fill and
+//    the "all finished" length are computed on device, the host polls every 16 steps.
+//  * <= 32 sequences (one image = 29 regions): every projection is a weight-streaming
+//    "skinny" GEMM: weights pre-packed into v_mfma_f32_32x32x2_f32 B-fragment order so a
+//    wave streams them as fully coalesced 1-KiB loads straight into registers (HBM-bound,
+//    no LDS round trip); activations (<=32 rows) are the A operand; the K range is split
+//    over the 4 waves of a workgroup (+ over workgroups when N is small) and reduced in a
+//    fixed order -> bitwise reproducible.
+//  * > 32 sequences: the same step runs on the tiled MFMA GEMM of gemm_f32.hip.
+#include <vector>
+
+#include "common.h"
+
+namespace rgrg {
+
+struct GemmParams;
+int launch_gemm_dense(const float* A, const float* W, const float* shift, const float* R, float* Y, int M, int N, int K,
+                      int ldy, int act, hipStream_t st);
+int init_gemm_attrs();
+
+constexpr int PAD_ROWS = 32;
+constexpr int BOS_ID = 50256, EOS_ID = 50256, PAD_ID = 50256;
+constexpr float LN_EPS = 1e-5f;
+
+// ------------------------------------------------------------------ weight packing
+// W [N,K] row-major -> P [NT][K/8][64 lanes][4]: lane l = (j = l&31, h = l>>5) holds
+// W[nt*32+j][kc*8 + 4h .. +3]; rows >= N are zero.
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ W, float* __restrict__ P, int N,
+                                                           int K, int NT) {
+    const size_t total = (size_t)NT * (K / 8) * 64;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(o & 63);
+        const size_t t = o >> 6;
+        const int kc = (int)(t % (K / 8));
+        const int nt = (int)(t / (K / 8));
+        const int n = nt * 32 + (l & 31);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < N) v = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + kc * 8 + (l >> 5) * 4);
+        reinterpret_cast<f32x4*>(P)[o] = v;
+    }
+}
+
+// ------------------------------------------------------------------ skinny GEMM
+struct SkinnyArgs {
+    const float* X;     // [32][K] (rows >= M are zero)
+    const float* P;     // packed weights
+    const float* bias;  // [N] or null
+    const float* R;     // residual [32][ldy] or null
+    float* Y;           // [32][ldy]
+    float* part;        // [KS][32][NT*32] partial sums when KS > 1
+    int M, K, N, NT, KS, ldy, act;
+};
+
+__device__ __forceinline__ void skinny_store(const SkinnyArgs& a, int row, int col, float v) {
+    if (row >= a.M || col >= a.N) return;
+    if (a.bias) v += a.bias[col];
+    if (a.R) v += a.R[(size_t)row * a.ldy + col];
+    a.Y[(size_t)row * a.ldy + col] = apply_act(v, a.act);
+}
+
+__global__ __launch_bounds__(256) void rgrg_skinny_gemm_f32(const SkinnyArgs a) {
+    __shared__ float red[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x, ks = blockIdx.y;
+    const int chunks = a.K >> 3;
+    const int per_wave = chunks / (a.KS * 4);
+    const int kc0 = (ks * 4 + wave) * per_wave;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.P) + ((size_t)nt * chunks + kc0) * 64 + lane;
+    const float* xp = a.X + (size_t)(lane & 31) * a.K + kc0 * 8 + (lane >> 5) * 4;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < per_wave; ++c) {
+        const f32x4 w = __builtin_nontemporal_load(wp + (size_t)c * 64);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(xp + c * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], w[j], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = tid + 256 * q;
+        const int r = idx >> 6, l = idx & 63;
+        const float v = ((red[0][r][l] + red[1][r][l]) + red[2][r][l]) + red[3][r][l];
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        const int col = nt * 32 + (l & 31);
+        if (a.KS == 1)
+            skinny_store(a, row, col, v);
+        else
+            a.part[((size_t)ks * PAD_ROWS + row) * (a.NT * 32) + col] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(const SkinnyArgs a) {
+    const int ldp = a.NT * 32;
+    const int total = a.M * a.N;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int row = i / a.N, col = i - row * a.N;
+        float v = 0.f;
+        for (int ks = 0; ks < a.KS; ++ks) v += a.part[((size_t)ks * PAD_ROWS + row) * ldp + col];
+        skinny_store(a, row, col, v);
+    }
+}
+
+// ------------------------------------------------------------------ small kernels
+// x[s] = wte[ids[s][t]] + wte[t]   (quirk: positions are embedded with wte, language_model.py:307)
+__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ wte, const long long* __restrict__ ids,
+                                                    int ld_ids, const int* __restrict__ step, float* __restrict__ x,
+                                                    int D) {
+    const int s = blockIdx.x, t = *step;
+    const long long tok = ids[(size_t)s * ld_ids + t];
+    const f32x4* a = reinterpret_cast<const f32x4*>(wte + (size_t)tok * D);
+    const f32x4* p = reinterpret_cast<const f32x4*>(wte + (size_t)t * D);
+    f32x4* o = reinterpret_cast<f32x4*>(x + (size_t)s * D);
+    for (int q = threadIdx.x; q < D / 4; q += 256) o[q] = a[q] + p[q];
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// nn.LayerNorm(1024, eps=1e-5); one workgroup per row, D == 1024.
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, float* __restrict__ y, int D) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const f32x4 v = reinterpret_cast<const f32x4*>(x + (size_t)row * D)[tid];
+    const float mean = block_sum_256((v[0] + v[1]) + (v[2] + v[3]), sh) / (float)D;
+    f32x4 d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = v[e] - mean;
+    const float var = block_sum_256((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]), sh) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[tid], bb = reinterpret_cast<const f32x4*>(b)[tid];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = d[e] * rstd * gg[e] + bb[e];
+    reinterpret_cast<f32x4*>(y + (size_t)row * D)[tid] = o;
+}
+
+// Pseudo self-attention for ONE new token per sequence (GPT2PseudoAttention.forward with
+// layer_past, :162-174, and _attn :84-122: scores / 8, softmax, . V; the causal mask row
+// of a single query and the all-zero padding mask are no-ops in greedy generation).
+// One wave per (sequence, head); lane = (key group g = lane>>4, 4 dims d4 = lane&15).
+__global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, int ld_qkv,
+                                                          float* __restrict__ kc, float* __restrict__ vc,
+                                                          const int* __restrict__ step, float* __restrict__ out,
+                                                          int S, int H, int T) {
+    __shared__ float sc[4][136];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wid = blockIdx.x * 4 + wave;
+    if (wid >= S * H) return;
+    const int s = wid / H, hd = wid - s * H;
+    const int t = *step, nkeys = t + 2, slot = t + 1;
+    const int g = lane >> 4, d4 = lane & 15;
+    const float* row = qkv + (size_t)s * ld_qkv;
+    const int D = H * 64;
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(row + hd * 64 + d4 * 4);
+    const f32x4 k4 = *reinterpret_cast<const f32x4*>(row + D + hd * 64 + d4 * 4);
+    const f32x4 v4 = *reinterpret_cast<const f32x4*>(row + 2 * D + hd * 64 + d4 * 4);
+    float* kbase = kc + ((size_t)s * H + hd) * T * 64;
+    float* vbase = vc + ((size_t)s * H + hd) * T * 64;
+    if (g == 0) {
+        *reinterpret_cast<f32x4*>(kbase + (size_t)slot * 64 + d4 * 4) = k4;
+        *reinterpret_cast<f32x4*>(vbase + (size_t)slot * 64 + d4 * 4) = v4;
+    }
+    float* mysc = sc[wave];
+    for (int j0 = 0; j0 < nkeys; j0 += 4) {
+        const int j = j0 + g;
+        float dot = 0.f;
+        if (j < nkeys) {
+            f32x4 kk = k4;
+            if (j != slot) kk = *reinterpret_cast<const f32x4*>(kbase + (size_t)j * 64 + d4 * 4);
+            dot = (q4[0] * kk[0] + q4[1] * kk[1]) + (q4[2] * kk[2] + q4[3] * kk[3]);
+        }
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        dot += __shfl_xor(dot, 4, 64);
+        dot += __shfl_xor(dot, 8, 64);
+        if (d4 == 0 && j < nkeys) mysc[j] = dot / 8.0f;
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // LDS writes of this wave visible to its own lanes
+    __builtin_amdgcn_wave_barrier();
+    float m = -INFINITY;
+    for (int j = lane; j < nkeys; j += 64) m = fmaxf(m, mysc[j]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < nkeys; j += 64) {
+        const float e = expf(mysc[j] - m);
+        mysc[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < nkeys; j0 += 4) {
+        const int j = j0 + g;
+        if (j < nkeys) {
+            const float p = mysc[j] / sum;
+            f32x4 vv = v4;
+            if (j != slot) vv = *reinterpret_cast<const f32x4*>(vbase + (size_t)j * 64 + d4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += p * vv[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        acc[e] += __shfl_xor(acc[e], 16, 64);
+        acc[e] += __shfl_xor(acc[e], 32, 64);
+    }
+    if (g == 0) *reinterpret_cast<f32x4*>(out + (size_t)s * D + hd * 64 + d4 * 4) = acc;
+}
+
+// image key/value (uk/uv outputs) -> cache slot 0 of every layer
+__global__ __launch_bounds__(256) void kv_slot0_kernel(const float* __restrict__ ukv, int ld, float* __restrict__ kv_all,
+                                                       size_t layer_stride, size_t kv_stride, int S, int H, int T,
+                                                       int L) {
+    const int D = H * 64;
+    const size_t total = (size_t)L * 2 * S * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        size_t r = i / D;
+        const int s = (int)(r % S);
+        r /= S;
+        const int kv = (int)(r & 1), l = (int)(r >> 1);
+        const int hd = d >> 6, e = d & 63;
+        kv_all[(size_t)l * layer_stride + (size_t)kv * kv_stride + (((size_t)s * H + hd) * T) * 64 + e] =
+            ukv[(size_t)s * ld + ((size_t)l * 2 + kv) * D + d];
+    }
+}
+
+// first-occurrence arg-max over the vocabulary (torch.argmax), one workgroup per row
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int ld, int V,
+                                                      int* __restrict__ out) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = logits + (size_t)row * ld;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = tid; i < V; i += 1024) {
+        const float v = x[i];
+        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        out[row] = idx == 0x7fffffff ? 0 : idx;
+    }
+}
+
+// greedy_search bookkeeping (:629-650): PAD for finished rows, append, EOS -> finished,
+// first length at which every row is finished, step += 1.
+__global__ __launch_bounds__(1024) void greedy_update_kernel(const int* __restrict__ next, long long* __restrict__ ids,
+                                                             int ld_ids, int* __restrict__ finished,
+                                                             int* __restrict__ step, int* __restrict__ done_len, int S) {
+    __shared__ int unfinished;
+    const int tid = threadIdx.x, t = *step;
+    if (tid == 0) unfinished = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int s = tid; s < S; s += 1024) {
+        int tok = next[s];
+        int fin = finished[s];
+        if (fin) tok = PAD_ID;
+        ids[(size_t)s * ld_ids + t + 1] = tok;
+        if (tok == EOS_ID) fin = 1;
+        finished[s] = fin;
+        mine += fin ? 0 : 1;
+    }
+    if (mine) atomicAdd(&unfinished, mine);
+    __syncthreads();
+    if (tid == 0) {
+        if (unfinished == 0 && *done_len == 0) *done_len = t + 2;
+        *step = t + 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void decode_reset_kernel(long long* __restrict__ ids, int ld_ids, int* __restrict__ finished,
+                                                           int* __restrict__ step, int* __restrict__ done_len, int S,
+                                                           int L) {
+    const size_t total = (size_t)S * L;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        ids[(i / L) * ld_ids + (i % L)] = (i % L) == 0 ? BOS_ID : PAD_ID;
+    if (blockIdx.x == 0) {
+        for (int s = threadIdx.x; s < S; s += 256) finished[s] = 0;
+        if (threadIdx.x == 0) { *step = 0; *done_len = 0; }
+    }
+}
+
+// ------------------------------------------------------------------ decoder object
+struct Lin {
+    const float* w = nullptr;  // [N,K]
+    const float* b = nullptr;  // [N]
+    float* packed = nullptr;   // skinny layout
+    int N = 0, K = 0, NT = 0, KS = 1;
+};
+
+struct LayerW {
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    Lin c_attn, attn_proj, c_fc, mlp_proj;
+};
+
+struct GraphEntry {
+    int S;
+    hipGraphExec_t exec;
+};
+
+}  // namespace rgrg
+
+using namespace rgrg;
+
+struct rgrg_decoder {
+    int n_layer, D, H, V, max_seqs, rows, T, max_len;
+    const float* wte;
+    const float *lnf_g, *lnf_b;
+    Lin fst0, fst2, ukv, lm_head;
+    std::vector<LayerW> layers;
+    // workspace
+    float *feats, *h1, *img, *ukv_out, *x, *xn, *qkv, *att, *ff, *logits, *part, *kv;
+    size_t kv_layer_stride, kv_kv_stride;
+    int ld_logits, ld_ukv;
+    long long* ids;
+    int *next, *finished, *step, *done_len;
+    int* h_done;  // pinned
+    hipStream_t stream;
+    hipEvent_t ev_in;
+    std::vector<GraphEntry> graphs;
+    std::vector<void*> allocs;
+    size_t gemm_bytes_per_step = 0;
+    int gemm_launches_per_step = 0;
+};
+
+namespace rgrg {
+
+static int dmalloc(rgrg_decoder* d, void** p, size_t bytes, bool zero) {
+    RGRG_HIP(hipMalloc(p, bytes));
+    d->allocs.push_back(*p);
+    if (zero) RGRG_HIP(hipMemset(*p, 0, bytes));
+    return RGRG_OK;
+}
+
+static int pick_ks(int NT, int chunks) {
+    // enough workgroups to cover the 256 CUs, keep >= 4 chunks (4 KiB) per wave
+    int ks = 1;
+    while (NT * ks < 256 && chunks / (ks * 2 * 4) >= 4 && chunks % (ks * 2 * 4) == 0) ks *= 2;
+    return ks;
+}
+
+static int make_lin(rgrg_decoder* d, Lin& l, const float* w, const float* b, int N, int K, bool pack) {
+    l.w = w; l.b = b; l.N = N; l.K = K;
+    l.NT = (N + 31) / 32;
+    l.KS = pick_ks(l.NT, K / 8);
+    if (pack) {
+        const size_t bytes = (size_t)l.NT * 32 * K * sizeof(float);
+        int rc = dmalloc(d, (void**)&l.packed, bytes, false);
+        if (rc) return rc;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(2048), dim3(256), 0, d->stream, w, l.packed, N, K, l.NT);
+        RGRG_LAUNCH_CHECK();
+    }
+    return RGRG_OK;
+}
+
+// Y[:M] = act(X W^T + b) + R on whichever GEMM fits the row count
+static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R, float* Y, int M, int ldy, int act,
+                  bool count) {
+    if (M <= PAD_ROWS && l.packed) {
+        SkinnyArgs a{X, l.packed, l.b, R, Y, d->part, M, l.K, l.N, l.NT, l.KS, ldy, act};
+        hipLaunchKernelGGL(rgrg_skinny_gemm_f32, dim3(l.NT, l.KS), dim3(256), 0, d->stream, a);
+        RGRG_LAUNCH_CHECK();
+        if (l.KS > 1) {
+            const int total = M * l.N;
+            hipLaunchKernelGGL(skinny_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, d->stream, a);
+            RGRG_LAUNCH_CHECK();
+        }
+        if (count) {
+            d->gemm_bytes_per_step += (size_t)l.N * l.K * sizeof(float);
+            d->gemm_launches_per_step += 1;
+        }
+        return RGRG_OK;
+    }
+    return launch_gemm_dense(X, l.w, l.b, R, Y, M, l.N, l.K, ldy, act, d->stream);
+}
+
+static int enqueue_step(rgrg_decoder* d, int S, bool count) {
+    if (count) { d->gemm_bytes_per_step = 0; d->gemm_launches_per_step = 0; }
+    hipStream_t st = d->stream;
+    const int D = d->D;
+    hipLaunchKernelGGL(embed_kernel, dim3(S), dim3(256), 0, st, d->wte, d->ids, d->max_len, d->step, d->x, D);
+    RGRG_LAUNCH_CHECK();
+    for (int l = 0; l < d->n_layer; ++l) {
+        const LayerW& w = d->layers[l];
+        float* kc = d->kv + (size_t)l * d->kv_layer_stride;
+        float* vc = kc + d->kv_kv_stride;
+        int rc;
+        hipLaunchKernelGGL(layernorm_kernel, dim3(S), dim3(256), 0, st, d->x, w.ln1_g, w.ln1_b, d->xn, D);
+        RGRG_LAUNCH_CHECK();
+        if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, count))) return rc;
+        hipLaunchKernelGGL(attn_decode_kernel, dim3((S * d->H + 3) / 4), dim3(256), 0, st, d->qkv, 3 * D, kc, vc,
+                           d->step, d->att, S, d->H, d->T);
+        RGRG_LAUNCH_CHECK();
+        if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count))) return rc;
+        hipLaunchKernelGGL(layernorm_kernel, dim3(S), dim3(256), 0, st, d->x, w.ln2_g, w.ln2_b, d->xn, D);
+        RGRG_LAUNCH_CHECK();
+        if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, count))) return rc;
+        if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->x, S, D, RGRG_ACT_NONE, count))) return rc;
+    }
+    hipLaunchKernelGGL(layernorm_kernel, dim3(S), dim3(256), 0, st, d->x, d->lnf_g, d->lnf_b, d->xn, D);
+    RGRG_LAUNCH_CHECK();
+    int rc;
+    if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count))) return rc;
+    hipLaunchKernelGGL(argmax_kernel, dim3(S), dim3(1024), 0, st, d->logits, d->ld_logits, d->V, d->next);
+    RGRG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(greedy_update_kernel, dim3(1), dim3(1024), 0, st, d->next, d->ids, d->max_len, d->finished,
+                       d->step, d->done_len, S);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+static int enqueue_prefill(rgrg_decoder* d, const float* feats, int S) {
+    hipStream_t st = d->stream;
+    const int D = d->D;
+    hipLaunchKernelGGL(decode_reset_kernel, dim3(64), dim3(256), 0, st, d->ids, d->max_len, d->finished, d->step,
+                       d->done_len, S, d->max_len);
+    RGRG_LAUNCH_CHECK();
+    RGRG_HIP(hipMemcpyAsync(d->feats, feats, (size_t)S * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    int rc;
+    // feature_space_transformation_nn (:284) - needed once: only step 0 consumes it (:135-157)
+    if ((rc = linear(d, d->fst0, d->feats, nullptr, d->h1, S, D, RGRG_ACT_RELU, false))) return rc;
+    if ((rc = linear(d, d->fst2, d->h1, nullptr, d->img, S, D, RGRG_ACT_NONE, false))) return rc;
+    // uk / uv of all layers in one GEMM, then scatter to cache slot 0
+    if ((rc = linear(d, d->ukv, d->img, nullptr, d->ukv_out, S, d->ld_ukv, RGRG_ACT_NONE, false))) return rc;
+    hipLaunchKernelGGL(kv_slot0_kernel, dim3(1024), dim3(256), 0, st, d->ukv_out, d->ld_ukv, d->kv, d->kv_layer_stride,
+                       d->kv_kv_stride, S, d->H, d->T, d->n_layer);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+}  // namespace rgrg
+
+extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, int max_len, rgrg_decoder** out) {
+    RGRG_CHECK_ARG(w && out && max_seqs > 0 && max_len >= 2 && max_len <= 1024);
+    RGRG_CHECK_ARG(w->d_model == 1024 && w->n_head == 16 && w->n_layer > 0 && w->vocab > 0 && w->layers);
+    int rc = init_gemm_attrs();
+    if (rc) return rc;
+    rgrg_decoder* d = new rgrg_decoder();
+    d->n_layer = w->n_layer; d->D = w->d_model; d->H = w->n_head; d->V = w->vocab;
+    d->max_seqs = max_seqs; d->max_len = max_len; d->T = max_len + 1;
+    d->rows = ((max_seqs + PAD_ROWS - 1) / PAD_ROWS) * PAD_ROWS;
+    d->wte = w->wte; d->lnf_g = w->lnf_g; d->lnf_b = w->lnf_b;
+    const int D = d->D;
+#define TRY(x) do { rc = (x); if (rc) { rgrg_decoder_destroy(d); return rc; } } while (0)
+    if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&d->ev_in, hipEventDisableTiming) != hipSuccess) {
+        set_error("decoder: stream/event creation failed");
+        delete d;
+        return RGRG_EHIP;
+    }
+    if (hipHostMalloc((void**)&d->h_done, sizeof(int), 0) != hipSuccess) {
+        set_error("decoder: hipHostMalloc failed");
+        delete d;
+        return RGRG_EHIP;
+    }
+    TRY(make_lin(d, d->fst0, w->fst0_w, w->fst0_b, D, D, true));
+    TRY(make_lin(d, d->fst2, w->fst2_w, w->fst2_b, D, D, true));
+    TRY(make_lin(d, d->ukv, w->ukv_w, w->ukv_b, w->n_layer * 2 * D, D, true));
+    TRY(make_lin(d, d->lm_head, w->wte, nullptr, w->vocab, D, true));
+    d->layers.resize(w->n_layer);
+    for (int l = 0; l < w->n_layer; ++l) {
+        const rgrg_decoder_layer_weights& s = w->layers[l];
+        LayerW& t = d->layers[l];
+        t.ln1_g = s.ln1_g; t.ln1_b = s.ln1_b; t.ln2_g = s.ln2_g; t.ln2_b = s.ln2_b;
+        TRY(make_lin(d, t.c_attn, s.c_attn_w, s.c_attn_b, 3 * D, D, true));
+        TRY(make_lin(d, t.attn_proj, s.attn_proj_w, s.attn_proj_b, D, D, true));
+        TRY(make_lin(d, t.c_fc, s.c_fc_w, s.c_fc_b, 4 * D, D, true));
+        TRY(make_lin(d, t.mlp_proj, s.mlp_proj_w, s.mlp_proj_b, D, 4 * D, true));
+    }
+    const size_t R = d->rows;
+    d->ld_logits = d->lm_head.NT * 32;
+    d->ld_ukv = d->ukv.N;
+    TRY(dmalloc(d, (void**)&d->feats, R * D * 4, true));
+    TRY(dmalloc(d, (void**)&d->h1, R * D * 4, true));
+    TRY(dmalloc(d, (void**)&d->img, R * D * 4, true));
+    TRY(dmalloc(d, (void**)&d->ukv_out, R * d->ld_ukv * 4, true));
+    TRY(dmalloc(d, (void**)&d->x, R * D * 4, true));
+    TRY(dmalloc(d, (void**)&d->xn, R * D * 4, true));
+    TRY(dmalloc(d, (void**)&d->qkv, R * 3 * D * 4, true));
+    TRY(dmalloc(d, (void**)&d->att, R * D * 4, true));
+    TRY(dmalloc(d, (void**)&d->ff, R * 4 * D * 4, true));
+    TRY(dmalloc(d, (void**)&d->logits, R * d->ld_logits * 4, true));
+    TRY(dmalloc(d, (void**)&d->part, (size_t)16 * PAD_ROWS * 4 * D * 4, true));  // KS<=16, N<=4096 when KS>1
+    d->kv_kv_stride = (size_t)d->max_seqs * d->H * d->T * 64;
+    d->kv_layer_stride = 2 * d->kv_kv_stride;
+    TRY(dmalloc(d, (void**)&d->kv, (size_t)d->n_layer * d->kv_layer_stride * 4, true));
+    TRY(dmalloc(d, (void**)&d->ids, R * max_len * sizeof(long long), true));
+    TRY(dmalloc(d, (void**)&d->next, R * 4, true));
+    TRY(dmalloc(d, (void**)&d->finished, R * 4, true));
+    TRY(dmalloc(d, (void**)&d->step, 4, true));
+    TRY(dmalloc(d, (void**)&d->done_len, 4, true));
+#undef TRY
+    if (hipStreamSynchronize(d->stream) != hipSuccess) {
+        set_error("decoder: weight packing failed");
+        rgrg_decoder_destroy(d);
+        return RGRG_EHIP;
+    }
+    *out = d;
+    return RGRG_OK;
+}
+
+extern "C" void rgrg_decoder_destroy(rgrg_decoder* d) {
+    if (!d) return;
+    for (auto& g : d->graphs) (void)hipGraphExecDestroy(g.exec);
+    for (void* p : d->allocs) (void)hipFree(p);
+    if (d->h_done) (void)hipHostFree(d->h_done);
+    if (d->ev_in) (void)hipEventDestroy(d->ev_in);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+}
+
+extern "C" int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S, int max_length, int64_t* out_ids,
+                                     int out_ld, int* out_len, int use_graph, void* stream) {
+    RGRG_CHECK_ARG(d && feats && out_ids && out_len && S > 0 && S <= d->max_seqs);
+    int limit = (max_length > 0) ? max_length : d->max_len;
+    RGRG_CHECK_ARG(limit >= 2 && limit <= d->max_len && out_ld >= limit);
+    hipStream_t caller = as_stream(stream);
+    RGRG_HIP(hipEventRecord(d->ev_in, caller));
+    RGRG_HIP(hipStreamWaitEvent(d->stream, d->ev_in, 0));
+    int rc = enqueue_prefill(d, feats, S);
+    if (rc) return rc;
+
+    hipGraphExec_t exec = nullptr;
+    if (use_graph) {
+        for (auto& g : d->graphs)
+            if (g.S == S) exec = g.exec;
+        if (!exec) {
+            hipGraph_t graph = nullptr;
+            RGRG_HIP(hipStreamBeginCapture(d->stream, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_step(d, S, true);
+            hipError_t e = hipStreamEndCapture(d->stream, &graph);
+            if (rc) return rc;
+            if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return RGRG_EHIP; }
+            RGRG_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            d->graphs.push_back({S, exec});
+        }
+    }
+    const int steps = limit - 1;
+    int done = 0;
+    for (int t = 0; t < steps; ++t) {
+        if (exec) {
+            RGRG_HIP(hipGraphLaunch(exec, d->stream));
+        } else {
+            rc = enqueue_step(d, S, t == 0);
+            if (rc) return rc;
+        }
+        if ((t & 15) == 15 && t + 1 < steps) {  // poll "all finished" every 16 steps
+            RGRG_HIP(hipMemcpyAsync(d->h_done, d->done_len, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+            RGRG_HIP(hipStreamSynchronize(d->stream));
+            if (*d->h_done) { done = *d->h_done; break; }
+        }
+    }
+    RGRG_HIP(hipMemcpyAsync(d->h_done, d->done_len, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    RGRG_HIP(hipMemcpy2DAsync(out_ids, (size_t)out_ld * sizeof(int64_t), d->ids, (size_t)d->max_len * sizeof(long long),
+                              (size_t)limit * sizeof(int64_t), S, hipMemcpyDeviceToDevice, d->stream));
+    RGRG_HIP(hipStreamSynchronize(d->stream));
+    done = *d->h_done;
+    *out_len = (done > 0 && done < limit) ? done : limit;
+    return RGRG_OK;
+}
+
+extern "C" int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S, void* stream) {
+    RGRG_CHECK_ARG(d && dst && S > 0 && S <= d->max_seqs);
+    RGRG_HIP(hipMemcpy2DAsync(dst, (size_t)d->V * 4, d->logits, (size_t)d->ld_logits * 4, (size_t)d->V * 4, S,
+                              hipMemcpyDeviceToDevice, as_stream(stream)));
+    RGRG_HIP(hipStreamSynchronize(as_stream(stream)));
+    return RGRG_OK;
+}
+
+extern "C" int rgrg_decoder_time_gemms(rgrg_decoder* d, int S, int iters, float* ms_total, double* bytes_per_iter,
+                                       int* launches_per_iter) {
+    RGRG_CHECK_ARG(d && S > 0 && S <= PAD_ROWS && S <= d->max_seqs && iters > 0 && ms_total && bytes_per_iter);
+    hipEvent_t e0, e1;
+    RGRG_HIP(hipEventCreate(&e0));
+    RGRG_HIP(hipEventCreate(&e1));
+    const int D = d->D;
+    d->gemm_bytes_per_step = 0;
+    d->gemm_launches_per_step = 0;
+    float total = 0.f;
+    int rc = RGRG_OK;
+    // the weight-streaming GEMM launches of one decode step, each bracketed by events on the decoder's stream
+    auto timed = [&](const Lin& l, const float* X, float* Y, int ldy, int act, bool count) -> int {
+        RGRG_HIP(hipEventRecord(e0, d->stream));
+        int r = linear(d, l, X, nullptr, Y, S, ldy, act, count);
+        if (r) return r;
+        RGRG_HIP(hipEventRecord(e1, d->stream));
+        RGRG_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        RGRG_HIP(hipEventElapsedTime(&ms, e0, e1));
+        total += ms;
+        return RGRG_OK;
+    };
+    for (int it = 0; it < iters && !rc; ++it) {
+        const bool c = it == 0;
+        for (int l = 0; l < d->n_layer && !rc; ++l) {
+            const LayerW& w = d->layers[l];
+            if ((rc = timed(w.c_attn, d->xn, d->qkv, 3 * D, RGRG_ACT_NONE, c))) break;
+            if ((rc = timed(w.attn_proj, d->att, d->h1, D, RGRG_ACT_NONE, c))) break;
+            if ((rc = timed(w.c_fc, d->xn, d->ff, 4 * D, RGRG_ACT_GELU_NEW, c))) break;
+            if ((rc = timed(w.mlp_proj, d->ff, d->h1, D, RGRG_ACT_NONE, c))) break;
+        }
+        if (!rc) rc = timed(d->lm_head, d->xn, d->logits, d->ld_logits, RGRG_ACT_NONE, c);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    *ms_total = total;
+    *bytes_per_iter = (double)d->gemm_bytes_per_step;
+    if (launches_per_iter) *launches_per_iter = d->gemm_launches_per_step;
+    return RGRG_OK;
+}

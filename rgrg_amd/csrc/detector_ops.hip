@@ -1,0 +1,609 @@
+// Detector-side kernels that are not GEMMs: ResNet stem, max-pool, RPN proposal
+// selection (top-k + decode + NMS), RoIAlign fused with the 8x8 average pool, the
+// reference's top-1-box-per-class post-processing and the region-selection mask.
+//
+// All box / sampling arithmetic is compiled with FP contraction OFF and follows the
+// operation order of the CPU algorithms it replaces, so that given identical inputs
+// the results are bit-identical except where a transcendental (exp) is involved.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace rgrg {
+
+// ----------------------------------------------------------------------------------
+// ResNet stem: 7x7 stride-2 pad-3 conv on ONE input channel -> 64, + BN + ReLU.
+// One 16x16 output tile per workgroup; the 37x37 input patch and the 49x64 filter
+// bank sit in LDS; a lane owns one output pixel and sweeps 16 channels at a time.
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, float* __restrict__ Y,
+                                                           int H, int Wd, int OH, int OW) {
+    __shared__ float tile[37][38];
+    __shared__ __attribute__((aligned(16))) float w[49 * 64];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 16;
+    for (int i = tid; i < 49 * 64; i += 256) w[i] = Wt[i];
+    for (int i = tid; i < 37 * 37; i += 256) {
+        const int r = i / 37, c = i - r * 37;
+        const int ih = oy0 * 2 - 3 + r, iw = ox0 * 2 - 3 + c;
+        float v = 0.f;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)Wd) v = X[((size_t)b * H + ih) * Wd + iw];
+        tile[r][c] = v;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    float* out = Y + (((size_t)b * OH + oy) * OW + ox) * 64;
+    for (int cg = 0; cg < 4; ++cg) {
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+        for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+                const float x = tile[ty * 2 + kh][tx * 2 + kw];
+                const f32x4* wp = reinterpret_cast<const f32x4*>(&w[(kh * 7 + kw) * 64 + cg * 16]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 wv = wp[q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[q * 4 + e] = __builtin_fmaf(x, wv[e], acc[q * 4 + e]);
+                }
+            }
+        if (oy < OH && ox < OW) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = cg * 16 + q * 4 + e;
+                    const float v = acc[q * 4 + e] * scale[c] + shift[c];
+                    o[e] = v > 0.f ? v : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(out + cg * 16 + q * 4) = o;
+            }
+        }
+    }
+}
+
+// nn.MaxPool2d(3, stride 2, padding 1), NHWC; one thread per (pixel, 4 channels).
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ X, float* __restrict__ Y, int B,
+                                                           int H, int Wd, int C, int OH, int OW) {
+    const int C4 = C >> 2;
+    const size_t total = (size_t)B * OH * OW * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t t = i / C4;
+        const int ox = (int)(t % OW);
+        t /= OW;
+        const int oy = (int)(t % OH);
+        const int b = (int)(t / OH);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oy * 2 - 1 + kh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ox * 2 - 1 + kw;
+                if ((unsigned)iw >= (unsigned)Wd) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(X + (((size_t)b * H + ih) * Wd + iw) * C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+        }
+        *reinterpret_cast<f32x4*>(Y + (((size_t)b * OH + oy) * OW + ox) * C + c4 * 4) = m;
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// RPN proposals.  One 1024-thread workgroup per image:
+//   1. radix-select the pre_nms-th largest 48-bit composite key
+//      (order-preserving logit bits << 16 | (0xFFFF - index)): unique keys, so ties
+//      between equal logits resolve to the LOWER anchor index, like a stable sort;
+//   2. bitonic-sort the <=1024 survivors descending in LDS;
+//   3. decode (BoxCoder weights 1,1,1,1; dw/dh clamped at log(1000/16)), clip, drop
+//      boxes smaller than min_size, keep order;
+//   4. 64-bit suppression bitmask (IoU > thr) in LDS, greedy scan by one wave.
+// ----------------------------------------------------------------------------------
+constexpr int PROP_THREADS = 1024;
+constexpr int PROP_MAX = 1024;   // sort width
+constexpr int PROP_ROWS = 1000;  // max boxes entering NMS (LDS budget: 160 KiB total)
+
+struct PropSmem {
+    unsigned long long mask[PROP_ROWS][16];  // 125 KiB
+    unsigned long long keys[PROP_MAX];      // 8 KiB
+    float box[PROP_MAX][4];                 // 16 KiB
+    float area[PROP_MAX];                   // 4 KiB
+    int keep[PROP_MAX];                     // 4 KiB
+    unsigned hist[256];
+    int wave_tot[16];
+    unsigned long long prefix;
+    int kleft, cnt, nvalid, nkeep;
+};
+
+static_assert(sizeof(PropSmem) <= 160 * 1024, "PropSmem must fit the 160 KiB LDS of a CU");
+
+__device__ __forceinline__ unsigned order_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(PROP_THREADS) void rpn_proposals_kernel(
+    const float* __restrict__ head_out, const float* __restrict__ anchors, float* __restrict__ proposals,
+    int* __restrict__ counts, int HW, int A, int pre_nms, int post_nms, float nms_thresh, float min_size, float img_w,
+    float img_h) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    PropSmem& s = *reinterpret_cast<PropSmem*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int n_total = HW * A, ld = 5 * A;
+    const float* ho = head_out + (size_t)b * HW * ld;
+    const int k_sel = pre_nms < n_total ? pre_nms : n_total;
+
+    auto composite = [&](int idx) -> unsigned long long {
+        const int loc = idx / A, a = idx - loc * A;
+        const unsigned k = order_key(ho[(size_t)loc * ld + a]);
+        return ((unsigned long long)k << 16) | (unsigned long long)(0xFFFF - idx);
+    };
+
+    // 1. radix select, 6 passes of 8 bits, most significant first
+    if (tid == 0) { s.prefix = 0ull; s.kleft = k_sel; s.cnt = 0; }
+    for (int pass = 5; pass >= 0; --pass) {
+        if (tid < 256) s.hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long pre = s.prefix;
+        const int sh = 8 * pass;
+        for (int idx = tid; idx < n_total; idx += PROP_THREADS) {
+            const unsigned long long c = composite(idx);
+            if (pass == 5 || (c >> (sh + 8)) == pre) atomicAdd(&s.hist[(unsigned)(c >> sh) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, k = s.kleft, bsel = 0;
+            for (int bin = 255; bin >= 0; --bin) {
+                const int h = (int)s.hist[bin];
+                if (cum + h >= k) { bsel = bin; k -= cum; break; }
+                cum += h;
+            }
+            s.kleft = k;
+            s.prefix = (pre << 8) | (unsigned long long)bsel;
+        }
+        __syncthreads();
+    }
+    const unsigned long long thr_key = s.prefix;
+    s.keys[tid] = 0ull;
+    __syncthreads();
+    for (int idx = tid; idx < n_total; idx += PROP_THREADS) {
+        const unsigned long long c = composite(idx);
+        if (c >= thr_key) {
+            const int pos = atomicAdd(&s.cnt, 1);
+            if (pos < PROP_MAX) s.keys[pos] = c;
+        }
+    }
+    __syncthreads();
+    const int cnt = s.cnt < PROP_MAX ? s.cnt : PROP_MAX;
+
+    // 2. bitonic sort, descending
+    for (int k = 2; k <= PROP_MAX; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int ixj = tid ^ j;
+            if (ixj > tid) {
+                const unsigned long long x = s.keys[tid], y = s.keys[ixj];
+                const bool desc = (tid & k) == 0;
+                if ((x < y) == desc) { s.keys[tid] = y; s.keys[ixj] = x; }
+            }
+            __syncthreads();
+        }
+
+    // 3. decode + clip + small-box filter, order-preserving compaction
+    float bx[4] = {0.f, 0.f, 0.f, 0.f};
+    bool valid = false;
+    if (tid < cnt) {
+        const int idx = 0xFFFF - (int)(s.keys[tid] & 0xFFFFull);
+        const int loc = idx / A, a = idx - loc * A;
+        const float* d = ho + (size_t)loc * ld + A + a * 4;
+        const float* an = anchors + (size_t)idx * 4;
+        const float aw = an[2] - an[0], ah = an[3] - an[1];
+        const float cx = an[0] + 0.5f * aw, cy = an[1] + 0.5f * ah;
+        const float clipv = 4.135166556742356f;  // log(1000/16)
+        const float dw = fminf(d[2], clipv), dh = fminf(d[3], clipv);
+        const float pcx = d[0] * aw + cx, pcy = d[1] * ah + cy;
+        const float pw = expf(dw) * aw, ph = expf(dh) * ah;
+        const float hw_ = 0.5f * pw, hh_ = 0.5f * ph;
+        bx[0] = fminf(fmaxf(pcx - hw_, 0.f), img_w);
+        bx[1] = fminf(fmaxf(pcy - hh_, 0.f), img_h);
+        bx[2] = fminf(fmaxf(pcx + hw_, 0.f), img_w);
+        bx[3] = fminf(fmaxf(pcy + hh_, 0.f), img_h);
+        valid = (bx[2] - bx[0] >= min_size) && (bx[3] - bx[1] >= min_size);
+    }
+    {
+        const unsigned long long bal = __ballot(valid);
+        const int wpre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s.wave_tot[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0, tot = 0;
+        for (int w2 = 0; w2 < 16; ++w2) {
+            if (w2 < wave) off += s.wave_tot[w2];
+            tot += s.wave_tot[w2];
+        }
+        if (valid) {
+            const int pos = off + wpre;
+            s.box[pos][0] = bx[0]; s.box[pos][1] = bx[1]; s.box[pos][2] = bx[2]; s.box[pos][3] = bx[3];
+            s.area[pos] = (bx[2] - bx[0]) * (bx[3] - bx[1]);
+        }
+        if (tid == 0) s.nvalid = tot;
+        __syncthreads();
+    }
+    const int nv = s.nvalid;
+
+    // 4a. suppression bitmask: bit j of mask[i][w] set iff j > i and IoU(i,j) > thr
+    for (int item = tid; item < nv * 16; item += PROP_THREADS) {
+        const int i = item >> 4, w2 = item & 15;
+        unsigned long long bits = 0ull;
+        const int j0 = w2 * 64;
+        if (j0 + 63 > i) {
+            const float x1 = s.box[i][0], y1 = s.box[i][1], x2 = s.box[i][2], y2 = s.box[i][3], ai = s.area[i];
+            for (int jj = 0; jj < 64; ++jj) {
+                const int j = j0 + jj;
+                if (j <= i || j >= nv) continue;
+                const float xx1 = fmaxf(x1, s.box[j][0]), yy1 = fmaxf(y1, s.box[j][1]);
+                const float xx2 = fminf(x2, s.box[j][2]), yy2 = fminf(y2, s.box[j][3]);
+                const float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
+                const float inter = iw * ih;
+                const float ovr = inter / (ai + s.area[j] - inter);
+                if (ovr > nms_thresh) bits |= 1ull << jj;
+            }
+        }
+        s.mask[i][w2] = bits;
+    }
+    __syncthreads();
+
+    // 4b. greedy scan by wave 0 (lane w < 16 owns suppression word w)
+    if (wave == 0) {
+        unsigned long long removed = 0ull;
+        int nkeep = 0;
+        for (int i = 0; i < nv && nkeep < post_nms; ++i) {
+            const unsigned lo = __shfl((unsigned)(removed & 0xFFFFFFFFull), i >> 6, 64);
+            const unsigned hi = __shfl((unsigned)(removed >> 32), i >> 6, 64);
+            const unsigned long long word = ((unsigned long long)hi << 32) | lo;
+            if (!((word >> (i & 63)) & 1ull)) {
+                if (lane == 0) s.keep[nkeep] = i;
+                ++nkeep;
+                if (lane < 16) removed |= s.mask[i][lane];
+            }
+        }
+        if (lane == 0) s.nkeep = nkeep;
+    }
+    __syncthreads();
+    const int nkeep = s.nkeep;
+    float* pout = proposals + (size_t)b * post_nms * 4;
+    for (int r = tid; r < post_nms; r += PROP_THREADS) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (r < nkeep) {
+            const int i = s.keep[r];
+            o[0] = s.box[i][0]; o[1] = s.box[i][1]; o[2] = s.box[i][2]; o[3] = s.box[i][3];
+        }
+        *reinterpret_cast<f32x4*>(pout + (size_t)r * 4) = o;
+    }
+    if (tid == 0) counts[b] = nkeep;
+}
+
+__global__ void prefix_counts_kernel(const int* __restrict__ counts, int* __restrict__ offsets, int B) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int acc = 0;
+        offsets[0] = 0;
+        for (int b = 0; b < B; ++b) { acc += counts[b]; offsets[b + 1] = acc; }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// RoIAlign(8x8, sampling_ratio 2, aligned=False) + AvgPool2d(8), NHWC.
+// Workgroup = (128-channel slab, RoI chunk, image).  The slab of the WHOLE feature
+// map (FH*FW positions x 128 channels fp32 = 128 KiB at 16x16) is staged in LDS once
+// and every RoI of the chunk is then served from LDS: 16 weighted ds_read_b128 per
+// output float4, output rows written as 512-B coalesced runs in [bin][channel] order.
+// ----------------------------------------------------------------------------------
+struct RoiTables {
+    int lo[2][16], hi[2][16];  // [0]=y samples, [1]=x samples; index = bin*2 + sample
+    float l[2][16], h[2][16];
+    int dead[2][16];
+};
+
+__global__ __launch_bounds__(256) void roi_align_avg_kernel(const float* __restrict__ feat,
+                                                            const float* __restrict__ proposals,
+                                                            const int* __restrict__ offsets, float* __restrict__ out,
+                                                            float* __restrict__ pooled, int FH, int FW, int C,
+                                                            int max_props, float spatial_scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int npos = FH * FW;
+    float* slab = reinterpret_cast<float*>(smem_raw);                       // [npos][128]
+    float* red = slab + (size_t)npos * 128;                                  // [8][128]
+    RoiTables* tabs = reinterpret_cast<RoiTables*>(red + 8 * 128);           // [2]
+    const int tid = threadIdx.x;
+    const int slab_i = blockIdx.x, chunk = blockIdx.y, nchunk = gridDim.y, b = blockIdx.z;
+    const int off = offsets[b], nb = offsets[b + 1] - off;
+    const int per = (nb + nchunk - 1) / nchunk;
+    const int r0 = chunk * per, r1 = (r0 + per < nb) ? r0 + per : nb;
+    if (r0 >= r1) return;
+
+    const float* fsrc = feat + (size_t)b * npos * C + slab_i * 128;
+    for (int i = tid; i < npos * 32; i += 256) {
+        const int pos = i >> 5, c4 = i & 31;
+        *reinterpret_cast<f32x4*>(slab + pos * 128 + c4 * 4) =
+            *reinterpret_cast<const f32x4*>(fsrc + (size_t)pos * C + c4 * 4);
+    }
+    const int c4 = tid & 31, ph = tid >> 5;  // this thread: bin row ph, channels c4*4..+3
+    for (int r = r0; r < r1; ++r) {
+        RoiTables& T = tabs[r & 1];
+        if (tid < 32) {
+            const int ax = tid >> 4;  // 0: y, 1: x
+            const int sidx = tid & 15, bin = sidx >> 1, g = sidx & 1;
+            const float* pb = proposals + ((size_t)b * max_props + r) * 4;
+            const float start = (ax ? pb[0] : pb[1]) * spatial_scale;
+            const float end = (ax ? pb[2] : pb[3]) * spatial_scale;
+            const float roi = fmaxf(end - start, 1.0f);
+            const float bsz = roi / 8.0f;
+            const int size = ax ? FW : FH;
+            float v = start + (float)bin * bsz + ((float)g + 0.5f) * bsz / 2.0f;
+            const int dead = (v < -1.0f || v > (float)size) ? 1 : 0;
+            v = fmaxf(v, 0.0f);
+            int lo = (int)v, hi;
+            if (lo >= size - 1) { lo = hi = size - 1; v = (float)lo; } else { hi = lo + 1; }
+            const float l = v - (float)lo;
+            T.lo[ax][sidx] = lo; T.hi[ax][sidx] = hi; T.l[ax][sidx] = l; T.h[ax][sidx] = 1.0f - l; T.dead[ax][sidx] = dead;
+        }
+        __syncthreads();
+        float* orow = out + ((size_t)(off + r) * 64 + ph * 8) * C + slab_i * 128 + c4 * 4;
+        f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+        for (int pw = 0; pw < 8; ++pw) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int iy = 0; iy < 2; ++iy) {
+                const int sy = ph * 2 + iy;
+                const int ylo = T.lo[0][sy], yhi = T.hi[0][sy];
+                const float ly = T.l[0][sy], hy = T.h[0][sy];
+                const int ydead = T.dead[0][sy];
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix) {
+                    const int sx = pw * 2 + ix;
+                    if (ydead | T.dead[1][sx]) continue;  // contributes exactly 0
+                    const int xlo = T.lo[1][sx], xhi = T.hi[1][sx];
+                    const float lx = T.l[1][sx], hx = T.h[1][sx];
+                    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + (ylo * FW + xlo) * 128 + c4 * 4);
+                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(slab + (ylo * FW + xhi) * 128 + c4 * 4);
+                    const f32x4 v3 = *reinterpret_cast<const f32x4*>(slab + (yhi * FW + xlo) * 128 + c4 * 4);
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(slab + (yhi * FW + xhi) * 128 + c4 * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float val = w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+                        acc[e] = acc[e] + val;
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] = acc[e] / 4.0f; psum[e] += acc[e]; }
+            *reinterpret_cast<f32x4*>(orow + (size_t)pw * C) = acc;
+        }
+        // 8x8 average: reduce the 8 bin rows through LDS
+        *reinterpret_cast<f32x4*>(red + ph * 128 + c4 * 4) = psum;
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += red[q * 128 + tid];
+            pooled[(size_t)(off + r) * C + slab_i * 128 + tid] = t / 64.0f;
+        }
+        // red is rewritten only after the next iteration's table barrier -> safe
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// Top-1 box per class (custom_roi_heads.py:63-208).  One workgroup per image.
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void top1_per_class_kernel(const float* __restrict__ pred, int ldp,
+                                                             const float* __restrict__ proposals,
+                                                             const int* __restrict__ offsets,
+                                                             const float* __restrict__ pooled,
+                                                             unsigned char* __restrict__ class_detected,
+                                                             float* __restrict__ top_scores,
+                                                             float* __restrict__ top_boxes,
+                                                             float* __restrict__ top_feats, int C, int max_props,
+                                                             float img_w, float img_h) {
+    __shared__ int cstar[1024];
+    __shared__ float cscore[1024];
+    __shared__ int best_idx[29];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int off = offsets[b], nb = offsets[b + 1] - off;
+    for (int r = tid; r < nb; r += 256) {
+        const float* x = pred + (size_t)(off + r) * ldp;
+        float m = x[0];
+        for (int i = 1; i < 30; ++i) m = fmaxf(m, x[i]);
+        float e[30], sum = 0.f;
+        for (int i = 0; i < 30; ++i) { e[i] = expf(x[i] - m); sum += e[i]; }
+        int bi = 0;
+        float bp = e[1] / sum;
+        for (int i = 1; i < 29; ++i) {
+            const float p = e[i + 1] / sum;
+            if (p > bp) { bp = p; bi = i; }
+        }
+        cstar[r] = bi;
+        cscore[r] = bp;
+    }
+    __syncthreads();
+    if (tid < 29) {
+        float best = 0.f;
+        int idx = 0, cnt = 0;
+        for (int r = 0; r < nb; ++r)
+            if (cstar[r] == tid) {
+                ++cnt;
+                if (cscore[r] > best) { best = cscore[r]; idx = r; }
+            }
+        best_idx[tid] = idx;
+        class_detected[b * 29 + tid] = cnt > 0 ? 1 : 0;
+        top_scores[b * 29 + tid] = best;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (nb > 0) {
+            const float* d = pred + (size_t)(off + idx) * ldp + 30 + (tid + 1) * 4;
+            const float* pb = proposals + ((size_t)b * max_props + idx) * 4;
+            const float w = pb[2] - pb[0], h = pb[3] - pb[1];
+            const float cx = pb[0] + 0.5f * w, cy = pb[1] + 0.5f * h;
+            const float clipv = 4.135166556742356f;
+            const float dx = d[0] / 10.0f, dy = d[1] / 10.0f;
+            const float dw = fminf(d[2] / 5.0f, clipv), dh = fminf(d[3] / 5.0f, clipv);
+            const float pcx = dx * w + cx, pcy = dy * h + cy;
+            const float pw = expf(dw) * w, phh = expf(dh) * h;
+            const float hw_ = 0.5f * pw, hh_ = 0.5f * phh;
+            o[0] = fminf(fmaxf(pcx - hw_, 0.f), img_w);
+            o[1] = fminf(fmaxf(pcy - hh_, 0.f), img_h);
+            o[2] = fminf(fmaxf(pcx + hw_, 0.f), img_w);
+            o[3] = fminf(fmaxf(pcy + hh_, 0.f), img_h);
+        }
+        for (int k = 0; k < 4; ++k) top_boxes[((size_t)b * 29 + tid) * 4 + k] = o[k];
+    }
+    __syncthreads();
+    const int C4 = C >> 2;
+    for (int i = tid; i < 29 * C4; i += 256) {
+        const int c = i / C4, q = i - c * C4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (nb > 0) v = *reinterpret_cast<const f32x4*>(pooled + (size_t)(off + best_idx[c]) * C + q * 4);
+        *reinterpret_cast<f32x4*>(top_feats + ((size_t)b * 29 + c) * C + q * 4) = v;
+    }
+}
+
+// selected = (logit > thr) & detected; ordered compaction of the selected flat indices.
+__global__ __launch_bounds__(1024) void select_regions_kernel(const float* __restrict__ logits,
+                                                              const unsigned char* __restrict__ detected, float thr,
+                                                              unsigned char* __restrict__ selected,
+                                                              int* __restrict__ sel_rows, int* __restrict__ n_selected,
+                                                              int n) {
+    __shared__ int wave_tot[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int start = 0; start < n; start += 1024) {
+        const int i = start + tid;
+        const bool sel = (i < n) && (logits[i] > thr) && (detected[i] != 0);
+        if (i < n) selected[i] = sel ? 1 : 0;
+        const unsigned long long bal = __ballot(sel);
+        if (lane == 0) wave_tot[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base, tot = 0;
+        for (int w2 = 0; w2 < 16; ++w2) {
+            if (w2 < wave) off += wave_tot[w2];
+            tot += wave_tot[w2];
+        }
+        if (sel) sel_rows[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0) base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *n_selected = base;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows,
+                                                          float* __restrict__ dst, int D4) {
+    const int r = blockIdx.x;
+    const int s = rows[r];
+    for (int q = threadIdx.x; q < D4; q += 256)
+        reinterpret_cast<f32x4*>(dst + (size_t)r * D4 * 4)[q] = reinterpret_cast<const f32x4*>(src + (size_t)s * D4 * 4)[q];
+}
+
+}  // namespace rgrg
+
+using namespace rgrg;
+
+extern "C" int rgrg_stem_conv7x7_f32(const float* X, const float* Wt, const float* scale, const float* shift, float* Y,
+                                     int B, int H, int Wd, void* stream) {
+    RGRG_CHECK_ARG(X && Wt && scale && shift && Y && B > 0 && H % 32 == 0 && Wd % 32 == 0);
+    const int OH = H / 2, OW = Wd / 2;
+    hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(OW / 16, OH / 16, B), dim3(256), 0, as_stream(stream), X, Wt, scale,
+                       shift, Y, H, Wd, OH, OW);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+extern "C" int rgrg_maxpool3x3s2_nhwc_f32(const float* X, float* Y, int B, int H, int Wd, int C, void* stream) {
+    RGRG_CHECK_ARG(X && Y && B > 0 && C % 4 == 0);
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (Wd + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)B * OH * OW * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), X, Y, B, H, Wd, C, OH, OW);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+extern "C" int rgrg_rpn_proposals_f32(const float* head_out, const float* anchors, float* proposals, int32_t* counts,
+                                      int32_t* offsets, int B, int HW, int A, int pre_nms, int post_nms,
+                                      float nms_thresh, float min_size, float img_w, float img_h, void* stream) {
+    RGRG_CHECK_ARG(head_out && anchors && proposals && counts && offsets && B > 0);
+    RGRG_CHECK_ARG(pre_nms > 0 && pre_nms <= PROP_ROWS && post_nms > 0 && post_nms <= pre_nms && HW * A <= 65536);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rpn_proposals_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PropSmem)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(rpn_proposals_kernel, dim3(B), dim3(PROP_THREADS), sizeof(PropSmem), as_stream(stream), head_out,
+                       anchors, proposals, counts, HW, A, pre_nms, post_nms, nms_thresh, min_size, img_w, img_h);
+    RGRG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(prefix_counts_kernel, dim3(1), dim3(64), 0, as_stream(stream), counts, offsets, B);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+extern "C" int rgrg_roi_align_avgpool_f32(const float* feat, const float* proposals, const int32_t* offsets, float* out,
+                                          float* pooled, int B, int FH, int FW, int C, int max_props, int R_total,
+                                          float spatial_scale, void* stream) {
+    RGRG_CHECK_ARG(feat && proposals && offsets && out && pooled && B > 0 && C % 128 == 0);
+    const size_t lds = (size_t)FH * FW * 128 * 4 + 8 * 128 * 4 + 2 * sizeof(RoiTables);
+    RGRG_CHECK_ARG(lds <= 160 * 1024);
+    if (R_total <= 0) return RGRG_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_avg_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int slabs = C / 128;
+    int nchunk = (512 + slabs * B - 1) / (slabs * B);  // ~2 workgroups per CU worth of blocks
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > 64) nchunk = 64;
+    hipLaunchKernelGGL(roi_align_avg_kernel, dim3(slabs, nchunk, B), dim3(256), lds, as_stream(stream), feat, proposals,
+                       offsets, out, pooled, FH, FW, C, max_props, spatial_scale);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+extern "C" int rgrg_top1_per_class_f32(const float* pred, int ldp, const float* proposals, const int32_t* offsets,
+                                       const float* pooled, uint8_t* class_detected, float* top_scores,
+                                       float* top_boxes, float* top_feats, int B, int C, int max_props, float img_w,
+                                       float img_h, void* stream) {
+    RGRG_CHECK_ARG(pred && proposals && offsets && pooled && class_detected && top_scores && top_boxes && top_feats);
+    RGRG_CHECK_ARG(B > 0 && ldp >= 150 && C % 4 == 0 && max_props <= 1024);
+    hipLaunchKernelGGL(top1_per_class_kernel, dim3(B), dim3(256), 0, as_stream(stream), pred, ldp, proposals, offsets,
+                       pooled, class_detected, top_scores, top_boxes, top_feats, C, max_props, img_w, img_h);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+extern "C" int rgrg_select_regions_f32(const float* logits, const uint8_t* class_detected, float thr, uint8_t* selected,
+                                       int32_t* sel_rows, int32_t* n_selected, int n, void* stream) {
+    RGRG_CHECK_ARG(logits && class_detected && selected && sel_rows && n_selected && n > 0);
+    hipLaunchKernelGGL(select_regions_kernel, dim3(1), dim3(1024), 0, as_stream(stream), logits, class_detected, thr,
+                       selected, sel_rows, n_selected, n);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+extern "C" int rgrg_gather_rows_f32(const float* src, const int32_t* rows, float* dst, int n_rows, int D, void* stream) {
+    RGRG_CHECK_ARG(src && rows && dst && D % 4 == 0);
+    if (n_rows <= 0) return RGRG_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(n_rows), dim3(256), 0, as_stream(stream), src, rows, dst, D / 4);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}

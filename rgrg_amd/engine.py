@@ -1,0 +1,362 @@
+"""Host-side driver of the HIP kernels: weight repacking at load time and the launch
+sequence of the detector / selection head / decoder.
+
+torch is used for device memory (tensors as buffers), the current stream and the
+one-off layout transforms of the weights; every FLOP of the hot path runs in
+``librgrg_hip.so``.  The engine refuses to run without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _hip
+from .constants import (ANCHOR_RATIOS, ANCHOR_SIZES, IMAGE_INPUT_SIZE, NUM_REGIONS, RESNET50_LAYERS,
+                        RPN_NMS_THRESH, RPN_POST_NMS_TOP_N, RPN_PRE_NMS_TOP_N, SELECTION_LOGIT_THRESHOLD)
+
+Tensor = torch.Tensor
+BN_EPS = 1e-5
+
+
+def _require_gpu(device: torch.device) -> None:
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise _hip.RgrgHipError("rgrg_amd runs only on an AMD GPU through librgrg_hip.so: move the model to "
+                                "'cuda' (there is no CPU fallback)")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pick_splitk(M: int, N: int, K: int) -> int:
+    """Split the K loop over workgroups when the output has too few tiles to fill
+    256 CUs (each split still streams >= 4 K tiles of 32)."""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    if tiles >= 128:
+        return 1
+    sk = 1
+    while sk * 2 <= 16 and tiles * sk * 2 <= 512 and K % (32 * sk * 2) == 0 and K // (32 * sk * 2) >= 4:
+        sk *= 2
+    return sk
+
+
+def grid_anchors(image_size: int, grid: int) -> Tensor:
+    """AnchorGenerator of object_detector.py:78-81 (torchvision 0.13.1 semantics):
+    160 anchors per cell, index = (y*grid + x)*160 + ratio*10 + size, base anchors
+    rounded half-to-even, stride = image // grid, no half-stride offset.  CPU fp32."""
+    scales = torch.tensor(ANCHOR_SIZES, dtype=torch.float32)
+    h_r = torch.sqrt(torch.tensor(ANCHOR_RATIOS, dtype=torch.float32))
+    w_r = 1.0 / h_r
+    ws = (w_r[:, None] * scales[None, :]).reshape(-1)
+    hs = (h_r[:, None] * scales[None, :]).reshape(-1)
+    base = (torch.stack([-ws, -hs, ws, hs], dim=1) / 2).round()
+    stride = image_size // grid
+    s = torch.arange(0, grid, dtype=torch.int32) * stride
+    yy, xx = torch.meshgrid(s, s, indexing="ij")
+    shifts = torch.stack((xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)), dim=1).to(torch.float32)
+    return (shifts.view(-1, 1, 4) + base.view(1, -1, 4)).reshape(-1, 4).contiguous()
+
+
+class _Conv:
+    """One conv (+BN) layer in kernel layout: w [Cout][KH][KW][Cin], scale/shift [Cout]."""
+
+    def __init__(self, w: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], stride: int, pad: int):
+        self.cout, self.cin, self.kh, self.kw = w.shape
+        self.w = w.permute(0, 2, 3, 1).contiguous()
+        self.scale, self.shift, self.stride, self.pad = scale, shift, stride, pad
+
+
+def _bn_affine(sd: Dict[str, Tensor], p: str) -> Tuple[Tensor, Tensor]:
+    # eval BatchNorm2d as PyTorch's CPU kernel applies it: alpha = w / sqrt(var+eps), beta = b - mean*alpha
+    invstd = 1.0 / torch.sqrt(sd[p + "running_var"] + BN_EPS)
+    alpha = sd[p + "weight"] * invstd
+    beta = sd[p + "bias"] - sd[p + "running_mean"] * alpha
+    return alpha.contiguous(), beta.contiguous()
+
+
+class HipEngine:
+    def __init__(self, state_dict: Dict[str, Tensor], device: torch.device):
+        _require_gpu(device)
+        self.lib = _hip.load()
+        arch = C.create_string_buffer(64)
+        _hip.check(self.lib.rgrg_device_arch(device.index or 0, arch, 64), "rgrg_device_arch")
+        self.arch = arch.value.decode()
+        self.device = device
+        sd = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in state_dict.items()
+              if v.dtype.is_floating_point}
+        self._decoder = None
+        self._decoder_caps = (0, 0)
+        # a sub-model used stand-alone only brings its own keys: pack what is there
+        self.has_detector = "object_detector.backbone.0.weight" in sd
+        self.has_selection = "binary_classifier_region_selection.classifier.0.weight" in sd
+        self.has_decoder = "language_model.gpt_with_lm_head.transformer.wte.weight" in sd
+        if self.has_detector:
+            self._pack_detector(sd)
+        if self.has_selection:
+            self._pack_selection(sd)
+        if self.has_decoder:
+            self._pack_decoder(sd)
+
+    # ------------------------------------------------------------------ packing
+    def _pack_detector(self, sd):
+        bb = "object_detector.backbone."
+        w = sd[bb + "0.weight"]  # [64,1,7,7]
+        self.stem_w = w.reshape(64, 49).t().contiguous()  # [49][64]
+        self.stem_scale, self.stem_shift = _bn_affine(sd, bb + "1.")
+        self.blocks: List[Dict[str, _Conv]] = []
+        for li, (_planes, blocks, stride) in enumerate(RESNET50_LAYERS):
+            for b in range(blocks):
+                p = f"{bb}{4 + li}.{b}."
+                s = stride if b == 0 else 1
+                blk = {"c1": _Conv(sd[p + "conv1.weight"], *_bn_affine(sd, p + "bn1."), 1, 0),
+                       "c2": _Conv(sd[p + "conv2.weight"], *_bn_affine(sd, p + "bn2."), s, 1),
+                       "c3": _Conv(sd[p + "conv3.weight"], *_bn_affine(sd, p + "bn3."), 1, 0)}
+                if (p + "downsample.0.weight") in sd:
+                    blk["ds"] = _Conv(sd[p + "downsample.0.weight"], *_bn_affine(sd, p + "downsample.1."), s, 0)
+                self.blocks.append(blk)
+        rp = "object_detector.rpn.head."
+        self.rpn_conv = _Conv(sd[rp + "conv.0.0.weight"], None, sd[rp + "conv.0.0.bias"].contiguous(), 1, 1)
+        # objectness (160) and deltas (640) 1x1 convs fused into one N=800 GEMM
+        w_head = torch.cat([sd[rp + "cls_logits.weight"], sd[rp + "bbox_pred.weight"]], 0)
+        b_head = torch.cat([sd[rp + "cls_logits.bias"], sd[rp + "bbox_pred.bias"]], 0).contiguous()
+        self.rpn_head = _Conv(w_head, None, b_head, 1, 0)
+        self.num_anchors = sd[rp + "cls_logits.weight"].shape[0]
+        self.anchors = grid_anchors(IMAGE_INPUT_SIZE, 16).to(self.device)
+        rh = "object_detector.roi_heads."
+        # RoIAlign output is [roi][bin][channel]; torchvision flattens [channel][bin] -> permute fc6's K axis
+        w6 = sd[rh + "box_head.fc6.weight"]
+        self.fc6_w = w6.view(w6.shape[0], 2048, 64).permute(0, 2, 1).reshape(w6.shape[0], -1).contiguous()
+        self.fc6_b = sd[rh + "box_head.fc6.bias"].contiguous()
+        self.fc7_w = sd[rh + "box_head.fc7.weight"].contiguous()
+        self.fc7_b = sd[rh + "box_head.fc7.bias"].contiguous()
+        self.pred_w = torch.cat([sd[rh + "box_predictor.cls_score.weight"], sd[rh + "box_predictor.bbox_pred.weight"]], 0).contiguous()
+        self.pred_b = torch.cat([sd[rh + "box_predictor.cls_score.bias"], sd[rh + "box_predictor.bbox_pred.bias"]], 0).contiguous()
+        self.dimred_w = sd[rh + "dim_reduction.weight"].contiguous()
+        self.dimred_b = sd[rh + "dim_reduction.bias"].contiguous()
+
+    def _pack_selection(self, sd):
+        c = "binary_classifier_region_selection.classifier."
+        self.sel = [(sd[c + f"{i}.weight"].contiguous(), sd[c + f"{i}.bias"].contiguous()) for i in (0, 2, 4)]
+
+    def _pack_decoder(self, sd):
+        g = "language_model.gpt_with_lm_head.transformer."
+        f = "language_model.feature_space_transformation_nn."
+        keep: List[Tensor] = []
+
+        def T(t: Tensor) -> Tensor:  # HF Conv1D [in,out] -> [out,in]
+            t = t.t().contiguous()
+            keep.append(t)
+            return t
+
+        def K(t: Tensor) -> Tensor:
+            t = t.contiguous()
+            keep.append(t)
+            return t
+
+        n_layer = 0
+        while f"{g}h.{n_layer}.ln_1.weight" in sd:
+            n_layer += 1
+        self.n_layer = n_layer
+        layers = (_hip.DecoderLayerWeights * n_layer)()
+        uk = []
+        ub = []
+        for l in range(n_layer):
+            b = f"{g}h.{l}."
+            lw = layers[l]
+            lw.ln1_g, lw.ln1_b = K(sd[b + "ln_1.weight"]).data_ptr(), K(sd[b + "ln_1.bias"]).data_ptr()
+            lw.ln2_g, lw.ln2_b = K(sd[b + "ln_2.weight"]).data_ptr(), K(sd[b + "ln_2.bias"]).data_ptr()
+            lw.c_attn_w, lw.c_attn_b = T(sd[b + "attn.c_attn.weight"]).data_ptr(), K(sd[b + "attn.c_attn.bias"]).data_ptr()
+            lw.attn_proj_w, lw.attn_proj_b = T(sd[b + "attn.c_proj.weight"]).data_ptr(), K(sd[b + "attn.c_proj.bias"]).data_ptr()
+            lw.c_fc_w, lw.c_fc_b = T(sd[b + "mlp.c_fc.weight"]).data_ptr(), K(sd[b + "mlp.c_fc.bias"]).data_ptr()
+            lw.mlp_proj_w, lw.mlp_proj_b = T(sd[b + "mlp.c_proj.weight"]).data_ptr(), K(sd[b + "mlp.c_proj.bias"]).data_ptr()
+            uk += [sd[b + "attn.uk.weight"], sd[b + "attn.uv.weight"]]
+            ub += [sd[b + "attn.uk.bias"], sd[b + "attn.uv.bias"]]
+        dw = _hip.DecoderWeights()
+        dw.n_layer, dw.d_model, dw.n_head = n_layer, 1024, 16
+        wte = K(sd[g + "wte.weight"])
+        dw.vocab = wte.shape[0]
+        dw.wte = wte.data_ptr()
+        dw.lnf_g, dw.lnf_b = K(sd[g + "ln_f.weight"]).data_ptr(), K(sd[g + "ln_f.bias"]).data_ptr()
+        dw.fst0_w, dw.fst0_b = K(sd[f + "0.weight"]).data_ptr(), K(sd[f + "0.bias"]).data_ptr()
+        dw.fst2_w, dw.fst2_b = K(sd[f + "2.weight"]).data_ptr(), K(sd[f + "2.bias"]).data_ptr()
+        dw.ukv_w, dw.ukv_b = K(torch.cat(uk, 0)).data_ptr(), K(torch.cat(ub, 0)).data_ptr()
+        dw.layers = layers
+        self._dec_weights, self._dec_layers, self._dec_keep = dw, layers, keep
+        self.vocab = dw.vocab
+
+    def close(self):
+        if self._decoder is not None:
+            self.lib.rgrg_decoder_destroy(self._decoder)
+            self._decoder = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ------------------------------------------------------------------ op wrappers
+    def linear(self, x: Tensor, w: Tensor, b: Optional[Tensor], act: int = _hip.ACT_NONE,
+               residual: Optional[Tensor] = None, splitk: Optional[int] = None) -> Tensor:
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        sk = pick_splitk(M, N, K) if splitk is None else splitk
+        ws = torch.empty((sk, M, N), dtype=torch.float32, device=x.device) if sk > 1 else None
+        _hip.check(self.lib.rgrg_linear_f32(_hip.ptr(x), _hip.ptr(w), None, _hip.ptr(b), _hip.ptr(residual), _hip.ptr(y),
+                                            M, N, K, N, act, sk, _hip.ptr(ws), _stream()), "rgrg_linear_f32")
+        return y
+
+    def conv(self, x: Tensor, c: _Conv, act: int, residual: Optional[Tensor] = None) -> Tensor:
+        B, H, W, Cin = x.shape
+        assert Cin == c.cin
+        OH = (H + 2 * c.pad - c.kh) // c.stride + 1
+        OW = (W + 2 * c.pad - c.kw) // c.stride + 1
+        y = torch.empty((B, OH, OW, c.cout), dtype=torch.float32, device=x.device)
+        M, N, K = B * OH * OW, c.cout, c.kh * c.kw * Cin
+        sk = pick_splitk(M, N, K)
+        ws = torch.empty((sk, M, N), dtype=torch.float32, device=x.device) if sk > 1 else None
+        _hip.check(self.lib.rgrg_conv2d_nhwc_f32(_hip.ptr(x), _hip.ptr(c.w), _hip.ptr(c.scale), _hip.ptr(c.shift),
+                                                 _hip.ptr(residual), _hip.ptr(y), B, H, W, Cin, c.cout, c.kh, c.kw,
+                                                 c.stride, c.pad, act, sk, _hip.ptr(ws), _stream()),
+                   "rgrg_conv2d_nhwc_f32")
+        return y
+
+    # ------------------------------------------------------------------ detector
+    def backbone(self, images: Tensor) -> Tensor:
+        """ResNet-50 trunk, [B,1,H,W] -> NHWC [B,H/32,W/32,2048]."""
+        B, Cc, H, W = images.shape
+        assert Cc == 1
+        x = images.reshape(B, H, W).contiguous()
+        y = torch.empty((B, H // 2, W // 2, 64), dtype=torch.float32, device=x.device)
+        _hip.check(self.lib.rgrg_stem_conv7x7_f32(_hip.ptr(x), _hip.ptr(self.stem_w), _hip.ptr(self.stem_scale),
+                                                  _hip.ptr(self.stem_shift), _hip.ptr(y), B, H, W, _stream()), "stem")
+        p = torch.empty((B, H // 4, W // 4, 64), dtype=torch.float32, device=x.device)
+        _hip.check(self.lib.rgrg_maxpool3x3s2_nhwc_f32(_hip.ptr(y), _hip.ptr(p), B, H // 2, W // 2, 64, _stream()), "maxpool")
+        x = p
+        for blk in self.blocks:
+            o = self.conv(x, blk["c1"], _hip.ACT_RELU)
+            o = self.conv(o, blk["c2"], _hip.ACT_RELU)
+            idt = self.conv(x, blk["ds"], _hip.ACT_NONE) if "ds" in blk else x
+            x = self.conv(o, blk["c3"], _hip.ACT_RELU, residual=idt)
+        return x
+
+    def rpn(self, feat: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        """RPN head + proposal filtering -> proposals [B,1000,4], counts [B], offsets [B+1] (device)."""
+        B, FH, FW, _ = feat.shape
+        t = self.conv(feat, self.rpn_conv, _hip.ACT_RELU)
+        head = self.conv(t, self.rpn_head, _hip.ACT_NONE)  # [B,FH,FW,800]
+        props = torch.empty((B, RPN_POST_NMS_TOP_N, 4), dtype=torch.float32, device=feat.device)
+        counts = torch.empty((B,), dtype=torch.int32, device=feat.device)
+        offsets = torch.empty((B + 1,), dtype=torch.int32, device=feat.device)
+        size = float(IMAGE_INPUT_SIZE)
+        _hip.check(self.lib.rgrg_rpn_proposals_f32(_hip.ptr(head), _hip.ptr(self.anchors), _hip.ptr(props),
+                                                   _hip.ptr(counts), _hip.ptr(offsets), B, FH * FW, self.num_anchors,
+                                                   RPN_PRE_NMS_TOP_N, RPN_POST_NMS_TOP_N, RPN_NMS_THRESH, 1e-3, size,
+                                                   size, _stream()), "rgrg_rpn_proposals_f32")
+        return props, counts, offsets
+
+    def roi_heads(self, feat: Tensor, props: Tensor, offsets: Tensor, taps: Optional[dict] = None):
+        B, FH, FW, Cf = feat.shape
+        R = int(offsets[-1].item())  # host sync #1: number of RoIs sizes the box-head launches
+        dev = feat.device
+        cd = torch.zeros((B, NUM_REGIONS), dtype=torch.uint8, device=dev)
+        scores = torch.zeros((B, NUM_REGIONS), dtype=torch.float32, device=dev)
+        boxes = torch.zeros((B, NUM_REGIONS, 4), dtype=torch.float32, device=dev)
+        feats = torch.zeros((B, NUM_REGIONS, Cf), dtype=torch.float32, device=dev)
+        if R > 0:
+            pooled_maps = torch.empty((R, 64, Cf), dtype=torch.float32, device=dev)
+            pooled = torch.empty((R, Cf), dtype=torch.float32, device=dev)
+            scale = 2.0 ** round(__import__("math").log2(FH / IMAGE_INPUT_SIZE))
+            _hip.check(self.lib.rgrg_roi_align_avgpool_f32(_hip.ptr(feat), _hip.ptr(props), _hip.ptr(offsets),
+                                                           _hip.ptr(pooled_maps), _hip.ptr(pooled), B, FH, FW, Cf,
+                                                           props.shape[1], R, scale, _stream()), "rgrg_roi_align")
+            h = self.linear(pooled_maps.view(R, 64 * Cf), self.fc6_w, self.fc6_b, _hip.ACT_RELU)
+            h = self.linear(h, self.fc7_w, self.fc7_b, _hip.ACT_RELU)
+            pred = self.linear(h, self.pred_w, self.pred_b)  # [R,150]: 30 class logits | 120 deltas
+            size = float(IMAGE_INPUT_SIZE)
+            _hip.check(self.lib.rgrg_top1_per_class_f32(_hip.ptr(pred), pred.shape[1], _hip.ptr(props), _hip.ptr(offsets),
+                                                        _hip.ptr(pooled), _hip.ptr(cd), _hip.ptr(scores), _hip.ptr(boxes),
+                                                        _hip.ptr(feats), B, Cf, props.shape[1], size, size, _stream()),
+                       "rgrg_top1_per_class_f32")
+            if taps is not None:
+                taps.update(pooled_maps=pooled_maps, pooled=pooled, pred=pred)
+        top = self.linear(feats.view(B * NUM_REGIONS, Cf), self.dimred_w, self.dimred_b).view(B, NUM_REGIONS, -1)
+        return cd.bool(), scores, boxes, top
+
+    def detect(self, images: Tensor, taps: Optional[dict] = None):
+        """ObjectDetector.forward (inference): -> (detections, top_region_features, class_detected)."""
+        _require_gpu(images.device)
+        images = images.to(torch.float32)
+        feat = self.backbone(images)
+        props, counts, offsets = self.rpn(feat)
+        cd, scores, boxes, top = self.roi_heads(feat, props, offsets, taps)
+        if taps is not None:
+            taps.update(features_nhwc=feat, proposals=props, counts=counts, offsets=offsets)
+        return {"top_region_boxes": boxes, "top_scores": scores}, top, cd
+
+    # ------------------------------------------------------------------ selection
+    def select(self, top_region_features: Tensor, class_detected: Tensor, taps: Optional[dict] = None):
+        B, Rg, D = top_region_features.shape
+        x = top_region_features.reshape(B * Rg, D).contiguous().to(torch.float32)
+        h = self.linear(x, *self.sel[0], act=_hip.ACT_RELU)
+        h = self.linear(h, *self.sel[1], act=_hip.ACT_RELU)
+        logits = self.linear(h, *self.sel[2]).view(-1)
+        n = B * Rg
+        det = class_detected.reshape(-1).to(torch.uint8).contiguous()
+        sel = torch.empty((n,), dtype=torch.uint8, device=x.device)
+        rows = torch.empty((n,), dtype=torch.int32, device=x.device)
+        nsel = torch.empty((1,), dtype=torch.int32, device=x.device)
+        _hip.check(self.lib.rgrg_select_regions_f32(_hip.ptr(logits), _hip.ptr(det), SELECTION_LOGIT_THRESHOLD,
+                                                    _hip.ptr(sel), _hip.ptr(rows), _hip.ptr(nsel), n, _stream()),
+                   "rgrg_select_regions_f32")
+        S = int(nsel.item())  # host sync #2 (the reference syncs here too: report_generation_model.py:260)
+        feats = torch.empty((S, D), dtype=torch.float32, device=x.device)
+        if S > 0:
+            _hip.check(self.lib.rgrg_gather_rows_f32(_hip.ptr(x), _hip.ptr(rows), _hip.ptr(feats), S, D, _stream()),
+                       "rgrg_gather_rows_f32")
+        if taps is not None:
+            taps.update(selection_logits=logits.view(B, Rg))
+        return sel.view(B, Rg).bool(), feats
+
+    # ------------------------------------------------------------------ decoder
+    def _get_decoder(self, S: int, max_len: int):
+        cap_s, cap_l = self._decoder_caps
+        if self._decoder is None or S > cap_s or max_len > cap_l:
+            self.close()
+            cap_s = max(32, ((S + 31) // 32) * 32, cap_s)
+            cap_l = max(max_len, cap_l)
+            h = C.c_void_p()
+            _hip.check(self.lib.rgrg_decoder_create(C.byref(self._dec_weights), cap_s, cap_l, C.byref(h)),
+                       "rgrg_decoder_create")
+            self._decoder, self._decoder_caps = h, (cap_s, cap_l)
+        return self._decoder
+
+    def greedy_decode(self, feats: Tensor, max_length: Optional[int], use_graph: bool = True) -> Tensor:
+        """LanguageModel.generate(num_beams=1): feats [S,1024] -> int64 [S, L']."""
+        _require_gpu(feats.device)
+        S = feats.shape[0]
+        limit = int(max_length) if max_length else 1024  # reference has no bound when None; positions stop at 1024
+        dec = self._get_decoder(S, limit)
+        feats = feats.to(torch.float32).contiguous()
+        out = torch.empty((S, limit), dtype=torch.int64, device=feats.device)
+        out_len = C.c_int(0)
+        _hip.check(self.lib.rgrg_decoder_generate(dec, _hip.ptr(feats), S, limit, _hip.ptr(out), limit,
+                                                  C.byref(out_len), 1 if use_graph else 0, _stream()),
+                   "rgrg_decoder_generate")
+        return out[:, :out_len.value].contiguous()
+
+    def last_logits(self, S: int) -> Tensor:
+        dst = torch.empty((S, self.vocab), dtype=torch.float32, device=self.device)
+        _hip.check(self.lib.rgrg_decoder_copy_last_logits(self._decoder, _hip.ptr(dst), S, _stream()), "copy_last_logits")
+        return dst
+
+    def time_decode_gemms(self, S: int, iters: int = 3) -> Tuple[float, float, int]:
+        """(avg ms per decode step spent in the weight-streaming GEMM launches, algorithmic
+        weight bytes per step, launches per step) measured with HIP events on the decoder's stream."""
+        ms, nbytes, n = C.c_float(0), C.c_double(0), C.c_int(0)
+        _hip.check(self.lib.rgrg_decoder_time_gemms(self._decoder, S, iters, C.byref(ms), C.byref(nbytes), C.byref(n)),
+                   "rgrg_decoder_time_gemms")
+        return ms.value / iters, nbytes.value, n.value
