@@ -1,0 +1,130 @@
+"""Host-side mirror of ``src/language_model/language_model.py`` (ttanida/rgrg).
+
+``LanguageModel`` keeps the reference's module tree - and therefore its state-dict keys,
+including the three aliased copies of every GPT-2 tensor (``gpt_with_lm_head.transformer.*``,
+``gpt.*``, ``gpt2_blocks.N.{0,1,2,3}.*``) and the pseudo-attention buffers - but holds
+parameters only.  ``generate`` (language_model.py:401-479) keeps the reference's mode
+checks and exceptions; the greedy mode runs on the HIP decoder, beam search is the next
+row of SURVEY.md 8(f).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ._owner import EngineOwner
+from .constants import BOS_TOKEN_ID, EOS_TOKEN_ID, PAD_TOKEN_ID
+
+N_LAYER, D_MODEL, VOCAB, N_POS = 24, 1024, 50257, 1024
+
+
+class Conv1DWithTrainedWeights(nn.Module):
+    """HF Conv1D layout: weight [in,out] (language_model.py:11-29)."""
+
+    def __init__(self, nin: int, nout: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(nin, nout), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(nout), requires_grad=False)
+
+
+class GPT2PseudoAttention(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.c_attn = Conv1DWithTrainedWeights(D_MODEL, 3 * D_MODEL)
+        self.c_proj = Conv1DWithTrainedWeights(D_MODEL, D_MODEL)
+        self.embed_dim, self.num_heads, self.head_dim, self.split_size = D_MODEL, 16, 64, D_MODEL
+        # buffers of the reference state dict (language_model.py:60-70); the decode kernels need neither:
+        # a single-query causal row and the all-ones padding mask are no-ops in greedy generation
+        self.register_buffer("causal_mask", torch.tril(torch.ones((N_POS, N_POS), dtype=torch.uint8)).view(1, 1, N_POS, N_POS))
+        self.register_buffer("mask_out_value", torch.tensor(-1e4))
+        self.uk = nn.Linear(D_MODEL, D_MODEL)
+        self.uv = nn.Linear(D_MODEL, D_MODEL)
+
+
+class GPT2MLP(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.c_fc = Conv1DWithTrainedWeights(D_MODEL, 4 * D_MODEL)
+        self.c_proj = Conv1DWithTrainedWeights(4 * D_MODEL, D_MODEL)
+
+
+class GPT2Block(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.ln_1 = nn.LayerNorm(D_MODEL, eps=1e-5)
+        self.attn = GPT2PseudoAttention()
+        self.ln_2 = nn.LayerNorm(D_MODEL, eps=1e-5)
+        self.mlp = GPT2MLP()
+
+
+class GPT2Transformer(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.wte = nn.Embedding(VOCAB, D_MODEL)
+        self.wpe = nn.Embedding(N_POS, D_MODEL)
+        self.drop = nn.Dropout(0.1)
+        self.h = nn.ModuleList(GPT2Block() for _ in range(N_LAYER))
+        self.ln_f = nn.LayerNorm(D_MODEL, eps=1e-5)
+
+
+class GPT2LMHeadSkeleton(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.transformer = GPT2Transformer()
+        self.lm_head = nn.Linear(D_MODEL, VOCAB, bias=False)
+        self.lm_head.weight = self.transformer.wte.weight  # tied
+
+
+class LanguageModel(EngineOwner):
+    _engine_prefix = "language_model."
+
+    def __init__(self):
+        super().__init__()
+        self.checkpoint = "healx/gpt-2-pubmed-medium"  # not downloaded: weights come from load_state_dict
+        self.bos_token_id, self.eos_token_id, self.pad_token_id = BOS_TOKEN_ID, EOS_TOKEN_ID, PAD_TOKEN_ID
+        self.gpt_with_lm_head = GPT2LMHeadSkeleton()
+        for p in self.gpt_with_lm_head.parameters():
+            p.requires_grad = False
+        # the same aliases the reference creates (language_model.py:215-227)
+        self.gpt = self.gpt_with_lm_head.transformer
+        self.lm_head = self.gpt_with_lm_head.lm_head
+        self.wte, self.wpe, self.drop = self.gpt.wte, self.gpt.wpe, self.gpt.drop
+        self.final_layernorm = self.gpt.ln_f
+        self.gpt2_blocks = nn.ModuleList(nn.ModuleList([b.ln_1, b.attn, b.ln_2, b.mlp]) for b in self.gpt.h)
+        self.feature_space_transformation_nn = nn.Sequential(nn.Linear(1024, 1024), nn.ReLU(), nn.Linear(1024, 1024))
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("teacher-forced LanguageModel.forward (training/eval loss) is SURVEY.md 8(f); "
+                                  "the HIP path implements generate()")
+
+    @torch.no_grad()
+    def generate(self, image_hidden_states: torch.FloatTensor, max_length: Optional[int] = None, num_beams: int = 1,
+                 num_beam_groups: int = 1, do_sample: bool = False, num_return_sequences: int = 1,
+                 early_stopping: bool = False) -> torch.LongTensor:
+        """Same contract as language_model.py:401-479: int64 [S, L'] incl. the leading BOS."""
+        is_greedy = (num_beams == 1) and (num_beam_groups == 1) and do_sample is False
+        is_sample = (num_beams == 1) and (num_beam_groups == 1) and do_sample is True
+        is_beam = (num_beams > 1) and (num_beam_groups == 1) and do_sample is False
+        is_beam_sample = (num_beams > 1) and (num_beam_groups == 1) and do_sample is True
+        is_group_beam = (num_beams > 1) and (num_beam_groups > 1)
+        if num_beam_groups > num_beams:
+            raise ValueError("'num_beam_groups' has to be smaller or equal to 'num_beams'")
+        if is_group_beam and do_sample is True:
+            raise ValueError("Diverse beam search cannot be used in sampling mode. Make sure that 'do_sample' is set to 'False'.")
+        if is_greedy:
+            if num_return_sequences > 1:
+                raise ValueError(f"num_return_sequences has to be 1, but is {num_return_sequences} when doing greedy search.")
+            return self.engine().greedy_decode(image_hidden_states, max_length)
+        if is_sample:
+            raise NotImplementedError("Multinomial sampling is not implemented.")
+        if is_beam:
+            if num_return_sequences > num_beams:
+                raise ValueError("'num_return_sequences' has to be smaller or equal to 'num_beams'.")
+            if max_length is None:
+                raise ValueError("max_length has to be set for beam generation.")
+            raise NotImplementedError("beam search on the HIP path is the next row of SURVEY.md 8(f); use num_beams=1")
+        if is_beam_sample:
+            raise NotImplementedError("Beam-search multinomial sampling is not implemented.")
+        raise NotImplementedError("Diverse beam-search decoding is not implemented.")

@@ -1,0 +1,112 @@
+"""Host-side mirror of ``src/full_model/report_generation_model.py`` (ttanida/rgrg).
+
+Drop-in for the inference hot path: same constructor, sub-module attribute names,
+``load_state_dict(checkpoint["model"])`` keys and ``generate()`` signature / return
+tuple / ``-1`` sentinel (report_generation_model.py:12-33, :212-276).
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+from torch import Tensor
+
+from ._owner import EngineOwner
+from .binary_classifier import BinaryClassifierRegionAbnormal, BinaryClassifierRegionSelection
+from .language_model import LanguageModel
+from .object_detector import ObjectDetector
+
+_LM = "language_model."
+_G = _LM + "gpt_with_lm_head.transformer."
+_BLOCK_SUB = {"ln_1": "0", "attn": "1", "ln_2": "2", "mlp": "3"}
+
+
+def expand_alias_keys(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """The reference state dict holds every GPT-2 tensor under three aliased key families
+    (SURVEY.md 8(b)).  Accept a dict that carries only one family (canonical
+    ``gpt_with_lm_head.transformer.*``, ``gpt.*`` or ``gpt2_blocks.*`` + ``wte/wpe/...``)
+    by filling in the others; also accept the pre-0.13 ``rpn.head.conv.{weight,bias}``
+    names (generate_reports_for_images.py:156-159)."""
+    out = dict(sd)
+    for old, new in (("object_detector.rpn.head.conv.weight", "object_detector.rpn.head.conv.0.0.weight"),
+                     ("object_detector.rpn.head.conv.bias", "object_detector.rpn.head.conv.0.0.bias")):
+        if old in out and new not in out:
+            out[new] = out.pop(old)
+    # gpt.* / gpt2_blocks.* / top-level -> canonical
+    for k in list(out):
+        if k.startswith(_LM + "gpt."):
+            out.setdefault(_G + k[len(_LM + "gpt."):], out[k])
+        elif k.startswith(_LM + "gpt2_blocks."):
+            n, sub, *rest = k[len(_LM + "gpt2_blocks."):].split(".")
+            name = {v: kk for kk, v in _BLOCK_SUB.items()}[sub]
+            out.setdefault(f"{_G}h.{n}.{name}." + ".".join(rest), out[k])
+    for top, canon in ((_LM + "wte.weight", _G + "wte.weight"), (_LM + "wpe.weight", _G + "wpe.weight"),
+                       (_LM + "final_layernorm.weight", _G + "ln_f.weight"), (_LM + "final_layernorm.bias", _G + "ln_f.bias"),
+                       (_LM + "lm_head.weight", _LM + "gpt_with_lm_head.lm_head.weight")):
+        if top in out:
+            out.setdefault(canon, out[top])
+    if _G + "wte.weight" in out:
+        out.setdefault(_LM + "gpt_with_lm_head.lm_head.weight", out[_G + "wte.weight"])
+    # canonical -> aliases
+    for k in [k for k in out if k.startswith(_G)]:
+        rest = k[len(_G):]
+        out.setdefault(_LM + "gpt." + rest, out[k])
+        parts = rest.split(".")
+        if parts[0] == "h":
+            out.setdefault(f"{_LM}gpt2_blocks.{parts[1]}.{_BLOCK_SUB[parts[2]]}." + ".".join(parts[3:]), out[k])
+        elif parts[0] in ("wte", "wpe"):
+            out.setdefault(f"{_LM}{parts[0]}.weight", out[k])
+        elif parts[0] == "ln_f":
+            out.setdefault(_LM + "final_layernorm." + parts[1], out[k])
+    if _LM + "gpt_with_lm_head.lm_head.weight" in out:
+        out.setdefault(_LM + "lm_head.weight", out[_LM + "gpt_with_lm_head.lm_head.weight"])
+    return out
+
+
+class ReportGenerationModel(EngineOwner):
+    """Object detector encoder -> region-selection classifier -> language-model decoder."""
+
+    def __init__(self, pretrain_without_lm_model: bool = False):
+        super().__init__()
+        self.pretrain_without_lm_model = pretrain_without_lm_model
+        self.object_detector = ObjectDetector(return_feature_vectors=True)
+        self.binary_classifier_region_selection = BinaryClassifierRegionSelection()
+        self.binary_classifier_region_abnormal = BinaryClassifierRegionAbnormal()
+        self.language_model = LanguageModel()
+        for child in (self.object_detector, self.binary_classifier_region_selection, self.language_model):
+            self._adopt(child)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        """Loads a reference ``checkpoint["model"]`` unchanged.  Missing alias families and the
+        persistent buffers the kernels do not need (``causal_mask``, ``mask_out_value``,
+        ``num_batches_tracked``, ``pos_weight``) are filled from the module; anything else that
+        is missing or unexpected is reported (raised when ``strict``), never silently dropped."""
+        sd = expand_alias_keys(state_dict)
+        own = self.state_dict()
+        optional = ("causal_mask", "mask_out_value", "num_batches_tracked", "loss_fn.pos_weight")
+        for k, v in own.items():
+            if k not in sd and k.endswith(optional):
+                sd[k] = v
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("ReportGenerationModel.forward (training / eval losses, report_generation_model.py:35-168) "
+                                  "is SURVEY.md 8(f) 'next'; the HIP path implements generate()")
+
+    @torch.no_grad()
+    def generate(self, images: torch.FloatTensor, max_length: int = None, num_beams: int = 1, num_beam_groups: int = 1,
+                 do_sample: bool = False, num_return_sequences: int = 1, early_stopping: bool = False):
+        """images [B,1,512,512] -> (output_ids int64 [S,L'], selected_regions bool [B,29],
+        detections {top_region_boxes [B,29,4], top_scores [B,29]}, class_detected bool [B,29]) or ``-1``
+        when no region is both detected and selected (report_generation_model.py:260-261)."""
+        _, detections, top_region_features, class_detected = self.object_detector(images)
+        del images
+        selected_regions, selected_region_features = self.binary_classifier_region_selection(
+            top_region_features, class_detected, return_loss=False)
+        del top_region_features
+        if selected_region_features.shape[0] == 0:
+            return -1
+        output_ids = self.language_model.generate(selected_region_features, max_length, num_beams, num_beam_groups,
+                                                  do_sample, num_return_sequences, early_stopping)
+        del selected_region_features
+        return output_ids, selected_regions, detections, class_detected

@@ -1,0 +1,300 @@
+"""Parity of every C-ABI entry point (librgrg_hip.so, called through ctypes) against the
+CPU oracle on identical seeded inputs.  Tolerances are written next to each check:
+integer / index / mask outputs are bit-exact, fp32 outputs are compared with the stated
+absolute+relative bound (different summation order of fp32 MFMA vs the CPU BLAS)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import gpu_model, synth_sd
+from oracle import detector as o_det
+from oracle import full_model as o_full
+from oracle import tv013
+from rgrg_amd import _hip, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def close(a, b, rtol, atol_frac, what):
+    """|a-b| <= atol_frac*max|b| + rtol*|b| elementwise; reports the worst offender."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    tol = atol_frac * b.abs().max() + rtol * b.abs()
+    err = (a - b).abs()
+    bad = err > tol
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max abs err "
+                           f"{err.max().item():.3e} (ref max {b.abs().max().item():.3e})")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return gpu_model("bench").engine()
+
+
+@pytest.fixture(scope="module")
+def oracle_bench():
+    """CPU oracle intermediates for two synthetic images (computed once)."""
+    sd = synth_sd("bench")
+    images = torch.cat([synth.make_images(1, 1234), synth.make_images(1, 77)], 0)
+    out = o_det.object_detector_forward(sd, images, return_intermediates=True)
+    obj, reg = tv013.rpn_head(sd, "object_detector.rpn.head.", out["_features"])
+    out["_rpn_obj"], out["_rpn_reg"], out["_images"] = obj, reg, images
+    return out
+
+
+# ------------------------------------------------------------------------- GEMM / conv
+@pytest.mark.parametrize("M,N,K,act,res,splitk", [
+    (29, 1024, 1024, 0, True, 1), (823, 1024, 4096, 1, False, 4), (100, 150, 1024, 0, False, 1),
+    (58, 1, 128, 0, False, 1), (300, 800, 2048, 2, False, 1), (1, 1024, 2048, 0, False, 2), (257, 129, 96, 1, True, 1)])
+def test_linear_f32(eng, M, N, K, act, res, splitk):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn((M, K), generator=g)
+    W = torch.randn((N, K), generator=g) / math.sqrt(K)
+    b = torch.randn((N,), generator=g)
+    R = torch.randn((M, N), generator=g) if res else None
+    ref = A.double() @ W.double().t() + b.double()
+    if res:
+        ref = ref + R.double()
+    ref = {0: lambda x: x, 1: F.relu, 2: lambda x: F.gelu(x, approximate="tanh")}[act](ref)
+    y = eng.linear(A.to(DEV), W.to(DEV), b.to(DEV), act, R.to(DEV) if res else None, splitk=splitk)
+    close(y, ref, 2e-5, 2e-6, f"linear {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride,pad,res", [
+    (2, 32, 64, 256, 1, 1, 0, True), (2, 16, 64, 64, 3, 1, 1, False), (1, 32, 128, 128, 3, 2, 1, False),
+    (2, 16, 256, 512, 1, 2, 0, False), (1, 16, 2048, 160, 1, 1, 0, False)])
+def test_conv2d_nhwc_f32(eng, B, H, Cin, Cout, k, stride, pad, res):
+    from rgrg_amd.engine import _Conv
+    g = torch.Generator().manual_seed(B * 100 + Cin + k)
+    x = torch.randn((B, Cin, H, H), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / math.sqrt(Cin * k * k)
+    scale = torch.rand((Cout,), generator=g) + 0.5
+    shift = torch.randn((Cout,), generator=g)
+    ref = F.conv2d(x.double(), w.double(), stride=stride, padding=pad) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    R = None
+    if res:
+        R = torch.randn(ref.shape, generator=g)
+        ref = ref + R.double()
+    ref = F.relu(ref)
+    conv = _Conv(w.to(DEV), scale.to(DEV), shift.to(DEV), stride, pad)
+    y = eng.conv(x.permute(0, 2, 3, 1).contiguous().to(DEV), conv, _hip.ACT_RELU,
+                 R.permute(0, 2, 3, 1).contiguous().to(DEV) if res else None)
+    close(y.permute(0, 3, 1, 2), ref, 2e-5, 2e-6, f"conv k{k} s{stride}")
+
+
+def test_stem_and_maxpool(eng):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 1, 64, 96), generator=g)
+    w = torch.randn((64, 1, 7, 7), generator=g) / 7.0
+    scale, shift = torch.rand((64,), generator=g) + 0.5, torch.randn((64,), generator=g)
+    ref = F.relu(F.conv2d(x.double(), w.double(), stride=2, padding=3) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    y = torch.empty((2, 32, 48, 64), device=DEV)
+    wt = w.reshape(64, 49).t().contiguous().to(DEV)
+    _hip.check(eng.lib.rgrg_stem_conv7x7_f32(x.to(DEV).data_ptr(), wt.data_ptr(), scale.to(DEV).data_ptr(),
+                                             shift.to(DEV).data_ptr(), y.data_ptr(), 2, 64, 96, _stream()))
+    close(y.permute(0, 3, 1, 2), ref, 1e-5, 1e-6, "stem conv7x7+bn+relu")
+    p = torch.empty((2, 16, 24, 64), device=DEV)
+    _hip.check(eng.lib.rgrg_maxpool3x3s2_nhwc_f32(y.data_ptr(), p.data_ptr(), 2, 32, 48, 64, _stream()))
+    refp = F.max_pool2d(y.permute(0, 3, 1, 2).cpu(), 3, 2, 1)
+    assert torch.equal(p.permute(0, 3, 1, 2).cpu(), refp)  # max is exact
+
+
+def test_backbone_vs_oracle(eng, oracle_bench):
+    feat = eng.backbone(oracle_bench["_images"].to(DEV)).permute(0, 3, 1, 2)
+    # 53 stacked convs in fp32 with a different summation order: 1e-4 of the map's max + 1e-3 relative
+    close(feat, oracle_bench["_features"], 1e-3, 1e-4, "ResNet-50 trunk features")
+
+
+# ------------------------------------------------------------------------- RPN proposals
+def _run_proposals(eng, head, B):
+    props = torch.empty((B, 1000, 4), device=DEV)
+    counts = torch.empty((B,), dtype=torch.int32, device=DEV)
+    offsets = torch.empty((B + 1,), dtype=torch.int32, device=DEV)
+    _hip.check(eng.lib.rgrg_rpn_proposals_f32(head.data_ptr(), eng.anchors.data_ptr(), props.data_ptr(), counts.data_ptr(),
+                                              offsets.data_ptr(), B, 256, 160, 1000, 1000, 0.7, 1e-3, 512.0, 512.0, _stream()))
+    return props.cpu(), counts.cpu(), offsets.cpu()
+
+
+def _head_nhwc(obj, reg):
+    B = obj.shape[0]
+    return torch.cat([obj.permute(0, 2, 3, 1).reshape(B, 256, 160), reg.permute(0, 2, 3, 1).reshape(B, 256, 640)], 2).contiguous()
+
+
+def _oracle_proposals(obj, reg):
+    B = obj.shape[0]
+    anchors = tv013.grid_anchors((512, 512), (16, 16))
+    objectness = tv013.permute_and_flatten(obj, 1).reshape(B, -1)
+    deltas = tv013.permute_and_flatten(reg, 4).reshape(-1, 4)
+    proposals = tv013.box_decode(deltas, anchors.repeat(B, 1), (1.0, 1.0, 1.0, 1.0)).view(B, -1, 4)
+    return tv013.filter_proposals(proposals, objectness, (512, 512))[0]
+
+
+def test_anchors_match_oracle(eng):
+    assert torch.equal(eng.anchors.cpu(), tv013.grid_anchors((512, 512), (16, 16)))
+
+
+def test_rpn_proposals_on_oracle_head(eng, oracle_bench):
+    obj, reg = oracle_bench["_rpn_obj"], oracle_bench["_rpn_reg"]
+    props, counts, offsets = _run_proposals(eng, _head_nhwc(obj, reg).to(DEV), 2)
+    ref = oracle_bench["_proposals"]
+    assert counts.tolist() == [p.shape[0] for p in ref]          # same survivors (integer: exact)
+    assert offsets.tolist() == [0, ref[0].shape[0], ref[0].shape[0] + ref[1].shape[0]]
+    for b in range(2):
+        n = ref[b].shape[0]
+        # coordinates go through expf (device vs host libm differ by <= 1 ulp): 1e-4 px absolute
+        assert (props[b, :n] - ref[b]).abs().max() <= 1e-4, (props[b, :n] - ref[b]).abs().max()
+        assert (props[b, n:] == 0).all()
+
+
+def test_rpn_proposals_ties_small_boxes_and_heavy_overlap(eng):
+    g = torch.Generator().manual_seed(11)
+    obj = torch.zeros((1, 160, 16, 16))                       # massive ties: lower index must win
+    obj.view(-1)[torch.randperm(40960, generator=g)[:300]] = 1.0
+    reg = torch.randn((1, 640, 16, 16), generator=g) * 0.05   # near-duplicate boxes -> long NMS chains
+    reg.view(1, 160, 4, 16, 16)[:, ::7, 2] = -20.0            # exp(-20)*w < 1e-3 -> dropped as too small
+    props, counts, _ = _run_proposals(eng, _head_nhwc(obj, reg).to(DEV), 1)
+    ref = _oracle_proposals(obj, reg)[0]
+    assert counts[0] == ref.shape[0]
+    assert (props[0, :ref.shape[0]] - ref).abs().max() <= 1e-4
+
+
+# ------------------------------------------------------------------------- RoIAlign + avg pool
+def _pad_props(plist):
+    B = len(plist)
+    props = torch.zeros((B, 1000, 4))
+    offs = [0]
+    for b, p in enumerate(plist):
+        props[b, :p.shape[0]] = p
+        offs.append(offs[-1] + p.shape[0])
+    return props, torch.tensor(offs, dtype=torch.int32)
+
+
+def _run_roi(eng, feat_nchw, plist):
+    props, offs = _pad_props(plist)
+    R = int(offs[-1])
+    B, Cc, FH, FW = feat_nchw.shape
+    out = torch.empty((R, 64, Cc), device=DEV)
+    pooled = torch.empty((R, Cc), device=DEV)
+    fn = feat_nchw.permute(0, 2, 3, 1).contiguous().to(DEV)
+    _hip.check(eng.lib.rgrg_roi_align_avgpool_f32(fn.data_ptr(), props.to(DEV).data_ptr(), offs.to(DEV).data_ptr(), out.data_ptr(),
+                                                  pooled.data_ptr(), B, FH, FW, Cc, 1000, R, 1.0 / 32, _stream()))
+    return out.cpu().view(R, 8, 8, Cc).permute(0, 3, 1, 2), pooled.cpu()
+
+
+def test_roi_align_on_oracle_features(eng, oracle_bench):
+    feat, plist = oracle_bench["_features"], [p[:200] for p in oracle_bench["_proposals"]]
+    out, pooled = _run_roi(eng, feat, plist)
+    rois = torch.cat([torch.cat([torch.full((p.shape[0], 1), float(i)), p], 1) for i, p in enumerate(plist)], 0)
+    ref = tv013.roi_align(feat, rois, 1.0 / 32, 8, 2)
+    # same operation order with FP contraction off -> bit-exact
+    assert torch.equal(out, ref), f"max abs diff {(out - ref).abs().max().item():.3e}"
+    close(pooled, F.avg_pool2d(ref, 8).flatten(1), 1e-6, 1e-6, "8x8 average pool")
+
+
+def test_roi_align_edge_boxes(eng):
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn((1, 256, 16, 16), generator=g)
+    boxes = torch.tensor([[0.0, 0.0, 512.0, 512.0], [500.0, 500.0, 512.0, 512.0], [100.0, 100.0, 100.5, 100.2],
+                          [0.0, 0.0, 1e-3, 1e-3], [31.9, 64.0, 480.1, 96.0], [200.0, 0.0, 232.0, 512.0]])
+    out, pooled = _run_roi(eng, feat, [boxes])
+    rois = torch.cat([torch.zeros((boxes.shape[0], 1)), boxes], 1)
+    ref = tv013.roi_align(feat, rois, 1.0 / 32, 8, 2)
+    assert torch.equal(out, ref), f"max abs diff {(out - ref).abs().max().item():.3e}"
+
+
+# ------------------------------------------------------------------------- top-1 per class
+def test_top1_per_class_on_oracle_inputs(eng, oracle_bench):
+    plist = oracle_bench["_proposals"]
+    props, offs = _pad_props(plist)
+    pred = torch.cat([oracle_bench["_class_logits"], oracle_bench["_box_regression"]], 1).contiguous()
+    pooled = oracle_bench["_pooled_avg"].contiguous()
+    B = 2
+    cd = torch.zeros((B, 29), dtype=torch.uint8, device=DEV)
+    sc = torch.zeros((B, 29), device=DEV)
+    bx = torch.zeros((B, 29, 4), device=DEV)
+    ft = torch.zeros((B, 29, 2048), device=DEV)
+    _hip.check(eng.lib.rgrg_top1_per_class_f32(pred.to(DEV).data_ptr(), 150, props.to(DEV).data_ptr(), offs.to(DEV).data_ptr(),
+                                               pooled.to(DEV).data_ptr(), cd.data_ptr(), sc.data_ptr(), bx.data_ptr(), ft.data_ptr(),
+                                               B, 2048, 1000, 512.0, 512.0, _stream()))
+    ref_cd, ref_ft, ref_bx, ref_sc = o_det.top_region_postprocess(pooled, oracle_bench["_box_regression"],
+                                                                  oracle_bench["_class_logits"], plist, [(512, 512)] * 2)
+    assert torch.equal(cd.cpu().bool(), ref_cd)
+    assert torch.equal(ft.cpu(), ref_ft)                         # pure gather: exact (=> same arg-max boxes)
+    close(sc, ref_sc, 1e-5, 1e-6, "top scores (softmax through expf)")
+    assert (bx.cpu() - ref_bx).abs().max() <= 1e-3               # pixels; decode goes through expf
+
+
+def test_top1_per_class_undetected_and_empty_image(eng):
+    g = torch.Generator().manual_seed(2)
+    n0 = 50
+    logits = torch.randn((n0, 30), generator=g)
+    logits[:, 5] = -50.0                                         # region 4 never wins -> undetected, score 0, index 0
+    deltas = torch.randn((n0, 120), generator=g) * 0.1
+    boxes0 = torch.rand((n0, 2), generator=g) * 300
+    plist = [torch.cat([boxes0, boxes0 + 50 + torch.rand((n0, 2), generator=g) * 100], 1), torch.zeros((0, 4))]
+    props, offs = _pad_props(plist)
+    pooled = torch.randn((n0, 256), generator=g)
+    pred = torch.cat([logits, deltas], 1).contiguous()
+    cd = torch.ones((2, 29), dtype=torch.uint8, device=DEV)
+    sc, bx, ft = torch.ones((2, 29), device=DEV), torch.ones((2, 29, 4), device=DEV), torch.ones((2, 29, 256), device=DEV)
+    _hip.check(eng.lib.rgrg_top1_per_class_f32(pred.to(DEV).data_ptr(), 150, props.to(DEV).data_ptr(), offs.to(DEV).data_ptr(),
+                                               pooled.to(DEV).data_ptr(), cd.data_ptr(), sc.data_ptr(), bx.data_ptr(), ft.data_ptr(),
+                                               2, 256, 1000, 512.0, 512.0, _stream()))
+    ref_cd, ref_ft, ref_bx, ref_sc = o_det.top_region_postprocess(pooled, deltas, logits, plist[:1], [(512, 512)])
+    assert torch.equal(cd.cpu()[0].bool(), ref_cd[0]) and not ref_cd[0, 4]
+    assert torch.equal(ft.cpu()[0], ref_ft[0]) and torch.equal(ft.cpu()[0, 4], pooled[0])
+    assert sc.cpu()[0, 4] == 0.0
+    assert (bx.cpu()[0] - ref_bx[0]).abs().max() <= 1e-3
+    assert not cd.cpu()[1].any() and (sc.cpu()[1] == 0).all() and (ft.cpu()[1] == 0).all()  # image without proposals
+
+
+# ------------------------------------------------------------------------- selection
+def test_select_regions_and_gather(eng):
+    g = torch.Generator().manual_seed(8)
+    n = 29 * 70  # > 1024: exercises the chunked ordered compaction
+    logits = torch.randn((n,), generator=g) - 1.0
+    logits[::13] = -1.0                                          # threshold is strict: exactly -1 is NOT selected
+    det = (torch.rand((n,), generator=g) > 0.3)
+    sel = torch.empty((n,), dtype=torch.uint8, device=DEV)
+    rows = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    _hip.check(eng.lib.rgrg_select_regions_f32(logits.to(DEV).data_ptr(), det.to(torch.uint8).to(DEV).data_ptr(), -1.0,
+                                               sel.data_ptr(), rows.data_ptr(), cnt.data_ptr(), n, _stream()))
+    ref = (logits > -1) & det
+    assert torch.equal(sel.cpu().bool(), ref)
+    S = int(cnt.item())
+    assert S == int(ref.sum()) and torch.equal(rows.cpu()[:S].long(), ref.nonzero().flatten())
+    src = torch.randn((n, 64), generator=g)
+    dst = torch.empty((S, 64), device=DEV)
+    _hip.check(eng.lib.rgrg_gather_rows_f32(src.to(DEV).data_ptr(), rows.data_ptr(), dst.data_ptr(), S, 64, _stream()))
+    assert torch.equal(dst.cpu(), src[ref])
+
+
+def test_selection_head_vs_oracle(eng, oracle_bench):
+    sd = synth_sd("bench")
+    trf, cd = oracle_bench["top_region_features"], oracle_bench["class_detected"]
+    taps = {}
+    sel, feats = eng.select(trf.to(DEV), cd.to(DEV), taps)
+    ref_sel, ref_feats, ref_logits = o_full.region_selection(sd, trf, cd)
+    close(taps["selection_logits"], ref_logits, 1e-5, 1e-6, "selection logits")
+    assert torch.equal(sel.cpu(), ref_sel) and torch.equal(feats.cpu(), ref_feats)
+
+
+# ------------------------------------------------------------------------- detector end to end
+def test_detector_end_to_end_vs_oracle(eng, oracle_bench):
+    taps = {}
+    det, top, cd = eng.detect(oracle_bench["_images"].to(DEV), taps)
+    assert taps["counts"].cpu().tolist() == [p.shape[0] for p in oracle_bench["_proposals"]]
+    assert torch.equal(cd.cpu(), oracle_bench["class_detected"])
+    # region boxes: pixels, tolerance 0.05 px (fp32 convs -> fc6 -> deltas -> exp); scores 1e-4 absolute
+    assert (det["top_region_boxes"].cpu() - oracle_bench["detections"]["top_region_boxes"]).abs().max() <= 5e-2
+    assert (det["top_scores"].cpu() - oracle_bench["detections"]["top_scores"]).abs().max() <= 1e-4
+    close(top, oracle_bench["top_region_features"], 1e-3, 1e-4, "top_region_features")

@@ -1,0 +1,63 @@
+"""CPU oracle vs the golden fixtures produced by the REAL reference
+(tests/golden/make_golden.py).  Bit-exact: both are torch-CPU fp32 running the same
+operation sequence, so any drift of the restatement shows up here."""
+import torch
+
+from conftest import load_golden
+from oracle import detector as o_det
+from oracle import full_model as o_full
+from oracle import language_model as o_lm
+from rgrg_amd import synth
+
+
+def test_fixtures_were_generated_from_the_reference():
+    for name in ("bench_b1_len128.pt", "ragged_b2_len24.pt", "lm_only_len12.pt", "lm_only_allfinish.pt"):
+        fx = load_golden(name)
+        assert fx["meta"]["oracle_matches_reference"] is True
+        assert fx["meta"]["reference"].startswith("ttanida/rgrg")
+
+
+def test_full_generate_ragged_matches_reference(sd_ragged):
+    fx = load_golden("ragged_b2_len24.pt")
+    images = torch.cat([synth.make_images(1, s) for s in fx["meta"]["image_seeds"]], 0)
+    out = o_det.object_detector_forward(sd_ragged, images, return_intermediates=True)
+    d = fx["detector"]
+    for a, b in zip(out["_proposals"], d["proposals"]):
+        assert torch.equal(a, b)
+    assert torch.equal(out["class_detected"], d["class_detected"])
+    assert torch.equal(out["top_region_features"], d["top_region_features"])
+    assert torch.equal(out["detections"]["top_region_boxes"], d["top_region_boxes"])
+    assert torch.equal(out["detections"]["top_scores"], d["top_scores"])
+    # ragged on purpose: some regions undetected, some unselected
+    assert 0 < int(d["class_detected"].sum()) < d["class_detected"].numel()
+    sel, feats, _ = o_full.region_selection(sd_ragged, out["top_region_features"], out["class_detected"])
+    g = fx["generate"]
+    assert torch.equal(sel, g["selected_regions"]) and 0 < int(sel.sum()) < int(d["class_detected"].sum())
+    ids = o_lm.greedy_generate(sd_ragged, feats, fx["meta"]["max_length"])
+    assert torch.equal(ids, g["output_ids"])
+    finished = (ids[:, 1:] == 50256).any(1)
+    assert finished.any() and not finished.all()  # rows finish at different steps, PAD afterwards
+    for row in ids[finished]:
+        first = int((row[1:] == 50256).nonzero()[0]) + 1
+        assert (row[first:] == 50256).all()
+
+
+def test_lm_only_and_early_exit(sd_ragged):
+    g = torch.Generator().manual_seed(99)
+    feats = torch.randn((5, 1024), generator=g)
+    fx = load_golden("lm_only_len12.pt")
+    ids, logits = o_lm.greedy_generate(sd_ragged, feats, 12, return_logits=True)
+    assert torch.equal(ids, fx["output_ids"]) and ids.shape == (5, 12)
+    assert torch.equal(logits[:, 0, ::101], fx["step0_logits_sample"])
+    assert torch.equal(logits[:, 0].argmax(-1), fx["step0_argmax"])
+    fin = load_golden("lm_only_allfinish.pt")
+    ids = o_lm.greedy_generate(sd_ragged, feats, 40)
+    assert torch.equal(ids, fin["output_ids"]) and ids.shape[1] < 40  # all rows emitted EOS -> early exit
+
+
+def test_empty_selection_returns_minus_one(sd_ragged):
+    sd0 = dict(sd_ragged)
+    sd0["binary_classifier_region_selection.classifier.4.bias"] = torch.tensor([-100.0])
+    feats = torch.zeros((1, 29, 1024))
+    sel, f, _ = o_full.region_selection(sd0, feats, torch.ones((1, 29), dtype=torch.bool))
+    assert int(sel.sum()) == 0 and f.shape == (0, 1024)

@@ -1,0 +1,88 @@
+"""Known-answer tests that pin the torchvision-0.13.1 restatement (oracle/tv013.py) on
+hand-computable cases written from the documented semantics.
+torchvision itself is not installable in the build image -> these are the only pins of
+that layer ("parity unpinned" beyond them)."""
+import math
+
+import torch
+
+from oracle import tv013
+from oracle.language_model import gelu_new
+
+
+def test_base_anchor_layout_and_rounding():
+    base = tv013.base_anchors()
+    assert base.shape == (160, 4)
+    # ratio 1.0 (index 8), size 20 (index 0): exact square of side 20 centred at 0
+    assert base[8 * 10 + 0].tolist() == [-10.0, -10.0, 10.0, 10.0]
+    # ratio 0.25, size 40: h_r = 0.5, w_r = 2 -> w = 80, h = 20
+    assert base[1 * 10 + 1].tolist() == [-40.0, -10.0, 40.0, 10.0]
+    # half-to-even rounding: ratio 0.5 size 100 -> w = 100/sqrt(.5) = 141.42 -> +-70.71 -> 71 ; h = 70.71 -> +-35.36 -> 35
+    assert base[3 * 10 + 4].tolist() == [-71.0, -35.0, 71.0, 35.0]
+
+
+def test_grid_anchor_order():
+    a = tv013.grid_anchors((512, 512), (16, 16))
+    assert a.shape == (40960, 4)
+    base = tv013.base_anchors()
+    # flat index = (y*16 + x)*160 + a ; shift = 32 px per cell, no half-stride offset
+    y, x, k = 3, 5, 42
+    exp = base[k] + torch.tensor([x * 32.0, y * 32.0, x * 32.0, y * 32.0])
+    assert torch.equal(a[(y * 16 + x) * 160 + k], exp)
+
+
+def test_box_decode_identity_and_clip():
+    boxes = torch.tensor([[10.0, 20.0, 50.0, 100.0]])
+    out = tv013.box_decode(torch.zeros(1, 4), boxes, (1.0, 1.0, 1.0, 1.0))
+    assert torch.allclose(out, boxes)
+    # dx = 0.5 widths, dw = log 2 (weights 10,10,5,5)
+    d = torch.tensor([[5.0, 0.0, 5.0 * math.log(2.0), 0.0]])
+    out = tv013.box_decode(d, boxes, (10.0, 10.0, 5.0, 5.0))
+    # w = 40, cx = 30 -> pcx = 50, pw = 80 -> x in [10, 90]
+    assert torch.allclose(out, torch.tensor([[10.0, 20.0, 90.0, 100.0]]), atol=1e-4)
+    # dw is clamped at log(1000/16)
+    big = tv013.box_decode(torch.tensor([[0.0, 0.0, 100.0, 0.0]]), boxes, (1.0, 1.0, 1.0, 1.0))
+    assert torch.allclose(big[0, 2] - big[0, 0], torch.tensor(40.0 * 1000.0 / 16.0), rtol=1e-5)
+    assert tv013.clip_boxes_to_image(torch.tensor([[-5.0, 3.0, 600.0, 700.0]]), (512, 512)).tolist() == [[0.0, 3.0, 512.0, 512.0]]
+
+
+def test_nms_hand_case():
+    boxes = torch.tensor([[0.0, 0.0, 10.0, 10.0],    # A
+                          [1.0, 0.0, 11.0, 10.0],    # B: IoU(A,B) = 90/110 = .818 > .7
+                          [0.0, 0.0, 10.0, 7.0],     # C: IoU(A,C) = 70/100 = .7 -> NOT > .7, kept
+                          [20.0, 20.0, 30.0, 30.0]])  # D disjoint
+    scores = torch.tensor([0.9, 0.8, 0.7, 0.95])
+    keep = tv013.nms(boxes, scores, 0.7)
+    assert keep.tolist() == [3, 0, 2]
+    # stable order on equal scores: lower index first
+    keep = tv013.nms(boxes[[0, 3]], torch.tensor([0.5, 0.5]), 0.7)
+    assert keep.tolist() == [0, 1]
+
+
+def test_roi_align_constant_and_ramp():
+    # constant map -> every bin equals the constant
+    feat = torch.full((1, 3, 16, 16), 2.5)
+    rois = torch.tensor([[0.0, 32.0, 64.0, 320.0, 448.0]])
+    out = tv013.roi_align(feat, rois, 1.0 / 32, 8, 2)
+    assert out.shape == (1, 3, 8, 8) and torch.allclose(out, torch.full_like(out, 2.5))
+    # linear ramp f(y,x) = x: bilinear sampling is exact -> bin value = mean sample x
+    ramp = torch.arange(16, dtype=torch.float32).view(1, 1, 1, 16).expand(1, 1, 16, 16).contiguous()
+    rois = torch.tensor([[0.0, 64.0, 64.0, 320.0, 320.0]])  # x in [2,10] feature units, bin_w = 1
+    out = tv013.roi_align(ramp, rois, 1.0 / 32, 8, 2)
+    exp = 2.0 + torch.arange(8, dtype=torch.float32) + 0.5  # samples at +.25 and +.75 -> mean +.5
+    assert torch.allclose(out[0, 0, 3], exp, atol=1e-5)
+    # aligned=False: roi smaller than 1 feature px is widened to 1
+    tiny = torch.tensor([[0.0, 64.0, 64.0, 70.0, 70.0]])
+    out = tv013.roi_align(ramp, tiny, 1.0 / 32, 8, 2)
+    assert torch.allclose(out[0, 0, 0], 2.0 + (torch.arange(8, dtype=torch.float32) + 0.5) / 8.0, atol=1e-5)
+    # samples beyond the map (> W) contribute 0; the last row/col is clamped
+    edge = torch.tensor([[0.0, 480.0, 0.0, 640.0, 32.0]])  # x in [15,20]: bins beyond x=16 are dead
+    out = tv013.roi_align(ramp, edge, 1.0 / 32, 8, 2)
+    assert out[0, 0, 0, -1] == 0.0 and out[0, 0, 0, 0] > 14.0
+
+
+def test_infer_scale_and_gelu():
+    assert tv013.infer_scale(16, 512) == 1.0 / 32
+    x = torch.tensor([-3.0, -1.0, 0.0, 0.5, 2.0])
+    ref = torch.nn.functional.gelu(x, approximate="tanh")
+    assert torch.allclose(gelu_new(x), ref, atol=1e-6)
