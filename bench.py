@@ -63,7 +63,7 @@ def main():
 
     import rgrg_amd
     from rgrg_amd import synth
-    from rgrg_amd.dist import gather_generate_outputs
+    from rgrg_amd.dist import generate_sharded
 
     sd = synth.make_state_dict(0, "bench")
     model = rgrg_amd.ReportGenerationModel(pretrain_without_lm_model=True)
@@ -73,10 +73,9 @@ def main():
     images = images_cpu.to(dev)
 
     def step():
-        out = model.generate(images, max_length=args.max_length, num_beams=1)
         if world > 1:
-            out = gather_generate_outputs(out, args.batch, args.max_length, dev)
-        return out
+            return generate_sharded(model, images, args.max_length)
+        return model.generate(images, max_length=args.max_length, num_beams=1)
 
     def barrier():
         if world > 1:

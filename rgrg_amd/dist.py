@@ -25,30 +25,39 @@ def shard_bounds(n_images: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + per + (1 if rank < rem else 0)
 
 
-def gather_generate_outputs(local: GenerateOutput, n_local_images: int, max_length: int, device: torch.device,
+def generate_sharded(model, images_local: torch.Tensor, max_length: Optional[int], group: Optional[dist.ProcessGroup] = None
+                     ) -> GenerateOutput:
+    """``generate()`` of the whole (rank-order concatenated) batch: every rank runs the three
+    stages on its own image shard, then one all_gather assembles the single-process result.
+    Equal shard sizes are required (fixed-shape collective)."""
+    _, detections, top_region_features, class_detected = model.object_detector(images_local)
+    selected, feats = model.binary_classifier_region_selection(top_region_features, class_detected, return_loss=False)
+    ids = model.language_model.generate(feats, max_length) if feats.shape[0] > 0 else None
+    return gather_generate_outputs(ids, selected, detections, class_detected, max_length, images_local.device, group)
+
+
+def gather_generate_outputs(out_ids: Optional[torch.Tensor], sel: torch.Tensor, det: Dict[str, torch.Tensor],
+                            cd: torch.Tensor, max_length: int, device: torch.device,
                             group: Optional[dist.ProcessGroup] = None) -> GenerateOutput:
-    """All-gather the per-rank ``generate()`` results into the result a single process
-    would have produced for the concatenated batch.
+    """All-gather the per-rank stage outputs (``out_ids`` is None when the rank selected no
+    region) into what a single process would have returned for the concatenated batch.
 
     One fixed-shape all_gather: ids padded to [29*n_local, max_length] int64 plus a packed
-    per-image record, so there is exactly one collective (payload ~ 30 KB/image).  The
-    single-process L' is the longest row of the WHOLE batch: after the gather the ids are
-    trimmed to the global maximum length so shapes stay bit-identical."""
+    per-image record (selected | detected | score bits | box bits), ~31 KB per image, so there
+    is exactly one collective.  The single-process L' is the longest row of the WHOLE batch:
+    after the gather the ids are trimmed to the global maximum length."""
     world = dist.get_world_size(group)
+    n_local_images = sel.shape[0]
     rows = NUM_REGIONS * n_local_images
     ids = torch.full((rows, max_length), PAD_TOKEN_ID, dtype=torch.int64, device=device)
-    # per image: 29 selected | 29 detected | 29 scores (bits) | 116 boxes (bits) -> int64 for a single dtype
-    meta = torch.zeros((n_local_images, NUM_REGIONS * 7 + 2), dtype=torch.int64, device=device)
-    if isinstance(local, int):
-        meta[:, -1] = 1  # "this rank returned -1"
-    else:
-        out_ids, sel, det, cd = local
+    meta = torch.zeros((n_local_images, NUM_REGIONS * 7 + 1), dtype=torch.int64, device=device)
+    meta[:, 0:29] = sel.to(torch.int64)
+    meta[:, 29:58] = cd.to(torch.int64)
+    meta[:, 58:87] = det["top_scores"].contiguous().view(torch.int32).to(torch.int64)
+    meta[:, 87:203] = det["top_region_boxes"].contiguous().view(n_local_images, -1).view(torch.int32).to(torch.int64)
+    if out_ids is not None:
         ids[: out_ids.shape[0], : out_ids.shape[1]] = out_ids
-        meta[:, 0:29] = sel.to(torch.int64)
-        meta[:, 29:58] = cd.to(torch.int64)
-        meta[:, 58:87] = det["top_scores"].contiguous().view(torch.int32).to(torch.int64)
-        meta[:, 87:203] = det["top_region_boxes"].contiguous().view(n_local_images, -1).view(torch.int32).to(torch.int64)
-        meta[:, -2] = out_ids.shape[1]
+        meta[:, -1] = out_ids.shape[1]
     payload = torch.cat([ids.view(n_local_images, -1), meta], dim=1).contiguous()
     gathered = [torch.empty_like(payload) for _ in range(world)]
     dist.all_gather(gathered, payload, group=group)
@@ -62,16 +71,11 @@ def gather_generate_outputs(local: GenerateOutput, n_local_images: int, max_leng
     boxes = meta_all[:, 87:203].to(torch.int32).view(torch.float32).view(n_img, NUM_REGIONS, 4)
     if int(sel_all.sum()) == 0:
         return -1
-    # rows of each rank are compact (selected regions first): re-compact over the whole batch
-    keep = torch.zeros((n_img, NUM_REGIONS), dtype=torch.bool, device=device)
-    per_rank_images = n_img // world
+    # each rank's rows are compact (its selected regions first): re-compact over the whole batch
     out_rows = []
     for r in range(world):
-        blk = slice(r * per_rank_images, (r + 1) * per_rank_images)
+        blk = slice(r * n_local_images, (r + 1) * n_local_images)
         n_sel = int(sel_all[blk].sum())
-        flat = ids_all[blk].reshape(-1, max_length)
-        out_rows.append(flat[:n_sel])
-    ids_cat = torch.cat(out_rows, 0)
-    L = int(meta_all[:, -2].max())
-    del keep
-    return ids_cat[:, :L].contiguous(), sel_all, {"top_region_boxes": boxes, "top_scores": scores}, cd_all
+        out_rows.append(ids_all[blk].reshape(-1, max_length)[:n_sel])
+    L = int(meta_all[:, -1].max())
+    return torch.cat(out_rows, 0)[:, :L].contiguous(), sel_all, {"top_region_boxes": boxes, "top_scores": scores}, cd_all

@@ -1,0 +1,83 @@
+"""world_size-2 test of the multi-GPU path on CPU (gloo): image sharding + the single
+all_gather of token ids / per-image outputs reproduce the single-process result
+(row order, global L', -1 sentinel)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from rgrg_amd.dist import gather_generate_outputs, shard_bounds
+
+MAXLEN = 24
+
+
+def _fake_generate(n_images, seed, none_selected=False, length=17):
+    """Deterministic stand-in for generate() on a shard (the HIP path needs a GPU)."""
+    g = torch.Generator().manual_seed(seed)
+    cd = torch.rand((n_images, 29), generator=g) > 0.2
+    sel = cd & (torch.rand((n_images, 29), generator=g) > 0.4)
+    det = {"top_scores": torch.rand((n_images, 29), generator=g), "top_region_boxes": torch.rand((n_images, 29, 4), generator=g) * 512}
+    if none_selected:
+        return None, torch.zeros_like(sel), det, cd
+    S = int(sel.sum())
+    ids = torch.randint(0, 50000, (S, length), generator=g)
+    ids[:, 0] = 50256
+    return ids, sel, det, cd
+
+
+def _worker(rank, world, port, case, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if case == "plain":
+            local = _fake_generate(2, 100 + rank, length=17 if rank == 0 else 21)
+        elif case == "one_rank_empty":
+            local = _fake_generate(2, 100 + rank, none_selected=(rank == 1))
+        else:
+            local = _fake_generate(2, 100 + rank, none_selected=True)
+        out = gather_generate_outputs(*local, MAXLEN, torch.device("cpu"))
+        if rank == 0:
+            ret["out"] = out if isinstance(out, int) else (out[0], out[1], out[2]["top_scores"], out[2]["top_region_boxes"], out[3])
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(case):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, case, ret), nprocs=2, join=True)
+    return ret["out"]
+
+
+def test_shard_bounds_cover_the_batch_in_order():
+    for n, w in ((256, 8), (10, 4), (3, 8), (32, 1)):
+        spans = [shard_bounds(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+def test_gather_reproduces_single_process_result():
+    ids, sel, scores, boxes, cd = _run("plain")
+    i0, s0, d0, c0 = _fake_generate(2, 100, length=17)
+    i1, s1, d1, c1 = _fake_generate(2, 101, length=21)
+    assert torch.equal(sel, torch.cat([s0, s1])) and torch.equal(cd, torch.cat([c0, c1]))
+    assert torch.equal(scores, torch.cat([d0["top_scores"], d1["top_scores"]]))       # floats travel bit-exactly
+    assert torch.equal(boxes, torch.cat([d0["top_region_boxes"], d1["top_region_boxes"]]))
+    assert ids.shape == (int(sel.sum()), 21)                                         # global L' = longest shard
+    pad0 = torch.nn.functional.pad(i0, (0, 4), value=50256)
+    assert torch.equal(ids, torch.cat([pad0, i1]))                                  # rank-order rows, PAD-extended
+
+
+def test_gather_with_an_empty_rank_and_all_empty():
+    ids, sel, _, boxes, cd = _run("one_rank_empty")
+    i0, s0, _, _ = _fake_generate(2, 100)
+    _, _, d1, c1 = _fake_generate(2, 101, none_selected=True)
+    assert torch.equal(ids, i0) and int(sel[2:].sum()) == 0 and torch.equal(sel[:2], s0)
+    assert torch.equal(cd[2:], c1) and torch.equal(boxes[2:], d1["top_region_boxes"])  # detections of the empty rank survive
+    assert _run("all_empty") == -1

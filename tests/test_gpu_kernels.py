@@ -98,8 +98,9 @@ def test_stem_and_maxpool(eng):
     ref = F.relu(F.conv2d(x.double(), w.double(), stride=2, padding=3) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
     y = torch.empty((2, 32, 48, 64), device=DEV)
     wt = w.reshape(64, 49).t().contiguous().to(DEV)
-    _hip.check(eng.lib.rgrg_stem_conv7x7_f32(x.to(DEV).data_ptr(), wt.data_ptr(), scale.to(DEV).data_ptr(),
-                                             shift.to(DEV).data_ptr(), y.data_ptr(), 2, 64, 96, _stream()))
+    xd, sc_d, sh_d = x.to(DEV), scale.to(DEV), shift.to(DEV)  # keep alive: the kernel reads them asynchronously
+    _hip.check(eng.lib.rgrg_stem_conv7x7_f32(xd.data_ptr(), wt.data_ptr(), sc_d.data_ptr(), sh_d.data_ptr(), y.data_ptr(),
+                                             2, 64, 96, _stream()))
     close(y.permute(0, 3, 1, 2), ref, 1e-5, 1e-6, "stem conv7x7+bn+relu")
     p = torch.empty((2, 16, 24, 64), device=DEV)
     _hip.check(eng.lib.rgrg_maxpool3x3s2_nhwc_f32(y.data_ptr(), p.data_ptr(), 2, 32, 48, 64, _stream()))
@@ -184,7 +185,8 @@ def _run_roi(eng, feat_nchw, plist):
     out = torch.empty((R, 64, Cc), device=DEV)
     pooled = torch.empty((R, Cc), device=DEV)
     fn = feat_nchw.permute(0, 2, 3, 1).contiguous().to(DEV)
-    _hip.check(eng.lib.rgrg_roi_align_avgpool_f32(fn.data_ptr(), props.to(DEV).data_ptr(), offs.to(DEV).data_ptr(), out.data_ptr(),
+    props_d, offs_d = props.to(DEV), offs.to(DEV)
+    _hip.check(eng.lib.rgrg_roi_align_avgpool_f32(fn.data_ptr(), props_d.data_ptr(), offs_d.data_ptr(), out.data_ptr(),
                                                   pooled.data_ptr(), B, FH, FW, Cc, 1000, R, 1.0 / 32, _stream()))
     return out.cpu().view(R, 8, 8, Cc).permute(0, 3, 1, 2), pooled.cpu()
 
@@ -221,8 +223,9 @@ def test_top1_per_class_on_oracle_inputs(eng, oracle_bench):
     sc = torch.zeros((B, 29), device=DEV)
     bx = torch.zeros((B, 29, 4), device=DEV)
     ft = torch.zeros((B, 29, 2048), device=DEV)
-    _hip.check(eng.lib.rgrg_top1_per_class_f32(pred.to(DEV).data_ptr(), 150, props.to(DEV).data_ptr(), offs.to(DEV).data_ptr(),
-                                               pooled.to(DEV).data_ptr(), cd.data_ptr(), sc.data_ptr(), bx.data_ptr(), ft.data_ptr(),
+    pred_d, props_d, offs_d, pooled_d = pred.to(DEV), props.to(DEV), offs.to(DEV), pooled.to(DEV)
+    _hip.check(eng.lib.rgrg_top1_per_class_f32(pred_d.data_ptr(), 150, props_d.data_ptr(), offs_d.data_ptr(),
+                                               pooled_d.data_ptr(), cd.data_ptr(), sc.data_ptr(), bx.data_ptr(), ft.data_ptr(),
                                                B, 2048, 1000, 512.0, 512.0, _stream()))
     ref_cd, ref_ft, ref_bx, ref_sc = o_det.top_region_postprocess(pooled, oracle_bench["_box_regression"],
                                                                   oracle_bench["_class_logits"], plist, [(512, 512)] * 2)
@@ -245,8 +248,9 @@ def test_top1_per_class_undetected_and_empty_image(eng):
     pred = torch.cat([logits, deltas], 1).contiguous()
     cd = torch.ones((2, 29), dtype=torch.uint8, device=DEV)
     sc, bx, ft = torch.ones((2, 29), device=DEV), torch.ones((2, 29, 4), device=DEV), torch.ones((2, 29, 256), device=DEV)
-    _hip.check(eng.lib.rgrg_top1_per_class_f32(pred.to(DEV).data_ptr(), 150, props.to(DEV).data_ptr(), offs.to(DEV).data_ptr(),
-                                               pooled.to(DEV).data_ptr(), cd.data_ptr(), sc.data_ptr(), bx.data_ptr(), ft.data_ptr(),
+    pred_d, props_d, offs_d, pooled_d = pred.to(DEV), props.to(DEV), offs.to(DEV), pooled.to(DEV)
+    _hip.check(eng.lib.rgrg_top1_per_class_f32(pred_d.data_ptr(), 150, props_d.data_ptr(), offs_d.data_ptr(),
+                                               pooled_d.data_ptr(), cd.data_ptr(), sc.data_ptr(), bx.data_ptr(), ft.data_ptr(),
                                                2, 256, 1000, 512.0, 512.0, _stream()))
     ref_cd, ref_ft, ref_bx, ref_sc = o_det.top_region_postprocess(pooled, deltas, logits, plist[:1], [(512, 512)])
     assert torch.equal(cd.cpu()[0].bool(), ref_cd[0]) and not ref_cd[0, 4]
@@ -266,7 +270,8 @@ def test_select_regions_and_gather(eng):
     sel = torch.empty((n,), dtype=torch.uint8, device=DEV)
     rows = torch.full((n,), -1, dtype=torch.int32, device=DEV)
     cnt = torch.zeros((1,), dtype=torch.int32, device=DEV)
-    _hip.check(eng.lib.rgrg_select_regions_f32(logits.to(DEV).data_ptr(), det.to(torch.uint8).to(DEV).data_ptr(), -1.0,
+    logits_d, det_d = logits.to(DEV), det.to(torch.uint8).to(DEV)
+    _hip.check(eng.lib.rgrg_select_regions_f32(logits_d.data_ptr(), det_d.data_ptr(), -1.0,
                                                sel.data_ptr(), rows.data_ptr(), cnt.data_ptr(), n, _stream()))
     ref = (logits > -1) & det
     assert torch.equal(sel.cpu().bool(), ref)
@@ -274,7 +279,8 @@ def test_select_regions_and_gather(eng):
     assert S == int(ref.sum()) and torch.equal(rows.cpu()[:S].long(), ref.nonzero().flatten())
     src = torch.randn((n, 64), generator=g)
     dst = torch.empty((S, 64), device=DEV)
-    _hip.check(eng.lib.rgrg_gather_rows_f32(src.to(DEV).data_ptr(), rows.data_ptr(), dst.data_ptr(), S, 64, _stream()))
+    src_d = src.to(DEV)
+    _hip.check(eng.lib.rgrg_gather_rows_f32(src_d.data_ptr(), rows.data_ptr(), dst.data_ptr(), S, 64, _stream()))
     assert torch.equal(dst.cpu(), src[ref])
 
 
