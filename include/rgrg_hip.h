@@ -158,6 +158,11 @@ int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S, void* stre
 int rgrg_decoder_time_gemms(rgrg_decoder* d, int S, int iters, float* ms_total, double* bytes_per_iter,
                             int* launches_per_iter);
 
+/* Measurement helper (tools/microbench.py; not on the product path): host wall
+ * microseconds per kernel of a dependent chain of n trivial kernels; mode 0 = eager on a
+ * private stream, 1 = one hipGraph replay, 2 = eager on the null stream. */
+int rgrg_debug_chain(int n, int mode, int blocks, float* us_per_kernel);
+
 #ifdef __cplusplus
 }
 #endif

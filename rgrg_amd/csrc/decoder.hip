@@ -69,33 +69,56 @@ __device__ __forceinline__ void skinny_store(const SkinnyArgs& a, int row, int c
     a.Y[(size_t)row * a.ldy + col] = apply_act(v, a.act);
 }
 
-__global__ __launch_bounds__(256) void rgrg_skinny_gemm_f32(const SkinnyArgs a) {
-    __shared__ float red[4][16][64];
+constexpr int SK_WAVES = 8;  // K is split over the 8 waves of a workgroup (and over KS workgroups)
+
+// One workgroup = one 32-column tile of the output x one K slice.  Each wave streams its
+// K sub-slice of the packed weights in groups of 4 x 1 KiB chunks, double-buffered in
+// registers (8 KiB in flight per wave, 64 KiB per CU) so HBM latency overlaps the MFMAs.
+__global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32(const SkinnyArgs a) {
+    __shared__ float red[SK_WAVES][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, ks = blockIdx.y;
     const int chunks = a.K >> 3;
-    const int per_wave = chunks / (a.KS * 4);
-    const int kc0 = (ks * 4 + wave) * per_wave;
+    const int per_wave = chunks / (a.KS * SK_WAVES);  // multiple of 4 (host guarantees)
+    const int kc0 = (ks * SK_WAVES + wave) * per_wave;
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.P) + ((size_t)nt * chunks + kc0) * 64 + lane;
     const float* xp = a.X + (size_t)(lane & 31) * a.K + kc0 * 8 + (lane >> 5) * 4;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 8
-    for (int c = 0; c < per_wave; ++c) {
-        const f32x4 w = __builtin_nontemporal_load(wp + (size_t)c * 64);
-        const f32x4 x = *reinterpret_cast<const f32x4*>(xp + c * 8);
+    f32x4 wa[4], xa[4], wb[4], xb[4];
+    auto load = [&](f32x4(&w)[4], f32x4(&x)[4], int g) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], w[j], acc, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            const int c = g * 4 + i;
+            w[i] = __builtin_nontemporal_load(wp + (size_t)c * 64);
+            x[i] = *reinterpret_cast<const f32x4*>(xp + c * 8);
+        }
+    };
+    auto mma = [&](const f32x4(&w)[4], const f32x4(&x)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[i][j], w[i][j], acc, 0, 0, 0);
+    };
+    const int ng = per_wave >> 2;
+    load(wa, xa, 0);
+    for (int g = 0; g < ng; g += 2) {
+        if (g + 1 < ng) load(wb, xb, g + 1);
+        mma(wa, xa);
+        if (g + 2 < ng) load(wa, xa, g + 2);
+        if (g + 1 < ng) mma(wb, xb);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = tid + 256 * q;
+    for (int q = 0; q < 2; ++q) {
+        const int idx = tid + 512 * q;
         const int r = idx >> 6, l = idx & 63;
-        const float v = ((red[0][r][l] + red[1][r][l]) + red[2][r][l]) + red[3][r][l];
+        float v = red[0][r][l];
+#pragma unroll
+        for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[w2][r][l];
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
         const int col = nt * 32 + (l & 31);
         if (a.KS == 1)
@@ -117,18 +140,6 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const SkinnyArgs a) 
 }
 
 // ------------------------------------------------------------------ small kernels
-// x[s] = wte[ids[s][t]] + wte[t]   (quirk: positions are embedded with wte, language_model.py:307)
-__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ wte, const long long* __restrict__ ids,
-                                                    int ld_ids, const int* __restrict__ step, float* __restrict__ x,
-                                                    int D) {
-    const int s = blockIdx.x, t = *step;
-    const long long tok = ids[(size_t)s * ld_ids + t];
-    const f32x4* a = reinterpret_cast<const f32x4*>(wte + (size_t)tok * D);
-    const f32x4* p = reinterpret_cast<const f32x4*>(wte + (size_t)t * D);
-    f32x4* o = reinterpret_cast<f32x4*>(x + (size_t)s * D);
-    for (int q = threadIdx.x; q < D / 4; q += 256) o[q] = a[q] + p[q];
-}
-
 __device__ __forceinline__ float block_sum_256(float v, float* sh) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -138,12 +149,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// nn.LayerNorm(1024, eps=1e-5); one workgroup per row, D == 1024.
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                        const float* __restrict__ b, float* __restrict__ y, int D) {
-    __shared__ float sh[4];
-    const int row = blockIdx.x, tid = threadIdx.x;
-    const f32x4 v = reinterpret_cast<const f32x4*>(x + (size_t)row * D)[tid];
+// nn.LayerNorm(1024, eps=1e-5) of the row held as one float4 per thread (256 threads)
+__device__ __forceinline__ f32x4 ln_row(const f32x4 v, const float* __restrict__ g, const float* __restrict__ b,
+                                        float* sh, int D) {
+    const int tid = threadIdx.x;
     const float mean = block_sum_256((v[0] + v[1]) + (v[2] + v[3]), sh) / (float)D;
     f32x4 d;
 #pragma unroll
@@ -154,22 +163,61 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = d[e] * rstd * gg[e] + bb[e];
-    reinterpret_cast<f32x4*>(y + (size_t)row * D)[tid] = o;
+    return o;
+}
+
+// x[s] = wte[ids[s][t]] + wte[t] (quirk: positions are embedded with wte, language_model.py:307),
+// xn[s] = ln_1 of layer 0.  One workgroup per sequence, D == 1024.
+__global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__ wte, const long long* __restrict__ ids,
+                                                       int ld_ids, const int* __restrict__ step, const float* __restrict__ g,
+                                                       const float* __restrict__ b, float* __restrict__ x,
+                                                       float* __restrict__ xn, int D) {
+    __shared__ float sh[4];
+    const int s = blockIdx.x, t = *step, tid = threadIdx.x;
+    const long long tok = ids[(size_t)s * ld_ids + t];
+    const f32x4 v = reinterpret_cast<const f32x4*>(wte + (size_t)tok * D)[tid] + reinterpret_cast<const f32x4*>(wte + (size_t)t * D)[tid];
+    reinterpret_cast<f32x4*>(x + (size_t)s * D)[tid] = v;
+    reinterpret_cast<f32x4*>(xn + (size_t)s * D)[tid] = ln_row(v, g, b, sh, D);
+}
+
+// Residual stream update fused with the split-K combine and the NEXT LayerNorm:
+//   x[row] += bias + sum_ks part[ks][row]   (fixed order)   ;   xn[row] = LN(x[row])
+// part == nullptr: x already holds the sum (tiled-GEMM path), only the LayerNorm runs.
+__global__ __launch_bounds__(256) void resid_ln_kernel(float* __restrict__ x, const float* __restrict__ bias,
+                                                       const float* __restrict__ part, int KS, int ldp,
+                                                       const float* __restrict__ g, const float* __restrict__ b,
+                                                       float* __restrict__ xn, int D) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    f32x4 v = reinterpret_cast<const f32x4*>(x + (size_t)row * D)[tid];
+    if (part) {
+        f32x4 p = reinterpret_cast<const f32x4*>(part + (size_t)row * ldp)[tid];
+        for (int ks = 1; ks < KS; ++ks) p += reinterpret_cast<const f32x4*>(part + ((size_t)ks * PAD_ROWS + row) * ldp)[tid];
+        v += p + reinterpret_cast<const f32x4*>(bias)[tid];
+        reinterpret_cast<f32x4*>(x + (size_t)row * D)[tid] = v;
+    }
+    reinterpret_cast<f32x4*>(xn + (size_t)row * D)[tid] = ln_row(v, g, b, sh, D);
 }
 
 // Pseudo self-attention for ONE new token per sequence (GPT2PseudoAttention.forward with
 // layer_past, :162-174, and _attn :84-122: scores / 8, softmax, . V; the causal mask row
 // of a single query and the all-zero padding mask are no-ops in greedy generation).
-// One wave per (sequence, head); lane = (key group g = lane>>4, 4 dims d4 = lane&15).
+// One workgroup per (sequence, head), 4 waves; a 16-lane group owns one key (4 dims per
+// lane), so a wave covers 4 keys and the workgroup 16 keys per iteration.  All K rows (and
+// the V rows of the first 144 keys) are requested up front, so the kernel pays ~2 HBM/L2
+// latencies instead of one per key.
+constexpr int ATT_NI = 9;            // iterations per chunk
+constexpr int ATT_CHUNK = 16 * ATT_NI;  // 144 keys
+constexpr int ATT_MAXKEYS = 1040;
+
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                           float* __restrict__ kc, float* __restrict__ vc,
                                                           const int* __restrict__ step, float* __restrict__ out,
                                                           int S, int H, int T) {
-    __shared__ float sc[4][136];
+    __shared__ float sc[ATT_MAXKEYS];
+    __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wid = blockIdx.x * 4 + wave;
-    if (wid >= S * H) return;
-    const int s = wid / H, hd = wid - s * H;
+    const int s = blockIdx.x / H, hd = blockIdx.x - s * H;
     const int t = *step, nkeys = t + 2, slot = t + 1;
     const int g = lane >> 4, d4 = lane & 15;
     const float* row = qkv + (size_t)s * ld_qkv;
@@ -179,48 +227,58 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     const f32x4 v4 = *reinterpret_cast<const f32x4*>(row + 2 * D + hd * 64 + d4 * 4);
     float* kbase = kc + ((size_t)s * H + hd) * T * 64;
     float* vbase = vc + ((size_t)s * H + hd) * T * 64;
-    if (g == 0) {
+    if (wave == 0 && g == 0) {
         *reinterpret_cast<f32x4*>(kbase + (size_t)slot * 64 + d4 * 4) = k4;
         *reinterpret_cast<f32x4*>(vbase + (size_t)slot * 64 + d4 * 4) = v4;
     }
-    float* mysc = sc[wave];
-    for (int j0 = 0; j0 < nkeys; j0 += 4) {
-        const int j = j0 + g;
-        float dot = 0.f;
-        if (j < nkeys) {
-            f32x4 kk = k4;
-            if (j != slot) kk = *reinterpret_cast<const f32x4*>(kbase + (size_t)j * 64 + d4 * 4);
-            dot = (q4[0] * kk[0] + q4[1] * kk[1]) + (q4[2] * kk[2] + q4[3] * kk[3]);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 vv0[ATT_NI];
+    for (int base = 0; base < nkeys; base += ATT_CHUNK) {
+        f32x4 kk[ATT_NI];
+#pragma unroll
+        for (int i = 0; i < ATT_NI; ++i) {
+            const int j = base + (i * 4 + wave) * 4 + g;
+            kk[i] = zero4;
+            if (j < nkeys) kk[i] = (j == slot) ? k4 : *reinterpret_cast<const f32x4*>(kbase + (size_t)j * 64 + d4 * 4);
         }
-        dot += __shfl_xor(dot, 1, 64);
-        dot += __shfl_xor(dot, 2, 64);
-        dot += __shfl_xor(dot, 4, 64);
-        dot += __shfl_xor(dot, 8, 64);
-        if (d4 == 0 && j < nkeys) mysc[j] = dot / 8.0f;
+        if (base == 0) {
+#pragma unroll
+            for (int i = 0; i < ATT_NI; ++i) {
+                const int j = (i * 4 + wave) * 4 + g;
+                vv0[i] = zero4;
+                if (j < nkeys) vv0[i] = (j == slot) ? v4 : *reinterpret_cast<const f32x4*>(vbase + (size_t)j * 64 + d4 * 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ATT_NI; ++i) {
+            const int j = base + (i * 4 + wave) * 4 + g;
+            float dot = (q4[0] * kk[i][0] + q4[1] * kk[i][1]) + (q4[2] * kk[i][2] + q4[3] * kk[i][3]);
+            dot += __shfl_xor(dot, 1, 64);
+            dot += __shfl_xor(dot, 2, 64);
+            dot += __shfl_xor(dot, 4, 64);
+            dot += __shfl_xor(dot, 8, 64);
+            if (d4 == 0 && j < nkeys) sc[j] = dot / 8.0f;
+        }
     }
-    __builtin_amdgcn_s_waitcnt(0);  // LDS writes of this wave visible to its own lanes
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     float m = -INFINITY;
-    for (int j = lane; j < nkeys; j += 64) m = fmaxf(m, mysc[j]);
+    for (int j = lane; j < nkeys; j += 64) m = fmaxf(m, sc[j]);
     m = wave_max(m);
     float sum = 0.f;
-    for (int j = lane; j < nkeys; j += 64) {
-        const float e = expf(mysc[j] - m);
-        mysc[j] = e;
-        sum += e;
-    }
+    for (int j = lane; j < nkeys; j += 64) sum += expf(sc[j] - m);
     sum = wave_sum(sum);
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int j0 = 0; j0 < nkeys; j0 += 4) {
-        const int j = j0 + g;
-        if (j < nkeys) {
-            const float p = mysc[j] / sum;
-            f32x4 vv = v4;
-            if (j != slot) vv = *reinterpret_cast<const f32x4*>(vbase + (size_t)j * 64 + d4 * 4);
+    f32x4 acc = zero4;
+    for (int base = 0; base < nkeys; base += ATT_CHUNK) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += p * vv[e];
+        for (int i = 0; i < ATT_NI; ++i) {
+            const int j = base + (i * 4 + wave) * 4 + g;
+            if (j < nkeys) {
+                f32x4 vv = vv0[i];
+                if (base > 0) vv = (j == slot) ? v4 : *reinterpret_cast<const f32x4*>(vbase + (size_t)j * 64 + d4 * 4);
+                const float p = expf(sc[j] - m) / sum;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += p * vv[e];
+            }
         }
     }
 #pragma unroll
@@ -228,7 +286,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
         acc[e] += __shfl_xor(acc[e], 16, 64);
         acc[e] += __shfl_xor(acc[e], 32, 64);
     }
-    if (g == 0) *reinterpret_cast<f32x4*>(out + (size_t)s * D + hd * 64 + d4 * 4) = acc;
+    if (g == 0) *reinterpret_cast<f32x4*>(&part[wave][d4 * 4]) = acc;
+    __syncthreads();
+    if (wave == 0 && g == 0) {
+        f32x4 o = *reinterpret_cast<const f32x4*>(&part[0][d4 * 4]);
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) o += *reinterpret_cast<const f32x4*>(&part[w2][d4 * 4]);
+        *reinterpret_cast<f32x4*>(out + (size_t)s * D + hd * 64 + d4 * 4) = o;
+    }
 }
 
 // image key/value (uk/uv outputs) -> cache slot 0 of every layer
@@ -249,12 +314,18 @@ __global__ __launch_bounds__(256) void kv_slot0_kernel(const float* __restrict__
     }
 }
 
-// first-occurrence arg-max over the vocabulary (torch.argmax), one workgroup per row
-__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int ld, int V,
-                                                      int* __restrict__ out) {
+// First-occurrence arg-max over the vocabulary (torch.argmax) fused with the greedy_search
+// bookkeeping (:629-650): PAD for finished rows, append, EOS -> finished; the LAST workgroup
+// to arrive (integer ticket -> deterministic) records the first length at which every row
+// is finished and advances the step counter.  sync[0] = unfinished rows, sync[1] = tickets.
+__global__ __launch_bounds__(1024) void argmax_update_kernel(const float* __restrict__ logits, int ld, int V,
+                                                             long long* __restrict__ ids, int ld_ids,
+                                                             int* __restrict__ finished, int* __restrict__ step,
+                                                             int* __restrict__ done_len, int* __restrict__ sync, int S) {
     __shared__ float bv[16];
     __shared__ int bi[16];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = *step;
     const float* x = logits + (size_t)row * ld;
     float best = -INFINITY;
     int idx = 0x7fffffff;
@@ -272,46 +343,36 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
     if (tid == 0) {
         for (int w = 1; w < 16; ++w)
             if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
-        out[row] = idx == 0x7fffffff ? 0 : idx;
-    }
-}
-
-// greedy_search bookkeeping (:629-650): PAD for finished rows, append, EOS -> finished,
-// first length at which every row is finished, step += 1.
-__global__ __launch_bounds__(1024) void greedy_update_kernel(const int* __restrict__ next, long long* __restrict__ ids,
-                                                             int ld_ids, int* __restrict__ finished,
-                                                             int* __restrict__ step, int* __restrict__ done_len, int S) {
-    __shared__ int unfinished;
-    const int tid = threadIdx.x, t = *step;
-    if (tid == 0) unfinished = 0;
-    __syncthreads();
-    int mine = 0;
-    for (int s = tid; s < S; s += 1024) {
-        int tok = next[s];
-        int fin = finished[s];
+        int tok = idx == 0x7fffffff ? 0 : idx;
+        int fin = finished[row];
         if (fin) tok = PAD_ID;
-        ids[(size_t)s * ld_ids + t + 1] = tok;
+        ids[(size_t)row * ld_ids + t + 1] = tok;
         if (tok == EOS_ID) fin = 1;
-        finished[s] = fin;
-        mine += fin ? 0 : 1;
-    }
-    if (mine) atomicAdd(&unfinished, mine);
-    __syncthreads();
-    if (tid == 0) {
-        if (unfinished == 0 && *done_len == 0) *done_len = t + 2;
-        *step = t + 1;
+        finished[row] = fin;
+        if (!fin) atomicAdd(&sync[0], 1);
+        __threadfence();
+        const int ticket = atomicAdd(&sync[1], 1);
+        if (ticket == S - 1) {  // every row has been recorded
+            __threadfence();
+            const int unfinished = atomicAdd(&sync[0], 0);
+            if (unfinished == 0 && *done_len == 0) *done_len = t + 2;
+            *step = t + 1;
+            sync[0] = 0;
+            sync[1] = 0;
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void decode_reset_kernel(long long* __restrict__ ids, int ld_ids, int* __restrict__ finished,
-                                                           int* __restrict__ step, int* __restrict__ done_len, int S,
-                                                           int L) {
+                                                           int* __restrict__ step, int* __restrict__ done_len,
+                                                           int* __restrict__ sync, int S, int L) {
     const size_t total = (size_t)S * L;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
         ids[(i / L) * ld_ids + (i % L)] = (i % L) == 0 ? BOS_ID : PAD_ID;
     if (blockIdx.x == 0) {
         for (int s = threadIdx.x; s < S; s += 256) finished[s] = 0;
         if (threadIdx.x == 0) { *step = 0; *done_len = 0; }
+        if (threadIdx.x < 2) sync[threadIdx.x] = 0;
     }
 }
 
@@ -348,7 +409,7 @@ struct rgrg_decoder {
     size_t kv_layer_stride, kv_kv_stride;
     int ld_logits, ld_ukv;
     long long* ids;
-    int *next, *finished, *step, *done_len;
+    int *next, *finished, *step, *done_len, *sync;
     int* h_done;  // pinned
     hipStream_t stream;
     hipEvent_t ev_in;
@@ -368,9 +429,12 @@ static int dmalloc(rgrg_decoder* d, void** p, size_t bytes, bool zero) {
 }
 
 static int pick_ks(int NT, int chunks) {
-    // enough workgroups to cover the 256 CUs, keep >= 4 chunks (4 KiB) per wave
+    // Wide outputs (>= 64 column tiles) keep the whole K in one workgroup: no partial sums.
+    // Narrow ones (N = 1024) split K over workgroups until ~all CUs stream, keeping a
+    // multiple of 4 one-KiB chunks per wave; the consumer (resid_ln_kernel) adds the partials.
     int ks = 1;
-    while (NT * ks < 256 && chunks / (ks * 2 * 4) >= 4 && chunks % (ks * 2 * 4) == 0) ks *= 2;
+    if (NT >= 64) return ks;
+    while (NT * ks < 256 && chunks % (ks * 2 * SK_WAVES * 4) == 0) ks *= 2;
     return ks;
 }
 
@@ -378,6 +442,10 @@ static int make_lin(rgrg_decoder* d, Lin& l, const float* w, const float* b, int
     l.w = w; l.b = b; l.N = N; l.K = K;
     l.NT = (N + 31) / 32;
     l.KS = pick_ks(l.NT, K / 8);
+    if ((K / 8) % (l.KS * SK_WAVES * 4) != 0) {
+        set_error("decoder: K=%d cannot be split over %d x %d waves in groups of 4 chunks", K, l.KS, SK_WAVES);
+        return RGRG_EINVAL;
+    }
     if (pack) {
         const size_t bytes = (size_t)l.NT * 32 * K * sizeof(float);
         int rc = dmalloc(d, (void**)&l.packed, bytes, false);
@@ -388,14 +456,17 @@ static int make_lin(rgrg_decoder* d, Lin& l, const float* w, const float* b, int
     return RGRG_OK;
 }
 
-// Y[:M] = act(X W^T + b) + R on whichever GEMM fits the row count
+// Y[:M] = act(X W^T + b + R).  <= 32 rows: weight-streaming skinny GEMM; when the layer
+// splits K over workgroups (KS > 1) and `defer` is set, only the partial sums are produced
+// (d->part) and the caller's next kernel (resid_ln_kernel) combines them with bias and
+// residual; otherwise a small reduce kernel finishes the job.  > 32 rows: tiled MFMA GEMM.
 static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R, float* Y, int M, int ldy, int act,
-                  bool count) {
+                  bool count, bool defer = false) {
     if (M <= PAD_ROWS && l.packed) {
         SkinnyArgs a{X, l.packed, l.b, R, Y, d->part, M, l.K, l.N, l.NT, l.KS, ldy, act};
-        hipLaunchKernelGGL(rgrg_skinny_gemm_f32, dim3(l.NT, l.KS), dim3(256), 0, d->stream, a);
+        hipLaunchKernelGGL(rgrg_skinny_gemm_f32, dim3(l.NT, l.KS), dim3(64 * SK_WAVES), 0, d->stream, a);
         RGRG_LAUNCH_CHECK();
-        if (l.KS > 1) {
+        if (l.KS > 1 && !defer) {
             const int total = M * l.N;
             hipLaunchKernelGGL(skinny_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, d->stream, a);
             RGRG_LAUNCH_CHECK();
@@ -409,37 +480,42 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
     return launch_gemm_dense(X, l.w, l.b, R, Y, M, l.N, l.K, ldy, act, d->stream);
 }
 
+// One decode step.  <= 32 sequences: 1 + 24*7 + 2 = 171 launches
+//   embed+ln1 | per layer: c_attn, attention, attn_proj(partials), resid+ln2, c_fc+gelu,
+//   mlp_proj(partials), resid+ln1(next layer / ln_f) | lm_head, argmax+bookkeeping
 static int enqueue_step(rgrg_decoder* d, int S, bool count) {
     if (count) { d->gemm_bytes_per_step = 0; d->gemm_launches_per_step = 0; }
     hipStream_t st = d->stream;
     const int D = d->D;
-    hipLaunchKernelGGL(embed_kernel, dim3(S), dim3(256), 0, st, d->wte, d->ids, d->max_len, d->step, d->x, D);
+    const bool skinny = S <= PAD_ROWS;
+    int rc;
+    hipLaunchKernelGGL(embed_ln_kernel, dim3(S), dim3(256), 0, st, d->wte, d->ids, d->max_len, d->step,
+                       d->layers[0].ln1_g, d->layers[0].ln1_b, d->x, d->xn, D);
     RGRG_LAUNCH_CHECK();
     for (int l = 0; l < d->n_layer; ++l) {
         const LayerW& w = d->layers[l];
         float* kc = d->kv + (size_t)l * d->kv_layer_stride;
         float* vc = kc + d->kv_kv_stride;
-        int rc;
-        hipLaunchKernelGGL(layernorm_kernel, dim3(S), dim3(256), 0, st, d->x, w.ln1_g, w.ln1_b, d->xn, D);
-        RGRG_LAUNCH_CHECK();
+        const float* ng = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_g : d->lnf_g;
+        const float* nb = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_b : d->lnf_b;
         if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, count))) return rc;
-        hipLaunchKernelGGL(attn_decode_kernel, dim3((S * d->H + 3) / 4), dim3(256), 0, st, d->qkv, 3 * D, kc, vc,
-                           d->step, d->att, S, d->H, d->T);
+        hipLaunchKernelGGL(attn_decode_kernel, dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc, vc, d->step, d->att, S,
+                           d->H, d->T);
         RGRG_LAUNCH_CHECK();
-        if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count))) return rc;
-        hipLaunchKernelGGL(layernorm_kernel, dim3(S), dim3(256), 0, st, d->x, w.ln2_g, w.ln2_b, d->xn, D);
+        const bool defer_a = skinny && w.attn_proj.KS > 1, defer_m = skinny && w.mlp_proj.KS > 1;
+        if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count, defer_a))) return rc;
+        hipLaunchKernelGGL(resid_ln_kernel, dim3(S), dim3(256), 0, st, d->x, w.attn_proj.b, defer_a ? d->part : nullptr,
+                           w.attn_proj.KS, w.attn_proj.NT * 32, w.ln2_g, w.ln2_b, d->xn, D);
         RGRG_LAUNCH_CHECK();
         if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, count))) return rc;
-        if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->x, S, D, RGRG_ACT_NONE, count))) return rc;
+        if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->x, S, D, RGRG_ACT_NONE, count, defer_m))) return rc;
+        hipLaunchKernelGGL(resid_ln_kernel, dim3(S), dim3(256), 0, st, d->x, w.mlp_proj.b, defer_m ? d->part : nullptr,
+                           w.mlp_proj.KS, w.mlp_proj.NT * 32, ng, nb, d->xn, D);
+        RGRG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(layernorm_kernel, dim3(S), dim3(256), 0, st, d->x, d->lnf_g, d->lnf_b, d->xn, D);
-    RGRG_LAUNCH_CHECK();
-    int rc;
     if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count))) return rc;
-    hipLaunchKernelGGL(argmax_kernel, dim3(S), dim3(1024), 0, st, d->logits, d->ld_logits, d->V, d->next);
-    RGRG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(greedy_update_kernel, dim3(1), dim3(1024), 0, st, d->next, d->ids, d->max_len, d->finished,
-                       d->step, d->done_len, S);
+    hipLaunchKernelGGL(argmax_update_kernel, dim3(S), dim3(1024), 0, st, d->logits, d->ld_logits, d->V, d->ids, d->max_len,
+                       d->finished, d->step, d->done_len, d->sync, S);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
@@ -448,7 +524,7 @@ static int enqueue_prefill(rgrg_decoder* d, const float* feats, int S) {
     hipStream_t st = d->stream;
     const int D = d->D;
     hipLaunchKernelGGL(decode_reset_kernel, dim3(64), dim3(256), 0, st, d->ids, d->max_len, d->finished, d->step,
-                       d->done_len, S, d->max_len);
+                       d->done_len, d->sync, S, d->max_len);
     RGRG_LAUNCH_CHECK();
     RGRG_HIP(hipMemcpyAsync(d->feats, feats, (size_t)S * D * sizeof(float), hipMemcpyDeviceToDevice, st));
     int rc;
@@ -524,6 +600,7 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     TRY(dmalloc(d, (void**)&d->finished, R * 4, true));
     TRY(dmalloc(d, (void**)&d->step, 4, true));
     TRY(dmalloc(d, (void**)&d->done_len, 4, true));
+    TRY(dmalloc(d, (void**)&d->sync, 64, true));
 #undef TRY
     if (hipStreamSynchronize(d->stream) != hipSuccess) {
         set_error("decoder: weight packing failed");
@@ -617,7 +694,7 @@ extern "C" int rgrg_decoder_time_gemms(rgrg_decoder* d, int S, int iters, float*
     // the weight-streaming GEMM launches of one decode step, each bracketed by events on the decoder's stream
     auto timed = [&](const Lin& l, const float* X, float* Y, int ldy, int act, bool count) -> int {
         RGRG_HIP(hipEventRecord(e0, d->stream));
-        int r = linear(d, l, X, nullptr, Y, S, ldy, act, count);
+        int r = linear(d, l, X, nullptr, Y, S, ldy, act, count, /*defer=*/true);  // the GEMM launch alone
         if (r) return r;
         RGRG_HIP(hipEventRecord(e1, d->stream));
         RGRG_HIP(hipEventSynchronize(e1));
