@@ -60,6 +60,8 @@ struct SkinnyArgs {
     float* Y;           // [32][ldy]
     float* part;        // [KS][32][NT*32] partial sums when KS > 1
     int M, K, N, NT, KS, ldy, act;
+    float* cand_val;    // optional [32][NT] per-tile row maxima (fused arg-max of lm_head), KS == 1 only
+    int* cand_idx;
 };
 
 __device__ __forceinline__ void skinny_store(const SkinnyArgs& a, int row, int col, float v) {
@@ -72,42 +74,61 @@ __device__ __forceinline__ void skinny_store(const SkinnyArgs& a, int row, int c
 constexpr int SK_WAVES = 8;  // K is split over the 8 waves of a workgroup (and over KS workgroups)
 
 // One workgroup = one 32-column tile of the output x one K slice.  Each wave streams its
-// K sub-slice of the packed weights in groups of 4 x 1 KiB chunks, double-buffered in
-// registers (8 KiB in flight per wave, 64 KiB per CU) so HBM latency overlaps the MFMAs.
+// K sub-slice of the packed weights as 1-KiB chunks.  PW (chunks per wave) known at compile
+// time (4/8/16): ALL loads are issued up front (<= 16 KiB in flight per wave, 128 KiB per
+// CU) and the MFMAs drain them in arrival order, so the kernel pays one HBM latency.
+// PW == 0: generic loop over groups of 4 chunks, double-buffered in registers.
+template <int PW>
 __global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32(const SkinnyArgs a) {
     __shared__ float red[SK_WAVES][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, ks = blockIdx.y;
     const int chunks = a.K >> 3;
-    const int per_wave = chunks / (a.KS * SK_WAVES);  // multiple of 4 (host guarantees)
+    const int per_wave = PW ? PW : chunks / (a.KS * SK_WAVES);  // multiple of 4 (host guarantees)
     const int kc0 = (ks * SK_WAVES + wave) * per_wave;
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.P) + ((size_t)nt * chunks + kc0) * 64 + lane;
     const float* xp = a.X + (size_t)(lane & 31) * a.K + kc0 * 8 + (lane >> 5) * 4;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    f32x4 wa[4], xa[4], wb[4], xb[4];
-    auto load = [&](f32x4(&w)[4], f32x4(&x)[4], int g) {
+    if constexpr (PW > 0) {
+        f32x4 w[PW], x[PW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = g * 4 + i;
-            w[i] = __builtin_nontemporal_load(wp + (size_t)c * 64);
-            x[i] = *reinterpret_cast<const f32x4*>(xp + c * 8);
+        for (int c = 0; c < PW; ++c) {
+            w[c] = __builtin_nontemporal_load(wp + (size_t)c * 64);
+            x[c] = *reinterpret_cast<const f32x4*>(xp + c * 8);
+            // pin the issue order (w0,x0,w1,x1,...) and keep every load ahead of the first MFMA:
+            // loads return in order, so MFMA c can start as soon as pair c has landed
+            __builtin_amdgcn_sched_barrier(0);
         }
-    };
-    auto mma = [&](const f32x4(&w)[4], const f32x4(&x)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int c = 0; c < PW; ++c)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[i][j], w[i][j], acc, 0, 0, 0);
-    };
-    const int ng = per_wave >> 2;
-    load(wa, xa, 0);
-    for (int g = 0; g < ng; g += 2) {
-        if (g + 1 < ng) load(wb, xb, g + 1);
-        mma(wa, xa);
-        if (g + 2 < ng) load(wa, xa, g + 2);
-        if (g + 1 < ng) mma(wb, xb);
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[c][j], w[c][j], acc, 0, 0, 0);
+    } else {
+        f32x4 wa[4], xa[4], wb[4], xb[4];
+        auto load = [&](f32x4(&w)[4], f32x4(&x)[4], int g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = g * 4 + i;
+                w[i] = __builtin_nontemporal_load(wp + (size_t)c * 64);
+                x[i] = *reinterpret_cast<const f32x4*>(xp + c * 8);
+            }
+        };
+        auto mma = [&](const f32x4(&w)[4], const f32x4(&x)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[i][j], w[i][j], acc, 0, 0, 0);
+        };
+        const int ng = per_wave >> 2;
+        load(wa, xa, 0);
+        for (int g = 0; g < ng; g += 2) {
+            if (g + 1 < ng) load(wb, xb, g + 1);
+            mma(wa, xa);
+            if (g + 2 < ng) load(wa, xa, g + 2);
+            if (g + 1 < ng) mma(wb, xb);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
@@ -121,10 +142,26 @@ __global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32(const SkinnyArgs a) 
         for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[w2][r][l];
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
         const int col = nt * 32 + (l & 31);
-        if (a.KS == 1)
+        if (a.KS == 1) {
             skinny_store(a, row, col, v);
-        else
+            if (a.cand_val) {
+                // fused arg-max: the 32 columns of `row` in this tile live in one 32-lane half; first max wins
+                float bv = (col < a.N) ? v + (a.bias ? a.bias[col] : 0.f) : -INFINITY;
+                int bi = col;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(bv, o, 64);
+                    const int oi = __shfl_xor(bi, o, 64);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                if ((l & 31) == 0 && row < a.M) {
+                    a.cand_val[(size_t)row * a.NT + nt] = bv;
+                    a.cand_idx[(size_t)row * a.NT + nt] = bi;
+                }
+            }
+        } else {
             a.part[((size_t)ks * PAD_ROWS + row) * (a.NT * 32) + col] = v;
+        }
     }
 }
 
@@ -315,23 +352,24 @@ __global__ __launch_bounds__(256) void kv_slot0_kernel(const float* __restrict__
 }
 
 // First-occurrence arg-max over the vocabulary (torch.argmax) fused with the greedy_search
-// bookkeeping (:629-650): PAD for finished rows, append, EOS -> finished; the LAST workgroup
-// to arrive (integer ticket -> deterministic) records the first length at which every row
-// is finished and advances the step counter.  sync[0] = unfinished rows, sync[1] = tickets.
-__global__ __launch_bounds__(1024) void argmax_update_kernel(const float* __restrict__ logits, int ld, int V,
-                                                             long long* __restrict__ ids, int ld_ids,
-                                                             int* __restrict__ finished, int* __restrict__ step,
-                                                             int* __restrict__ done_len, int* __restrict__ sync, int S) {
-    __shared__ float bv[16];
-    __shared__ int bi[16];
+// bookkeeping (:629-650).  The lm_head GEMM already reduced every 32-column tile to one
+// (max, index) candidate (ties: lower index), so a row is NT ~ 1571 candidates; the LAST
+// workgroup to arrive (integer ticket -> deterministic) records the first length at which
+// every row is finished and advances the step counter.  sync[0] = unfinished rows, sync[1] = tickets.
+__global__ __launch_bounds__(256) void argmax_update_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                                                            int NT, long long* __restrict__ ids, int ld_ids,
+                                                            int* __restrict__ finished, int* __restrict__ step,
+                                                            int* __restrict__ done_len, int* __restrict__ sync, int S) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = *step;
-    const float* x = logits + (size_t)row * ld;
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int i = tid; i < V; i += 1024) {
-        const float v = x[i];
-        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+    for (int i = tid; i < NT; i += 256) {
+        const float v = cand_val[(size_t)row * NT + i];
+        const int ci = cand_idx[(size_t)row * NT + i];
+        if (v > best || (v == best && ci < idx)) { best = v; idx = ci; }
     }
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o, 64);
@@ -341,7 +379,7 @@ __global__ __launch_bounds__(1024) void argmax_update_kernel(const float* __rest
     if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 16; ++w)
+        for (int w = 1; w < 4; ++w)
             if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
         int tok = idx == 0x7fffffff ? 0 : idx;
         int fin = finished[row];
@@ -361,6 +399,21 @@ __global__ __launch_bounds__(1024) void argmax_update_kernel(const float* __rest
             sync[1] = 0;
         }
     }
+}
+
+// tiled-GEMM path (> 32 sequences): reduce the logits row to per-32-column candidates first
+__global__ __launch_bounds__(256) void logits_candidates_kernel(const float* __restrict__ logits, int ld, int V, int NT,
+                                                                float* __restrict__ cand_val, int* __restrict__ cand_idx) {
+    const int row = blockIdx.y;
+    const int nt = blockIdx.x * 256 + threadIdx.x;
+    if (nt >= NT) return;
+    const float* x = logits + (size_t)row * ld + nt * 32;
+    float best = -INFINITY;
+    int idx = nt * 32;
+    for (int i = 0; i < 32 && nt * 32 + i < V; ++i)
+        if (x[i] > best) { best = x[i]; idx = nt * 32 + i; }
+    cand_val[(size_t)row * NT + nt] = best;
+    cand_idx[(size_t)row * NT + nt] = idx;
 }
 
 __global__ __launch_bounds__(256) void decode_reset_kernel(long long* __restrict__ ids, int ld_ids, int* __restrict__ finished,
@@ -405,7 +458,8 @@ struct rgrg_decoder {
     Lin fst0, fst2, ukv, lm_head;
     std::vector<LayerW> layers;
     // workspace
-    float *feats, *h1, *img, *ukv_out, *x, *xn, *qkv, *att, *ff, *logits, *part, *kv;
+    float *feats, *h1, *img, *ukv_out, *x, *xn, *qkv, *att, *ff, *logits, *part, *kv, *cand_val;
+    int* cand_idx;
     size_t kv_layer_stride, kv_kv_stride;
     int ld_logits, ld_ukv;
     long long* ids;
@@ -461,10 +515,16 @@ static int make_lin(rgrg_decoder* d, Lin& l, const float* w, const float* b, int
 // (d->part) and the caller's next kernel (resid_ln_kernel) combines them with bias and
 // residual; otherwise a small reduce kernel finishes the job.  > 32 rows: tiled MFMA GEMM.
 static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R, float* Y, int M, int ldy, int act,
-                  bool count, bool defer = false) {
+                  bool count, bool defer = false, bool cand = false) {
     if (M <= PAD_ROWS && l.packed) {
-        SkinnyArgs a{X, l.packed, l.b, R, Y, d->part, M, l.K, l.N, l.NT, l.KS, ldy, act};
-        hipLaunchKernelGGL(rgrg_skinny_gemm_f32, dim3(l.NT, l.KS), dim3(64 * SK_WAVES), 0, d->stream, a);
+        SkinnyArgs a{X, l.packed, l.b, R, Y, d->part, M, l.K, l.N, l.NT, l.KS, ldy, act, nullptr, nullptr};
+        if (cand && l.KS == 1) { a.cand_val = d->cand_val; a.cand_idx = d->cand_idx; }
+        const int pw = (l.K / 8) / (l.KS * SK_WAVES);
+        const dim3 grid(l.NT, l.KS), block(64 * SK_WAVES);
+        if (pw == 4) hipLaunchKernelGGL(rgrg_skinny_gemm_f32<4>, grid, block, 0, d->stream, a);
+        else if (pw == 8) hipLaunchKernelGGL(rgrg_skinny_gemm_f32<8>, grid, block, 0, d->stream, a);
+        else if (pw == 16) hipLaunchKernelGGL(rgrg_skinny_gemm_f32<16>, grid, block, 0, d->stream, a);
+        else hipLaunchKernelGGL(rgrg_skinny_gemm_f32<0>, grid, block, 0, d->stream, a);
         RGRG_LAUNCH_CHECK();
         if (l.KS > 1 && !defer) {
             const int total = M * l.N;
@@ -480,7 +540,7 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
     return launch_gemm_dense(X, l.w, l.b, R, Y, M, l.N, l.K, ldy, act, d->stream);
 }
 
-// One decode step.  <= 32 sequences: 1 + 24*7 + 2 = 171 launches
+// One decode step.  <= 32 sequences: 1 + 24*7 + 2 = 171 launches (lm_head emits arg-max candidates)
 //   embed+ln1 | per layer: c_attn, attention, attn_proj(partials), resid+ln2, c_fc+gelu,
 //   mlp_proj(partials), resid+ln1(next layer / ln_f) | lm_head, argmax+bookkeeping
 static int enqueue_step(rgrg_decoder* d, int S, bool count) {
@@ -513,9 +573,14 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count) {
                            w.mlp_proj.KS, w.mlp_proj.NT * 32, ng, nb, d->xn, D);
         RGRG_LAUNCH_CHECK();
     }
-    if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count))) return rc;
-    hipLaunchKernelGGL(argmax_update_kernel, dim3(S), dim3(1024), 0, st, d->logits, d->ld_logits, d->V, d->ids, d->max_len,
-                       d->finished, d->step, d->done_len, d->sync, S);
+    if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, false, true))) return rc;
+    if (!(skinny && d->lm_head.KS == 1)) {
+        hipLaunchKernelGGL(logits_candidates_kernel, dim3((d->lm_head.NT + 255) / 256, S), dim3(256), 0, st, d->logits,
+                           d->ld_logits, d->V, d->lm_head.NT, d->cand_val, d->cand_idx);
+        RGRG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(argmax_update_kernel, dim3(S), dim3(256), 0, st, d->cand_val, d->cand_idx, d->lm_head.NT, d->ids,
+                       d->max_len, d->finished, d->step, d->done_len, d->sync, S);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
@@ -601,6 +666,8 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     TRY(dmalloc(d, (void**)&d->step, 4, true));
     TRY(dmalloc(d, (void**)&d->done_len, 4, true));
     TRY(dmalloc(d, (void**)&d->sync, 64, true));
+    TRY(dmalloc(d, (void**)&d->cand_val, R * d->lm_head.NT * 4, true));
+    TRY(dmalloc(d, (void**)&d->cand_idx, R * d->lm_head.NT * 4, true));
 #undef TRY
     if (hipStreamSynchronize(d->stream) != hipSuccess) {
         set_error("decoder: weight packing failed");

@@ -31,15 +31,22 @@ def _stream() -> int:
 
 
 def pick_splitk(M: int, N: int, K: int) -> int:
-    """Split the K loop over workgroups when the output has too few tiles to fill
-    256 CUs (each split still streams >= 4 K tiles of 32)."""
+    """Split the K loop over workgroups when the output has too few tiles to fill the 256
+    CUs (each split still streams >= 4 K tiles of 32).  Large outputs (fc6: 823x1024 with
+    K = 131072) get the 128x128 tile (the C side picks it when tiles*splitk >= 192), which
+    halves the operand re-reads of the 64x64 tile; small ones split the 64x64 grid."""
+    def grow(tiles: int, target: int, cap: int) -> int:
+        sk = 1
+        while sk * 2 <= cap and tiles * sk < target and K % (32 * sk * 2) == 0 and K // (32 * sk * 2) >= 4:
+            sk *= 2
+        return sk
+
+    if M >= 512 and N >= 512:
+        return grow(((M + 127) // 128) * ((N + 127) // 128), 192, 16)
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
-    if tiles >= 128:
+    if tiles >= 256:
         return 1
-    sk = 1
-    while sk * 2 <= 16 and tiles * sk * 2 <= 512 and K % (32 * sk * 2) == 0 and K // (32 * sk * 2) >= 4:
-        sk *= 2
-    return sk
+    return grow(tiles, 256, 16)
 
 
 def grid_anchors(image_size: int, grid: int) -> Tensor:
