@@ -51,6 +51,23 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
 }
 
+// 16-column tiles for v_mfma_f32_16x16x4_f32: P [NT][K/16][64 lanes][4], lane l = (j = l&15,
+// q = l>>4) holds W[nt*16+j][kc*16 + 4q .. +3].
+__global__ __launch_bounds__(256) void pack_weights16_kernel(const float* __restrict__ W, float* __restrict__ P, int N,
+                                                             int K, int NT) {
+    const size_t total = (size_t)NT * (K / 16) * 64;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(o & 63);
+        const size_t t = o >> 6;
+        const int kc = (int)(t % (K / 16));
+        const int nt = (int)(t / (K / 16));
+        const int n = nt * 16 + (l & 15);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < N) v = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + kc * 16 + (l >> 4) * 4);
+        reinterpret_cast<f32x4*>(P)[o] = v;
+    }
+}
+
 // ------------------------------------------------------------------ skinny GEMM
 struct SkinnyArgs {
     const float* X;     // [32][K] (rows >= M are zero)
@@ -62,6 +79,7 @@ struct SkinnyArgs {
     int M, K, N, NT, KS, ldy, act;
     float* cand_val;    // optional [32][NT] per-tile row maxima (fused arg-max of lm_head), KS == 1 only
     int* cand_idx;
+    int ntile;          // 32 or 16 output columns per workgroup
 };
 
 __device__ __forceinline__ void skinny_store(const SkinnyArgs& a, int row, int col, float v) {
@@ -73,100 +91,161 @@ __device__ __forceinline__ void skinny_store(const SkinnyArgs& a, int row, int c
 
 constexpr int SK_WAVES = 8;  // K is split over the 8 waves of a workgroup (and over KS workgroups)
 
-// One workgroup = one 32-column tile of the output x one K slice.  Each wave streams its
-// K sub-slice of the packed weights as 1-KiB chunks.  PW (chunks per wave) known at compile
-// time (4/8/16): ALL loads are issued up front (<= 16 KiB in flight per wave, 128 KiB per
-// CU) and the MFMAs drain them in arrival order, so the kernel pays one HBM latency.
-// PW == 0: generic loop over groups of 4 chunks, double-buffered in registers.
-template <int PW>
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// Weight-streaming GEMM for <= 32 activation rows.  One workgroup = one NTILE-column tile of
+// the output x one K slice (K / KS):
+//   1. the 32 x (K/KS) activation slice is staged ONCE into LDS with fully coalesced 16-B
+//      loads (rows padded by 4 floats -> conflict-free ds_read_b128 A fragments);
+//   2. each of the 8 waves streams its PW one-KiB chunks of pre-packed weights straight into
+//      registers (non-temporal, all PW loads in flight before the first MFMA);
+//   3. f32 MFMAs (32x32x2 for NTILE 32, 2 x 16x16x4 for NTILE 16) drain the chunks in arrival
+//      order; the 8 per-wave accumulators are summed through LDS in a fixed order.
+// KS == 1: bias / residual / activation epilogue (+ per-tile arg-max candidates for lm_head);
+// KS  > 1: partial sums to a.part, combined by the consumer kernel.
+template <int NTILE, int PW>
 __global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32(const SkinnyArgs a) {
-    __shared__ float red[SK_WAVES][16][64];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KC = (NTILE == 32) ? 8 : 16;  // k per weight chunk
+    constexpr int KWG = PW * SK_WAVES * KC;      // K slice of this workgroup
+    constexpr int LDX = KWG + 4;
+    constexpr int XQ = KWG / 64;                 // float4 staging loads per thread (32*KWG/4/512)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, ks = blockIdx.y;
-    const int chunks = a.K >> 3;
-    const int per_wave = PW ? PW : chunks / (a.KS * SK_WAVES);  // multiple of 4 (host guarantees)
-    const int kc0 = (ks * SK_WAVES + wave) * per_wave;
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.P) + ((size_t)nt * chunks + kc0) * 64 + lane;
-    const float* xp = a.X + (size_t)(lane & 31) * a.K + kc0 * 8 + (lane >> 5) * 4;
-    f32x16 acc;
+    const int chunks = a.K / KC;
+    const int kc0 = (ks * SK_WAVES + wave) * PW;
+    const float* xsrc = a.X + (size_t)ks * KWG;
+    f32x4 xr[XQ];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if constexpr (PW > 0) {
-        f32x4 w[PW], x[PW];
+    for (int q = 0; q < XQ; ++q) {
+        const int idx = tid + 512 * q;
+        const int row = idx / (KWG / 4), c4 = idx - row * (KWG / 4);
+        xr[q] = *reinterpret_cast<const f32x4*>(xsrc + (size_t)row * a.K + c4 * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // activations first: they gate the first MFMA
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.P) + ((size_t)nt * chunks + kc0) * 64 + lane;
+    f32x4 w[PW];
+#pragma unroll
+    for (int c = 0; c < PW; ++c) w[c] = __builtin_nontemporal_load(wp + (size_t)c * 64);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+        const int idx = tid + 512 * q;
+        const int row = idx / (KWG / 4), c4 = idx - row * (KWG / 4);
+        *reinterpret_cast<f32x4*>(&smem[row * LDX + c4 * 4]) = xr[q];
+    }
+    __syncthreads();
+    float* red = smem;  // re-used after the MFMA loop
+    if constexpr (NTILE == 32) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* xa = &smem[(lane & 31) * LDX + wave * PW * KC + (lane >> 5) * 4];
 #pragma unroll
         for (int c = 0; c < PW; ++c) {
-            w[c] = __builtin_nontemporal_load(wp + (size_t)c * 64);
-            x[c] = *reinterpret_cast<const f32x4*>(xp + c * 8);
-            // pin the issue order (w0,x0,w1,x1,...) and keep every load ahead of the first MFMA:
-            // loads return in order, so MFMA c can start as soon as pair c has landed
-            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(xa + c * KC);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], w[c][j], acc, 0, 0, 0);
         }
+        __syncthreads();
 #pragma unroll
-        for (int c = 0; c < PW; ++c)
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+        __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[c][j], w[c][j], acc, 0, 0, 0);
+        for (int q = 0; q < 2; ++q) {
+            const int idx = tid + 512 * q;
+            const int r = idx >> 6, l = idx & 63;
+            float v = red[r * 64 + l];
+#pragma unroll
+            for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[(w2 * 16 + r) * 64 + l];
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+            const int col = nt * 32 + (l & 31);
+            if (a.KS == 1) {
+                skinny_store(a, row, col, v);
+                if (a.cand_val) {
+                    // fused arg-max: the 32 columns of `row` in this tile live in one 32-lane half; first max wins
+                    float bv = (col < a.N) ? v + (a.bias ? a.bias[col] : 0.f) : -INFINITY;
+                    int bi = col;
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) {
+                        const float ov = __shfl_xor(bv, o, 64);
+                        const int oi = __shfl_xor(bi, o, 64);
+                        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                    }
+                    if ((l & 31) == 0 && row < a.M) {
+                        a.cand_val[(size_t)row * a.NT + nt] = bv;
+                        a.cand_idx[(size_t)row * a.NT + nt] = bi;
+                    }
+                }
+            } else {
+                a.part[((size_t)ks * PAD_ROWS + row) * (a.NT * NTILE) + col] = v;
+            }
+        }
     } else {
-        f32x4 wa[4], xa[4], wb[4], xb[4];
-        auto load = [&](f32x4(&w)[4], f32x4(&x)[4], int g) {
+        f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* xa = &smem[(lane & 15) * LDX + wave * PW * KC + (lane >> 4) * 4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = g * 4 + i;
-                w[i] = __builtin_nontemporal_load(wp + (size_t)c * 64);
-                x[i] = *reinterpret_cast<const f32x4*>(xp + c * 8);
+        for (int c = 0; c < PW; ++c) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xa + c * KC);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(xa + 16 * LDX + c * KC);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], w[c][j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], w[c][j], acc1, 0, 0, 0);
             }
-        };
-        auto mma = [&](const f32x4(&w)[4], const f32x4(&x)[4]) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[i][j], w[i][j], acc, 0, 0, 0);
-        };
-        const int ng = per_wave >> 2;
-        load(wa, xa, 0);
-        for (int g = 0; g < ng; g += 2) {
-            if (g + 1 < ng) load(wb, xb, g + 1);
-            mma(wa, xa);
-            if (g + 2 < ng) load(wa, xa, g + 2);
-            if (g + 1 < ng) mma(wb, xb);
         }
-    }
+        __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
-    __syncthreads();
+        for (int r = 0; r < 4; ++r) {
+            red[((wave * 2 + 0) * 4 + r) * 64 + lane] = acc0[r];
+            red[((wave * 2 + 1) * 4 + r) * 64 + lane] = acc1[r];
+        }
+        __syncthreads();
+        {
+            // 32 rows x 16 cols = 512 outputs, one per thread.  C/D map of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
+            const int mt = tid >> 8, r = (tid >> 6) & 3, l = tid & 63;
+            float v = red[((0 * 2 + mt) * 4 + r) * 64 + l];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int idx = tid + 512 * q;
-        const int r = idx >> 6, l = idx & 63;
-        float v = red[0][r][l];
-#pragma unroll
-        for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[w2][r][l];
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        const int col = nt * 32 + (l & 31);
-        if (a.KS == 1) {
-            skinny_store(a, row, col, v);
-            if (a.cand_val) {
-                // fused arg-max: the 32 columns of `row` in this tile live in one 32-lane half; first max wins
-                float bv = (col < a.N) ? v + (a.bias ? a.bias[col] : 0.f) : -INFINITY;
-                int bi = col;
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(bv, o, 64);
-                    const int oi = __shfl_xor(bi, o, 64);
-                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                }
-                if ((l & 31) == 0 && row < a.M) {
-                    a.cand_val[(size_t)row * a.NT + nt] = bv;
-                    a.cand_idx[(size_t)row * a.NT + nt] = bi;
-                }
-            }
-        } else {
-            a.part[((size_t)ks * PAD_ROWS + row) * (a.NT * 32) + col] = v;
+            for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[((w2 * 2 + mt) * 4 + r) * 64 + l];
+            const int row = mt * 16 + (l >> 4) * 4 + r;
+            const int col = nt * 16 + (l & 15);
+            if (a.KS == 1)
+                skinny_store(a, row, col, v);
+            else
+                a.part[((size_t)ks * PAD_ROWS + row) * (a.NT * NTILE) + col] = v;
         }
     }
 }
 
+template <int NTILE, int PW>
+static int launch_skinny(const SkinnyArgs& a, hipStream_t st) {
+    constexpr int KC = (NTILE == 32) ? 8 : 16;
+    constexpr size_t lds_x = (size_t)32 * (PW * SK_WAVES * KC + 4) * sizeof(float);
+    constexpr size_t lds_r = (size_t)SK_WAVES * (NTILE == 32 ? 16 : 8) * 64 * sizeof(float);
+    constexpr size_t lds = lds_x > lds_r ? lds_x : lds_r;
+    hipLaunchKernelGGL((rgrg_skinny_gemm_f32<NTILE, PW>), dim3(a.NT, a.KS), dim3(64 * SK_WAVES), lds, st, a);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+// chunks-per-wave PW = K / (KC * KS * 8) must be one of the instantiated values
+static int launch_skinny_any(int ntile, const SkinnyArgs& a, hipStream_t st) {
+    const int kc = ntile == 32 ? 8 : 16;
+    const int pw = a.K / (kc * a.KS * SK_WAVES);
+    if (ntile == 32) {
+        if (pw == 4) return launch_skinny<32, 4>(a, st);
+        if (pw == 8) return launch_skinny<32, 8>(a, st);
+        if (pw == 16) return launch_skinny<32, 16>(a, st);
+    } else {
+        if (pw == 4) return launch_skinny<16, 4>(a, st);
+        if (pw == 8) return launch_skinny<16, 8>(a, st);
+    }
+    set_error("skinny GEMM: unsupported shape K=%d KS=%d ntile=%d (chunks per wave %d)", a.K, a.KS, ntile, pw);
+    return RGRG_EINVAL;
+}
+
 __global__ __launch_bounds__(256) void skinny_reduce_kernel(const SkinnyArgs a) {
-    const int ldp = a.NT * 32;
+    const int ldp = a.NT * a.ntile;
     const int total = a.M * a.N;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int row = i / a.N, col = i - row * a.N;
@@ -434,7 +513,7 @@ struct Lin {
     const float* w = nullptr;  // [N,K]
     const float* b = nullptr;  // [N]
     float* packed = nullptr;   // skinny layout
-    int N = 0, K = 0, NT = 0, KS = 1;
+    int N = 0, K = 0, NT = 0, KS = 1, ntile = 32;
 };
 
 struct LayerW {
@@ -494,20 +573,51 @@ static int pick_ks(int NT, int chunks) {
 
 static int make_lin(rgrg_decoder* d, Lin& l, const float* w, const float* b, int N, int K, bool pack) {
     l.w = w; l.b = b; l.N = N; l.K = K;
-    l.NT = (N + 31) / 32;
-    l.KS = pick_ks(l.NT, K / 8);
-    if ((K / 8) % (l.KS * SK_WAVES * 4) != 0) {
-        set_error("decoder: K=%d cannot be split over %d x %d waves in groups of 4 chunks", K, l.KS, SK_WAVES);
+    if (K == 1024 && N >= 2048 && N <= 8192) {
+        // c_attn / c_fc: 16-column tiles -> 192 / 256 workgroups with the whole K each (no partial sums)
+        l.ntile = 16; l.KS = 1;
+    } else {
+        l.ntile = 32;
+        l.KS = pick_ks((N + 31) / 32, K / 8);
+    }
+    l.NT = (N + l.ntile - 1) / l.ntile;
+    const int kc = l.ntile == 32 ? 8 : 16;
+    const int pw = K / (kc * l.KS * SK_WAVES);
+    const bool ok = (K % (kc * l.KS * SK_WAVES) == 0) &&
+                    (l.ntile == 32 ? (pw == 4 || pw == 8 || pw == 16) : (pw == 4 || pw == 8));
+    if (!ok) {
+        set_error("decoder: no skinny GEMM instance for N=%d K=%d (ntile %d, KS %d, %d chunks per wave)", N, K, l.ntile, l.KS, pw);
         return RGRG_EINVAL;
     }
     if (pack) {
-        const size_t bytes = (size_t)l.NT * 32 * K * sizeof(float);
+        const size_t bytes = (size_t)l.NT * l.ntile * K * sizeof(float);
         int rc = dmalloc(d, (void**)&l.packed, bytes, false);
         if (rc) return rc;
-        hipLaunchKernelGGL(pack_weights_kernel, dim3(2048), dim3(256), 0, d->stream, w, l.packed, N, K, l.NT);
+        if (l.ntile == 32)
+            hipLaunchKernelGGL(pack_weights_kernel, dim3(2048), dim3(256), 0, d->stream, w, l.packed, N, K, l.NT);
+        else
+            hipLaunchKernelGGL(pack_weights16_kernel, dim3(2048), dim3(256), 0, d->stream, w, l.packed, N, K, l.NT);
         RGRG_LAUNCH_CHECK();
     }
     return RGRG_OK;
+}
+
+// hipFuncSetAttribute is not capturable: raise the dynamic-LDS limit of every instance up front
+template <int NTILE, int PW>
+static int skinny_attr() {
+    constexpr int KC = (NTILE == 32) ? 8 : 16;
+    constexpr size_t lds_x = (size_t)32 * (PW * SK_WAVES * KC + 4) * sizeof(float);
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_gemm_f32<NTILE, PW>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_x > 65536 ? lds_x : 65536)));
+    return RGRG_OK;
+}
+static int init_skinny_attrs() {
+    int rc;
+    if ((rc = skinny_attr<32, 4>())) return rc;
+    if ((rc = skinny_attr<32, 8>())) return rc;
+    if ((rc = skinny_attr<32, 16>())) return rc;
+    if ((rc = skinny_attr<16, 4>())) return rc;
+    return skinny_attr<16, 8>();
 }
 
 // Y[:M] = act(X W^T + b + R).  <= 32 rows: weight-streaming skinny GEMM; when the layer
@@ -517,15 +627,10 @@ static int make_lin(rgrg_decoder* d, Lin& l, const float* w, const float* b, int
 static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R, float* Y, int M, int ldy, int act,
                   bool count, bool defer = false, bool cand = false) {
     if (M <= PAD_ROWS && l.packed) {
-        SkinnyArgs a{X, l.packed, l.b, R, Y, d->part, M, l.K, l.N, l.NT, l.KS, ldy, act, nullptr, nullptr};
-        if (cand && l.KS == 1) { a.cand_val = d->cand_val; a.cand_idx = d->cand_idx; }
-        const int pw = (l.K / 8) / (l.KS * SK_WAVES);
-        const dim3 grid(l.NT, l.KS), block(64 * SK_WAVES);
-        if (pw == 4) hipLaunchKernelGGL(rgrg_skinny_gemm_f32<4>, grid, block, 0, d->stream, a);
-        else if (pw == 8) hipLaunchKernelGGL(rgrg_skinny_gemm_f32<8>, grid, block, 0, d->stream, a);
-        else if (pw == 16) hipLaunchKernelGGL(rgrg_skinny_gemm_f32<16>, grid, block, 0, d->stream, a);
-        else hipLaunchKernelGGL(rgrg_skinny_gemm_f32<0>, grid, block, 0, d->stream, a);
-        RGRG_LAUNCH_CHECK();
+        SkinnyArgs a{X, l.packed, l.b, R, Y, d->part, M, l.K, l.N, l.NT, l.KS, ldy, act, nullptr, nullptr, l.ntile};
+        if (cand && l.KS == 1 && l.ntile == 32) { a.cand_val = d->cand_val; a.cand_idx = d->cand_idx; }
+        int rc = launch_skinny_any(l.ntile, a, d->stream);
+        if (rc) return rc;
         if (l.KS > 1 && !defer) {
             const int total = M * l.N;
             hipLaunchKernelGGL(skinny_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, d->stream, a);
@@ -565,16 +670,16 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count) {
         const bool defer_a = skinny && w.attn_proj.KS > 1, defer_m = skinny && w.mlp_proj.KS > 1;
         if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count, defer_a))) return rc;
         hipLaunchKernelGGL(resid_ln_kernel, dim3(S), dim3(256), 0, st, d->x, w.attn_proj.b, defer_a ? d->part : nullptr,
-                           w.attn_proj.KS, w.attn_proj.NT * 32, w.ln2_g, w.ln2_b, d->xn, D);
+                           w.attn_proj.KS, w.attn_proj.NT * w.attn_proj.ntile, w.ln2_g, w.ln2_b, d->xn, D);
         RGRG_LAUNCH_CHECK();
         if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, count))) return rc;
         if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->x, S, D, RGRG_ACT_NONE, count, defer_m))) return rc;
         hipLaunchKernelGGL(resid_ln_kernel, dim3(S), dim3(256), 0, st, d->x, w.mlp_proj.b, defer_m ? d->part : nullptr,
-                           w.mlp_proj.KS, w.mlp_proj.NT * 32, ng, nb, d->xn, D);
+                           w.mlp_proj.KS, w.mlp_proj.NT * w.mlp_proj.ntile, ng, nb, d->xn, D);
         RGRG_LAUNCH_CHECK();
     }
     if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, false, true))) return rc;
-    if (!(skinny && d->lm_head.KS == 1)) {
+    if (!(skinny && d->lm_head.KS == 1 && d->lm_head.ntile == 32)) {
         hipLaunchKernelGGL(logits_candidates_kernel, dim3((d->lm_head.NT + 255) / 256, S), dim3(256), 0, st, d->logits,
                            d->ld_logits, d->V, d->lm_head.NT, d->cand_val, d->cand_idx);
         RGRG_LAUNCH_CHECK();
@@ -611,6 +716,7 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     RGRG_CHECK_ARG(w->d_model == 1024 && w->n_head == 16 && w->n_layer > 0 && w->vocab > 0 && w->layers);
     int rc = init_gemm_attrs();
     if (rc) return rc;
+    if ((rc = init_skinny_attrs())) return rc;
     rgrg_decoder* d = new rgrg_decoder();
     d->n_layer = w->n_layer; d->D = w->d_model; d->H = w->n_head; d->V = w->vocab;
     d->max_seqs = max_seqs; d->max_len = max_len; d->T = max_len + 1;
@@ -644,7 +750,7 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
         TRY(make_lin(d, t.mlp_proj, s.mlp_proj_w, s.mlp_proj_b, D, 4 * D, true));
     }
     const size_t R = d->rows;
-    d->ld_logits = d->lm_head.NT * 32;
+    d->ld_logits = d->lm_head.NT * d->lm_head.ntile;
     d->ld_ukv = d->ukv.N;
     TRY(dmalloc(d, (void**)&d->feats, R * D * 4, true));
     TRY(dmalloc(d, (void**)&d->h1, R * D * 4, true));
