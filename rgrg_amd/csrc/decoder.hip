@@ -217,6 +217,86 @@ __global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32(const SkinnyArgs a) 
     }
 }
 
+// Persistent variant for very wide outputs (lm_head: 1571 column tiles, uk/uv: 1536): the
+// grid is ~one workgroup per CU; each workgroup stages the activations ONCE and then walks
+// column tiles nt = blockIdx.x, += gridDim.x, streaming 128 KiB of weights per tile.  Waves
+// 1..7 publish their accumulators through LDS and move on to the next tile's loads while
+// wave 0 sums (fixed order), applies the epilogue and emits the per-tile arg-max candidate.
+__global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32_wide(const SkinnyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PW = 16, KC = 8, KWG = PW * SK_WAVES * KC, LDX = KWG + 4, XQ = KWG / 64;
+    float* red = smem + 32 * LDX;  // [7][16][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunks = a.K / KC;
+    {
+        f32x4 xr[XQ];
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int idx = tid + 512 * q;
+            const int row = idx / (KWG / 4), c4 = idx - row * (KWG / 4);
+            xr[q] = *reinterpret_cast<const f32x4*>(a.X + (size_t)row * a.K + c4 * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int idx = tid + 512 * q;
+            const int row = idx / (KWG / 4), c4 = idx - row * (KWG / 4);
+            *reinterpret_cast<f32x4*>(&smem[row * LDX + c4 * 4]) = xr[q];
+        }
+    }
+    __syncthreads();
+    const float* xa = &smem[(lane & 31) * LDX + wave * PW * KC + (lane >> 5) * 4];
+    for (int nt = blockIdx.x; nt < a.NT; nt += gridDim.x) {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.P) + ((size_t)nt * chunks + wave * PW) * 64 + lane;
+        f32x4 w[PW];
+#pragma unroll
+        for (int c = 0; c < PW; ++c) w[c] = __builtin_nontemporal_load(wp + (size_t)c * 64);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < PW; ++c) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(xa + c * KC);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], w[c][j], acc, 0, 0, 0);
+        }
+        __syncthreads();  // wave 0 has finished reading `red` of the previous tile
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int col = nt * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[r];
+#pragma unroll
+                for (int w2 = 0; w2 < SK_WAVES - 1; ++w2) v += red[(w2 * 16 + r) * 64 + lane];
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                skinny_store(a, row, col, v);
+                if (a.cand_val) {
+                    float bv = (col < a.N) ? v + (a.bias ? a.bias[col] : 0.f) : -INFINITY;
+                    int bi = col;
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) {
+                        const float ov = __shfl_xor(bv, o, 64);
+                        const int oi = __shfl_xor(bi, o, 64);
+                        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                    }
+                    if ((lane & 31) == 0 && row < a.M) {
+                        a.cand_val[(size_t)row * a.NT + nt] = bv;
+                        a.cand_idx[(size_t)row * a.NT + nt] = bi;
+                    }
+                }
+            }
+        }
+    }
+}
+
+constexpr size_t WIDE_LDS = (size_t)(32 * (16 * SK_WAVES * 8 + 4) + (SK_WAVES - 1) * 16 * 64) * sizeof(float);
+static_assert(WIDE_LDS <= 160 * 1024, "wide skinny GEMM must fit the 160 KiB LDS");
+
 template <int NTILE, int PW>
 static int launch_skinny(const SkinnyArgs& a, hipStream_t st) {
     constexpr int KC = (NTILE == 32) ? 8 : 16;
@@ -232,6 +312,11 @@ static int launch_skinny(const SkinnyArgs& a, hipStream_t st) {
 static int launch_skinny_any(int ntile, const SkinnyArgs& a, hipStream_t st) {
     const int kc = ntile == 32 ? 8 : 16;
     const int pw = a.K / (kc * a.KS * SK_WAVES);
+    if (ntile == 32 && pw == 16 && a.KS == 1 && a.NT > 512) {
+        hipLaunchKernelGGL(rgrg_skinny_gemm_f32_wide, dim3(256), dim3(64 * SK_WAVES), WIDE_LDS, st, a);
+        RGRG_LAUNCH_CHECK();
+        return RGRG_OK;
+    }
     if (ntile == 32) {
         if (pw == 4) return launch_skinny<32, 4>(a, st);
         if (pw == 8) return launch_skinny<32, 8>(a, st);
@@ -617,6 +702,8 @@ static int init_skinny_attrs() {
     if ((rc = skinny_attr<32, 8>())) return rc;
     if ((rc = skinny_attr<32, 16>())) return rc;
     if ((rc = skinny_attr<16, 4>())) return rc;
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_gemm_f32_wide),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS));
     return skinny_attr<16, 8>();
 }
 
@@ -864,28 +951,25 @@ extern "C" int rgrg_decoder_time_gemms(rgrg_decoder* d, int S, int iters, float*
     d->gemm_launches_per_step = 0;
     float total = 0.f;
     int rc = RGRG_OK;
-    // the weight-streaming GEMM launches of one decode step, each bracketed by events on the decoder's stream
-    auto timed = [&](const Lin& l, const float* X, float* Y, int ldy, int act, bool count) -> int {
+    // the 97 weight-streaming GEMM launches of one decode step, back to back in step order, between ONE
+    // pair of events on the decoder's stream (the two event records amortise over the 97 launches)
+    for (int it = 0; it < iters && !rc; ++it) {
+        const bool c = it == 0;
         RGRG_HIP(hipEventRecord(e0, d->stream));
-        int r = linear(d, l, X, nullptr, Y, S, ldy, act, count, /*defer=*/true);  // the GEMM launch alone
-        if (r) return r;
+        for (int l = 0; l < d->n_layer && !rc; ++l) {
+            const LayerW& w = d->layers[l];
+            if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, c, true))) break;
+            if ((rc = linear(d, w.attn_proj, d->att, nullptr, d->h1, S, D, RGRG_ACT_NONE, c, true))) break;
+            if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, c, true))) break;
+            if ((rc = linear(d, w.mlp_proj, d->ff, nullptr, d->h1, S, D, RGRG_ACT_NONE, c, true))) break;
+        }
+        if (!rc) rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, c, true, true);
+        if (rc) break;
         RGRG_HIP(hipEventRecord(e1, d->stream));
         RGRG_HIP(hipEventSynchronize(e1));
         float ms = 0.f;
         RGRG_HIP(hipEventElapsedTime(&ms, e0, e1));
         total += ms;
-        return RGRG_OK;
-    };
-    for (int it = 0; it < iters && !rc; ++it) {
-        const bool c = it == 0;
-        for (int l = 0; l < d->n_layer && !rc; ++l) {
-            const LayerW& w = d->layers[l];
-            if ((rc = timed(w.c_attn, d->xn, d->qkv, 3 * D, RGRG_ACT_NONE, c))) break;
-            if ((rc = timed(w.attn_proj, d->att, d->h1, D, RGRG_ACT_NONE, c))) break;
-            if ((rc = timed(w.c_fc, d->xn, d->ff, 4 * D, RGRG_ACT_GELU_NEW, c))) break;
-            if ((rc = timed(w.mlp_proj, d->ff, d->h1, D, RGRG_ACT_NONE, c))) break;
-        }
-        if (!rc) rc = timed(d->lm_head, d->xn, d->logits, d->ld_logits, RGRG_ACT_NONE, c);
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
