@@ -27,6 +27,17 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (profiles/): PMC counters
+    cannot be collected from inside the timed process, so the last committed measurement is quoted."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["avg_hbm_bytes_per_gemm_launch"])
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(sd, images, max_length):
     """The CPU oracle (port of the reference's algorithm; oracle/) timed on this host:
     ONE image, full path (detector + selection + 127 decode steps)."""
@@ -118,10 +129,11 @@ def main():
             ms_step, bytes_step, launches = eng.time_decode_gemms(S_dec, iters=3)
             achieved = bytes_step / (ms_step * 1e-3) / 1e9
             res["roofline"] = {"bound": "hbm", "kernel": "rgrg_skinny_gemm_f32", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(),
                                "launches_per_decode_step": launches, "avg_launch_us": 1e3 * ms_step / max(launches, 1),
                                "algorithmic_bytes_per_launch": bytes_step / max(launches, 1),
-                               "note": "fp32 weight bytes streamed once per launch (SURVEY 8(d)); HIP events on the decoder stream"}
+                               "note": "achieved = fp32 weight bytes of the 97 GEMM launches of one decode step / their duration between "
+                                       "two HIP events on the decoder stream; traffic = FETCH_SIZE*2+WRITE_SIZE per launch from profiles/r01_pmc_traffic.json"}
         except Exception as e:  # noqa: BLE001
             res["roofline"] = {"bound": "hbm", "error": str(e)}
         if world == 1 and not args.no_cpu_baseline:

@@ -30,6 +30,7 @@ int launch_gemm_dense(const float* A, const float* W, const float* shift, const 
 int init_gemm_attrs();
 
 constexpr int PAD_ROWS = 32;
+constexpr int SKINNY_MAX_ROWS = 256;  // up to 8 row tiles go through the weight-streaming GEMM
 constexpr int BOS_ID = 50256, EOS_ID = 50256, PAD_ID = 50256;
 constexpr float LN_EPS = 1e-5f;
 
@@ -218,14 +219,16 @@ __global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32(const SkinnyArgs a) 
 }
 
 // Persistent variant for very wide outputs (lm_head: 1571 column tiles, uk/uv: 1536): the
-// grid is ~one workgroup per CU; each workgroup stages the activations ONCE and then walks
-// column tiles nt = blockIdx.x, += gridDim.x, streaming 128 KiB of weights per tile.  Waves
-// 1..7 publish their accumulators through LDS and move on to the next tile's loads while
-// wave 0 sums (fixed order), applies the epilogue and emits the per-tile arg-max candidate.
+// grid is one workgroup per CU; each workgroup stages the (<= 31) activation rows ONCE and
+// then walks column tiles nt = blockIdx.x, += gridDim.x.  A tile's 16 weight chunks per wave
+// live in two 8-chunk register buffers that are refilled with the NEXT tile's chunks as soon
+// as the MFMAs have consumed them, so 8-16 KiB per wave stay in flight through the MFMA
+// phase and the (8-wave parallel, fixed-order) reduction + epilogue of the current tile.
 __global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32_wide(const SkinnyArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int PW = 16, KC = 8, KWG = PW * SK_WAVES * KC, LDX = KWG + 4, XQ = KWG / 64;
-    float* red = smem + 32 * LDX;  // [7][16][64]
+    float* red = smem + a.M * LDX;  // [8][16][64]; rows >= M of the A operand read garbage that only
+                                    // reaches output rows >= M, which are never stored
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunks = a.K / KC;
     {
@@ -240,61 +243,73 @@ __global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32_wide(const SkinnyArg
         for (int q = 0; q < XQ; ++q) {
             const int idx = tid + 512 * q;
             const int row = idx / (KWG / 4), c4 = idx - row * (KWG / 4);
-            *reinterpret_cast<f32x4*>(&smem[row * LDX + c4 * 4]) = xr[q];
+            if (row < a.M) *reinterpret_cast<f32x4*>(&smem[row * LDX + c4 * 4]) = xr[q];
         }
     }
     __syncthreads();
     const float* xa = &smem[(lane & 31) * LDX + wave * PW * KC + (lane >> 5) * 4];
-    for (int nt = blockIdx.x; nt < a.NT; nt += gridDim.x) {
-        const f32x4* wp = reinterpret_cast<const f32x4*>(a.P) + ((size_t)nt * chunks + wave * PW) * 64 + lane;
-        f32x4 w[PW];
+    const f32x4* wbase = reinterpret_cast<const f32x4*>(a.P) + ((size_t)wave * PW) * 64 + lane;
+    f32x4 wa[8], wb[8];
+    auto load8 = [&](f32x4(&w)[8], int nt, int half) {
+        const f32x4* wp = wbase + ((size_t)nt * chunks + half * 8) * 64;
 #pragma unroll
-        for (int c = 0; c < PW; ++c) w[c] = __builtin_nontemporal_load(wp + (size_t)c * 64);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < 8; ++c) w[c] = __builtin_nontemporal_load(wp + (size_t)c * 64);
+    };
+    int nt = blockIdx.x;
+    if (nt < a.NT) { load8(wa, nt, 0); load8(wb, nt, 1); }
+    for (; nt < a.NT; nt += gridDim.x) {
+        const int nxt = nt + gridDim.x;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int c = 0; c < PW; ++c) {
+        for (int c = 0; c < 8; ++c) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(xa + c * KC);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], w[c][j], acc, 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], wa[c][j], acc, 0, 0, 0);
         }
-        __syncthreads();  // wave 0 has finished reading `red` of the previous tile
-        if (wave > 0) {
+        if (nxt < a.NT) load8(wa, nxt, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(xa + (8 + c) * KC);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], wb[c][j], acc, 0, 0, 0);
         }
+        if (nxt < a.NT) load8(wb, nxt, 1);
+        __syncthreads();  // every thread has finished reading `red` of the previous tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
         __syncthreads();
-        if (wave == 0) {
-            const int col = nt * 32 + (lane & 31);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[r];
+        for (int q = 0; q < 2; ++q) {
+            const int idx = tid + 512 * q;
+            const int r = idx >> 6, l = idx & 63;
+            float v = red[r * 64 + l];
 #pragma unroll
-                for (int w2 = 0; w2 < SK_WAVES - 1; ++w2) v += red[(w2 * 16 + r) * 64 + lane];
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                skinny_store(a, row, col, v);
-                if (a.cand_val) {
-                    float bv = (col < a.N) ? v + (a.bias ? a.bias[col] : 0.f) : -INFINITY;
-                    int bi = col;
+            for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[(w2 * 16 + r) * 64 + l];
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+            const int col = nt * 32 + (l & 31);
+            skinny_store(a, row, col, v);
+            if (a.cand_val) {
+                float bv = (col < a.N) ? v + (a.bias ? a.bias[col] : 0.f) : -INFINITY;
+                int bi = col;
 #pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) {
-                        const float ov = __shfl_xor(bv, o, 64);
-                        const int oi = __shfl_xor(bi, o, 64);
-                        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                    }
-                    if ((lane & 31) == 0 && row < a.M) {
-                        a.cand_val[(size_t)row * a.NT + nt] = bv;
-                        a.cand_idx[(size_t)row * a.NT + nt] = bi;
-                    }
+                for (int o = 16; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(bv, o, 64);
+                    const int oi = __shfl_xor(bi, o, 64);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                if ((l & 31) == 0 && row < a.M) {
+                    a.cand_val[(size_t)row * a.NT + nt] = bv;
+                    a.cand_idx[(size_t)row * a.NT + nt] = bi;
                 }
             }
         }
     }
 }
 
-constexpr size_t WIDE_LDS = (size_t)(32 * (16 * SK_WAVES * 8 + 4) + (SK_WAVES - 1) * 16 * 64) * sizeof(float);
+constexpr int WIDE_MAX_ROWS = 31;  // 31 staged rows + the 32 KiB reduction buffer fill the 160 KiB LDS
+constexpr size_t WIDE_LDS = (size_t)(WIDE_MAX_ROWS * (16 * SK_WAVES * 8 + 4) + SK_WAVES * 16 * 64) * sizeof(float);
 static_assert(WIDE_LDS <= 160 * 1024, "wide skinny GEMM must fit the 160 KiB LDS");
 
 template <int NTILE, int PW>
@@ -312,7 +327,7 @@ static int launch_skinny(const SkinnyArgs& a, hipStream_t st) {
 static int launch_skinny_any(int ntile, const SkinnyArgs& a, hipStream_t st) {
     const int kc = ntile == 32 ? 8 : 16;
     const int pw = a.K / (kc * a.KS * SK_WAVES);
-    if (ntile == 32 && pw == 16 && a.KS == 1 && a.NT > 512) {
+    if (ntile == 32 && pw == 16 && a.KS == 1 && a.NT > 512 && a.M <= WIDE_MAX_ROWS) {
         hipLaunchKernelGGL(rgrg_skinny_gemm_f32_wide, dim3(256), dim3(64 * SK_WAVES), WIDE_LDS, st, a);
         RGRG_LAUNCH_CHECK();
         return RGRG_OK;
@@ -392,8 +407,10 @@ __global__ __launch_bounds__(256) void resid_ln_kernel(float* __restrict__ x, co
     const int row = blockIdx.x, tid = threadIdx.x;
     f32x4 v = reinterpret_cast<const f32x4*>(x + (size_t)row * D)[tid];
     if (part) {
-        f32x4 p = reinterpret_cast<const f32x4*>(part + (size_t)row * ldp)[tid];
-        for (int ks = 1; ks < KS; ++ks) p += reinterpret_cast<const f32x4*>(part + ((size_t)ks * PAD_ROWS + row) * ldp)[tid];
+        // partials are stored per 32-row tile: [tile][ks][32][ldp]
+        const float* pt = part + ((size_t)(row >> 5) * KS * PAD_ROWS + (row & 31)) * ldp;
+        f32x4 p = reinterpret_cast<const f32x4*>(pt)[tid];
+        for (int ks = 1; ks < KS; ++ks) p += reinterpret_cast<const f32x4*>(pt + (size_t)ks * PAD_ROWS * ldp)[tid];
         v += p + reinterpret_cast<const f32x4*>(bias)[tid];
         reinterpret_cast<f32x4*>(x + (size_t)row * D)[tid] = v;
     }
@@ -713,19 +730,28 @@ static int init_skinny_attrs() {
 // residual; otherwise a small reduce kernel finishes the job.  > 32 rows: tiled MFMA GEMM.
 static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R, float* Y, int M, int ldy, int act,
                   bool count, bool defer = false, bool cand = false) {
-    if (M <= PAD_ROWS && l.packed) {
-        SkinnyArgs a{X, l.packed, l.b, R, Y, d->part, M, l.K, l.N, l.NT, l.KS, ldy, act, nullptr, nullptr, l.ntile};
-        if (cand && l.KS == 1 && l.ntile == 32) { a.cand_val = d->cand_val; a.cand_idx = d->cand_idx; }
-        int rc = launch_skinny_any(l.ntile, a, d->stream);
-        if (rc) return rc;
-        if (l.KS > 1 && !defer) {
-            const int total = M * l.N;
-            hipLaunchKernelGGL(skinny_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, d->stream, a);
-            RGRG_LAUNCH_CHECK();
+    if (M <= SKINNY_MAX_ROWS && l.packed) {
+        // row tiles of 32 sequences: the weights of the 2nd..nth tile are re-read from L2 / Infinity Cache
+        const int ldp = l.NT * l.ntile;
+        for (int m0 = 0; m0 < M; m0 += PAD_ROWS) {
+            const int mt = m0 / PAD_ROWS, rows = (M - m0 < PAD_ROWS) ? M - m0 : PAD_ROWS;
+            SkinnyArgs a{X + (size_t)m0 * l.K, l.packed, l.b, R ? R + (size_t)m0 * ldy : nullptr, Y + (size_t)m0 * ldy,
+                         d->part + (size_t)mt * l.KS * PAD_ROWS * ldp, rows, l.K, l.N, l.NT, l.KS, ldy, act, nullptr, nullptr, l.ntile};
+            if (cand && l.KS == 1 && l.ntile == 32) {
+                a.cand_val = d->cand_val + (size_t)m0 * l.NT;
+                a.cand_idx = d->cand_idx + (size_t)m0 * l.NT;
+            }
+            int rc = launch_skinny_any(l.ntile, a, d->stream);
+            if (rc) return rc;
+            if (l.KS > 1 && !defer) {
+                const int total = rows * l.N;
+                hipLaunchKernelGGL(skinny_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, d->stream, a);
+                RGRG_LAUNCH_CHECK();
+            }
         }
         if (count) {
             d->gemm_bytes_per_step += (size_t)l.N * l.K * sizeof(float);
-            d->gemm_launches_per_step += 1;
+            d->gemm_launches_per_step += (M + PAD_ROWS - 1) / PAD_ROWS;
         }
         return RGRG_OK;
     }
@@ -739,7 +765,7 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count) {
     if (count) { d->gemm_bytes_per_step = 0; d->gemm_launches_per_step = 0; }
     hipStream_t st = d->stream;
     const int D = d->D;
-    const bool skinny = S <= PAD_ROWS;
+    const bool skinny = S <= SKINNY_MAX_ROWS;
     int rc;
     hipLaunchKernelGGL(embed_ln_kernel, dim3(S), dim3(256), 0, st, d->wte, d->ids, d->max_len, d->step,
                        d->layers[0].ln1_g, d->layers[0].ln1_b, d->x, d->xn, D);
@@ -849,7 +875,7 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     TRY(dmalloc(d, (void**)&d->att, R * D * 4, true));
     TRY(dmalloc(d, (void**)&d->ff, R * 4 * D * 4, true));
     TRY(dmalloc(d, (void**)&d->logits, R * d->ld_logits * 4, true));
-    TRY(dmalloc(d, (void**)&d->part, (size_t)16 * PAD_ROWS * 4 * D * 4, true));  // KS<=16, N<=4096 when KS>1
+    TRY(dmalloc(d, (void**)&d->part, (size_t)(SKINNY_MAX_ROWS / PAD_ROWS) * 8 * PAD_ROWS * D * 4, true));  // [tiles][KS<=8][32][N=1024]
     d->kv_kv_stride = (size_t)d->max_seqs * d->H * d->T * 64;
     d->kv_layer_stride = 2 * d->kv_kv_stride;
     TRY(dmalloc(d, (void**)&d->kv, (size_t)d->n_layer * d->kv_layer_stride * 4, true));
@@ -942,7 +968,7 @@ extern "C" int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S,
 
 extern "C" int rgrg_decoder_time_gemms(rgrg_decoder* d, int S, int iters, float* ms_total, double* bytes_per_iter,
                                        int* launches_per_iter) {
-    RGRG_CHECK_ARG(d && S > 0 && S <= PAD_ROWS && S <= d->max_seqs && iters > 0 && ms_total && bytes_per_iter);
+    RGRG_CHECK_ARG(d && S > 0 && S <= SKINNY_MAX_ROWS && S <= d->max_seqs && iters > 0 && ms_total && bytes_per_iter);
     hipEvent_t e0, e1;
     RGRG_HIP(hipEventCreate(&e0));
     RGRG_HIP(hipEventCreate(&e1));
