@@ -18,6 +18,8 @@
 //    over the 4 waves of a workgroup (+ over workgroups when N is small) and reduced in a
 //    fixed order -> bitwise reproducible.
 //  * > 32 sequences: the same step runs on the tiled MFMA GEMM of gemm_f32.hip.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "common.h"
@@ -26,11 +28,17 @@ namespace rgrg {
 
 struct GemmParams;
 int launch_gemm_dense(const float* A, const float* W, const float* shift, const float* R, float* Y, int M, int N, int K,
-                      int ldy, int act, hipStream_t st);
+                      int ldy, int act, float* ws, size_t ws_floats, hipStream_t st);
 int init_gemm_attrs();
 
 constexpr int PAD_ROWS = 32;
-constexpr int SKINNY_MAX_ROWS = 256;  // up to 8 row tiles go through the weight-streaming GEMM
+constexpr int SKINNY_MAX_ROWS = 256;  // hard cap of the row-tiled weight-streaming path (RGRG_SKINNY_MAX_ROWS)
+static int skinny_max_rows() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("RGRG_SKINNY_MAX_ROWS"); v = e ? atoi(e) : 32;  // measured: beyond one row tile the split-K tiled GEMM wins (10.8 vs 8.7 img/s at batch 4)
+        if (v > SKINNY_MAX_ROWS) v = SKINNY_MAX_ROWS; if (v < 32) v = 32; }
+    return v;
+}
 constexpr int BOS_ID = 50256, EOS_ID = 50256, PAD_ID = 50256;
 constexpr float LN_EPS = 1e-5f;
 
@@ -639,7 +647,8 @@ struct rgrg_decoder {
     Lin fst0, fst2, ukv, lm_head;
     std::vector<LayerW> layers;
     // workspace
-    float *feats, *h1, *img, *ukv_out, *x, *xn, *qkv, *att, *ff, *logits, *part, *kv, *cand_val;
+    float *feats, *h1, *img, *ukv_out, *x, *xn, *qkv, *att, *ff, *logits, *part, *kv, *cand_val, *gemm_ws;
+    size_t gemm_ws_floats;
     int* cand_idx;
     size_t kv_layer_stride, kv_kv_stride;
     int ld_logits, ld_ukv;
@@ -730,7 +739,7 @@ static int init_skinny_attrs() {
 // residual; otherwise a small reduce kernel finishes the job.  > 32 rows: tiled MFMA GEMM.
 static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R, float* Y, int M, int ldy, int act,
                   bool count, bool defer = false, bool cand = false) {
-    if (M <= SKINNY_MAX_ROWS && l.packed) {
+    if (M <= skinny_max_rows() && l.packed) {
         // row tiles of 32 sequences: the weights of the 2nd..nth tile are re-read from L2 / Infinity Cache
         const int ldp = l.NT * l.ntile;
         for (int m0 = 0; m0 < M; m0 += PAD_ROWS) {
@@ -755,7 +764,7 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
         }
         return RGRG_OK;
     }
-    return launch_gemm_dense(X, l.w, l.b, R, Y, M, l.N, l.K, ldy, act, d->stream);
+    return launch_gemm_dense(X, l.w, l.b, R, Y, M, l.N, l.K, ldy, act, d->gemm_ws, d->gemm_ws_floats, d->stream);
 }
 
 // One decode step.  <= 32 sequences: 1 + 24*7 + 2 = 171 launches (lm_head emits arg-max candidates)
@@ -765,7 +774,7 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count) {
     if (count) { d->gemm_bytes_per_step = 0; d->gemm_launches_per_step = 0; }
     hipStream_t st = d->stream;
     const int D = d->D;
-    const bool skinny = S <= SKINNY_MAX_ROWS;
+    const bool skinny = S <= skinny_max_rows();
     int rc;
     hipLaunchKernelGGL(embed_ln_kernel, dim3(S), dim3(256), 0, st, d->wte, d->ids, d->max_len, d->step,
                        d->layers[0].ln1_g, d->layers[0].ln1_b, d->x, d->xn, D);
@@ -887,6 +896,9 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     TRY(dmalloc(d, (void**)&d->sync, 64, true));
     TRY(dmalloc(d, (void**)&d->cand_val, R * d->lm_head.NT * 4, true));
     TRY(dmalloc(d, (void**)&d->cand_idx, R * d->lm_head.NT * 4, true));
+    d->gemm_ws_floats = (d->max_seqs > 32) ? (size_t)16 * R * 4 * D : 0;  // split-K partials of the tiled GEMM
+    d->gemm_ws = nullptr;
+    if (d->gemm_ws_floats) TRY(dmalloc(d, (void**)&d->gemm_ws, d->gemm_ws_floats * 4, false));
 #undef TRY
     if (hipStreamSynchronize(d->stream) != hipSuccess) {
         set_error("decoder: weight packing failed");

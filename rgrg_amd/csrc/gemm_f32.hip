@@ -252,11 +252,21 @@ int launch_gemm(GemmParams p, hipStream_t st) {
     return RGRG_OK;
 }
 
+// Dense GEMM for the decoder's many-sequence path.  `ws` (>= ws_floats floats) lets the K loop be
+// split over workgroups when the output has too few tiles to fill the 256 CUs.
 int launch_gemm_dense(const float* A, const float* W, const float* shift, const float* R, float* Y, int M, int N, int K,
-                      int ldy, int act, hipStream_t st) {
+                      int ldy, int act, float* ws, size_t ws_floats, hipStream_t st) {
     GemmParams p{};
-    p.A = A; p.W = W; p.shift = shift; p.R = R; p.Y = Y;
+    p.A = A; p.W = W; p.shift = shift; p.R = R; p.Y = Y; p.ws = ws;
     p.M = M; p.N = N; p.K = K; p.lda = K; p.ldy = ldy; p.act = act; p.splitk = 1;
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    if (ws && tiles < 256) {
+        int sk = 1;
+        while (sk * 2 <= 16 && tiles * sk < 256 && K % (32 * sk * 2) == 0 && K / (32 * sk * 2) >= 4 &&
+               (size_t)(sk * 2) * M * N <= ws_floats)
+            sk *= 2;
+        p.splitk = sk;
+    }
     return launch_gemm(p, st);
 }
 
