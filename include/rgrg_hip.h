@@ -150,6 +150,16 @@ void rgrg_decoder_destroy(rgrg_decoder* d);
  * before returning.  use_graph=0 launches the kernels eagerly (debug/profiling). */
 int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S, int max_length, int64_t* out_ids,
                           int out_ld, int* out_len, int use_graph, void* stream);
+/* Beam search (LanguageModel.generate num_beams > 1 -> beam_search, language_model.py:450-475,
+ * :529-607, with transformers 4.19.2 BeamSearchScorer semantics, num_return_sequences = 1).
+ * The decoder must have been created with max_seqs >= S*num_beams; 2*num_beams <= 16.
+ * Device side: one decode step over the S*num_beams beam rows (KV cache never re-ordered:
+ * per-slot ancestor table), per-row log-sum-exp + top-2*num_beams, per-item merge.  Host
+ * side (one small D2H/H2D per step, like the reference's scorer): hypothesis bookkeeping.
+ * out_ids int64 [S, out_ld] receives the best hypothesis per item, *out_len its padded length. */
+int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int S, int num_beams, int max_length,
+                             int early_stopping, float length_penalty, int64_t* out_ids, int out_ld, int* out_len,
+                             void* stream);
 /* Debug/parity taps: logits of the LAST executed step [S, vocab] -> dst (device). */
 int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S, void* stream);
 /* Times `iters` replays of one decode step's weight-streaming GEMM launches with HIP

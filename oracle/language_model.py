@@ -121,3 +121,56 @@ def greedy_generate(sd: SD, image_hidden_states: Tensor, max_length: Optional[in
     if return_logits:
         return ids, torch.stack(all_logits, dim=1)
     return ids
+
+
+@torch.no_grad()
+def beam_generate(sd: SD, image_hidden_states: Tensor, max_length: int, num_beams: int, early_stopping: bool = False,
+                  num_return_sequences: int = 1, p: str = "language_model.", return_trace: bool = False):
+    """LanguageModel.generate(num_beams>1) -> beam_search (:450-475, :481-496, :529-607) on top of
+    the restated HF-4.19.2 BeamSearchScorer (length_penalty 1.0).  Returns int64 [S, L]."""
+    from .beam_scorer import BeamSearchScorer
+    S = image_hidden_states.shape[0]
+    scorer = BeamSearchScorer(batch_size=S, num_beams=num_beams, length_penalty=1.0, do_early_stopping=early_stopping,
+                              num_beam_hyps_to_keep=num_return_sequences)
+    expand = torch.arange(S).view(-1, 1).repeat(1, num_beams).view(-1)  # _expand_inputs_for_generation (:481-490)
+    ids = torch.full((S, 1), BOS, dtype=torch.int64).index_select(0, expand)
+    attn = torch.ones((S, 1), dtype=torch.int64).index_select(0, expand)
+    beam_scores = torch.zeros((S, num_beams), dtype=torch.float)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1)
+    past, cur_len, trace = None, 1, []
+    while True:
+        pos = attn.long().cumsum(-1) - 1
+        pos.masked_fill_(attn == 0, 1)
+        inp = ids if past is None else ids[:, -1:]
+        if past is not None:
+            pos = pos[:, -1:]
+        # step 0: uk/uv of the S image features are repeat_interleave'd to S*num_beams rows (:145-150)
+        logits, past = _lm_forward_beams(sd, inp, attn, image_hidden_states, past, pos, num_beams, p)
+        scores = F.log_softmax(logits[:, -1, :], dim=-1) + beam_scores[:, None]
+        V = scores.shape[-1]
+        scores, tokens = torch.topk(scores.view(S, num_beams * V), 2 * num_beams, dim=1, largest=True, sorted=True)
+        indices = torch.div(tokens, V, rounding_mode="floor")
+        tokens = tokens % V
+        if return_trace:
+            trace.append((scores.clone(), tokens.clone(), indices.clone()))
+        out = scorer.process(ids, scores, tokens, indices, pad_token_id=PAD, eos_token_id=EOS)
+        beam_scores, beam_tok, beam_idx = out["next_beam_scores"], out["next_beam_tokens"], out["next_beam_indices"]
+        ids = torch.cat([ids[beam_idx, :], beam_tok.unsqueeze(-1)], dim=-1)
+        attn = torch.cat([attn, attn.new_ones((attn.shape[0], 1))], dim=-1)
+        past = [(k.index_select(0, beam_idx), v.index_select(0, beam_idx)) for k, v in past]  # _reorder_cache (:492-496)
+        cur_len += 1
+        if scorer.is_done or (max_length and cur_len >= max_length):
+            break
+    seq = scorer.finalize(ids, beam_scores, tokens, indices, pad_token_id=PAD, eos_token_id=EOS, max_length=max_length)["sequences"]
+    return (seq, trace) if return_trace else seq
+
+
+def _lm_forward_beams(sd, input_ids, attention_mask, image_hidden_states, past, position_ids, num_beams, p):
+    """lm_forward for S*num_beams token rows and S image rows: the image key/value of a row's
+    batch item is repeated for its beams (GPT2PseudoAttention.forward :145-150)."""
+    if past is not None or num_beams == 1:
+        rep = image_hidden_states.repeat_interleave(num_beams, dim=0) if num_beams > 1 else image_hidden_states
+        return lm_forward(sd, input_ids, attention_mask, rep, past, position_ids, p)
+    # step 0: identical arithmetic on repeated rows (uk/uv are row-wise linear maps)
+    return lm_forward(sd, input_ids, attention_mask, image_hidden_states.repeat_interleave(num_beams, dim=0), None, position_ids, p)

@@ -50,6 +50,7 @@ SIGNATURES = {
     "rgrg_decoder_create": (_i, [C.POINTER(DecoderWeights), _i, _i, C.POINTER(_p)]),
     "rgrg_decoder_destroy": (None, [_p]),
     "rgrg_decoder_generate": (_i, [_p, _p, _i, _i, _p, _i, C.POINTER(_i), _i, _p]),
+    "rgrg_decoder_beam_search": (_i, [_p, _p, _i, _i, _i, _i, _f, _p, _i, C.POINTER(_i), _p]),
     "rgrg_decoder_copy_last_logits": (_i, [_p, _p, _i, _p]),
     "rgrg_decoder_time_gemms": (_i, [_p, _i, _i, C.POINTER(_f), C.POINTER(C.c_double), C.POINTER(_i)]),
     "rgrg_debug_chain": (_i, [_i, _i, _i, C.POINTER(_f)]),

@@ -18,8 +18,10 @@
 //    over the 4 waves of a workgroup (+ over workgroups when N is small) and reduced in a
 //    fixed order -> bitwise reproducible.
 //  * > 32 sequences: the same step runs on the tiled MFMA GEMM of gemm_f32.hip.
+#include <math.h>
 #include <stdlib.h>
 
+#include <cmath>
 #include <vector>
 
 #include "common.h"
@@ -395,10 +397,10 @@ __device__ __forceinline__ f32x4 ln_row(const f32x4 v, const float* __restrict__
 __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__ wte, const long long* __restrict__ ids,
                                                        int ld_ids, const int* __restrict__ step, const float* __restrict__ g,
                                                        const float* __restrict__ b, float* __restrict__ x,
-                                                       float* __restrict__ xn, int D) {
+                                                       float* __restrict__ xn, int D, const int* __restrict__ tok_override) {
     __shared__ float sh[4];
     const int s = blockIdx.x, t = *step, tid = threadIdx.x;
-    const long long tok = ids[(size_t)s * ld_ids + t];
+    const long long tok = tok_override ? (long long)tok_override[s] : ids[(size_t)s * ld_ids + t];  // beam search feeds the beam tokens
     const f32x4 v = reinterpret_cast<const f32x4*>(wte + (size_t)tok * D)[tid] + reinterpret_cast<const f32x4*>(wte + (size_t)t * D)[tid];
     reinterpret_cast<f32x4*>(x + (size_t)s * D)[tid] = v;
     reinterpret_cast<f32x4*>(xn + (size_t)s * D)[tid] = ln_row(v, g, b, sh, D);
@@ -439,7 +441,7 @@ constexpr int ATT_MAXKEYS = 1040;
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                           float* __restrict__ kc, float* __restrict__ vc,
                                                           const int* __restrict__ step, float* __restrict__ out,
-                                                          int S, int H, int T) {
+                                                          int S, int H, int T, const int* __restrict__ src) {
     __shared__ float sc[ATT_MAXKEYS];
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -453,6 +455,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     const f32x4 v4 = *reinterpret_cast<const f32x4*>(row + 2 * D + hd * 64 + d4 * 4);
     float* kbase = kc + ((size_t)s * H + hd) * T * 64;
     float* vbase = vc + ((size_t)s * H + hd) * T * 64;
+    // beam search: slot j of this beam's history lives in the cache row of the ancestor that wrote it
+    // (src[s][j]); the cache is never physically re-ordered (the reference's _reorder_cache, :492-496)
+    const int* srow = src ? src + (size_t)s * T : nullptr;
+    auto kv_off = [&](int j) -> size_t {
+        const size_t r = srow ? (size_t)srow[j] : (size_t)s;
+        return ((r * H + hd) * T + j) * 64 + d4 * 4;
+    };
     if (wave == 0 && g == 0) {
         *reinterpret_cast<f32x4*>(kbase + (size_t)slot * 64 + d4 * 4) = k4;
         *reinterpret_cast<f32x4*>(vbase + (size_t)slot * 64 + d4 * 4) = v4;
@@ -465,14 +474,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
         for (int i = 0; i < ATT_NI; ++i) {
             const int j = base + (i * 4 + wave) * 4 + g;
             kk[i] = zero4;
-            if (j < nkeys) kk[i] = (j == slot) ? k4 : *reinterpret_cast<const f32x4*>(kbase + (size_t)j * 64 + d4 * 4);
+            if (j < nkeys) kk[i] = (j == slot) ? k4 : *reinterpret_cast<const f32x4*>(kc + kv_off(j));
         }
         if (base == 0) {
 #pragma unroll
             for (int i = 0; i < ATT_NI; ++i) {
                 const int j = (i * 4 + wave) * 4 + g;
                 vv0[i] = zero4;
-                if (j < nkeys) vv0[i] = (j == slot) ? v4 : *reinterpret_cast<const f32x4*>(vbase + (size_t)j * 64 + d4 * 4);
+                if (j < nkeys) vv0[i] = (j == slot) ? v4 : *reinterpret_cast<const f32x4*>(vc + kv_off(j));
             }
         }
 #pragma unroll
@@ -500,7 +509,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
             const int j = base + (i * 4 + wave) * 4 + g;
             if (j < nkeys) {
                 f32x4 vv = vv0[i];
-                if (base > 0) vv = (j == slot) ? v4 : *reinterpret_cast<const f32x4*>(vbase + (size_t)j * 64 + d4 * 4);
+                if (base > 0) vv = (j == slot) ? v4 : *reinterpret_cast<const f32x4*>(vc + kv_off(j));
                 const float p = expf(sc[j] - m) / sum;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] += p * vv[e];
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
 // image key/value (uk/uv outputs) -> cache slot 0 of every layer
 __global__ __launch_bounds__(256) void kv_slot0_kernel(const float* __restrict__ ukv, int ld, float* __restrict__ kv_all,
                                                        size_t layer_stride, size_t kv_stride, int S, int H, int T,
-                                                       int L) {
+                                                       int L, int row_mul) {
     const int D = H * 64;
     const size_t total = (size_t)L * 2 * S * D;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(256) void kv_slot0_kernel(const float* __restrict__
         r /= S;
         const int kv = (int)(r & 1), l = (int)(r >> 1);
         const int hd = d >> 6, e = d & 63;
-        kv_all[(size_t)l * layer_stride + (size_t)kv * kv_stride + (((size_t)s * H + hd) * T) * 64 + e] =
+        kv_all[(size_t)l * layer_stride + (size_t)kv * kv_stride + (((size_t)s * row_mul * H + hd) * T) * 64 + e] =
             ukv[(size_t)s * ld + ((size_t)l * 2 + kv) * D + d];
     }
 }
@@ -618,6 +627,130 @@ __global__ __launch_bounds__(256) void decode_reset_kernel(long long* __restrict
     }
 }
 
+// ------------------------------------------------------------------ beam search kernels
+constexpr int BEAM_K = 16;  // max 2*num_beams candidates per row
+
+// Per beam row: max, log-sum-exp and the top-K (value desc, token asc on ties) logits.
+// log_softmax is monotonic within a row, so the row's best continuations are its top logits.
+__global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restrict__ logits, int ld, int V, int K,
+                                                            float* __restrict__ row_max, float* __restrict__ row_logsum,
+                                                            float* __restrict__ top_val, int* __restrict__ top_tok) {
+    __shared__ float sh[4];
+    __shared__ float wv[4];
+    __shared__ int wi[4];
+    __shared__ int winner;
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = logits + (size_t)row * ld;
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i]);
+    m = wave_max(m);
+    if (lane == 0) sh[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    float ssum = 0.f;
+    for (int i = tid; i < V; i += 256) ssum += expf(x[i] - m);
+    ssum = block_sum_256(ssum, sh);
+    // local top-K of this thread's strided elements, sorted (value desc, index asc)
+    float lv[BEAM_K];
+    int li[BEAM_K];
+#pragma unroll
+    for (int k = 0; k < BEAM_K; ++k) { lv[k] = -INFINITY; li[k] = 0x7fffffff; }
+    for (int i = tid; i < V; i += 256) {
+        const float v = x[i];
+        if (v > lv[BEAM_K - 1]) {  // strided indices ascend, so an equal value never displaces an earlier one
+            lv[BEAM_K - 1] = v; li[BEAM_K - 1] = i;
+#pragma unroll
+            for (int k = BEAM_K - 1; k > 0; --k) {
+                if (lv[k] > lv[k - 1]) {
+                    const float tv = lv[k]; lv[k] = lv[k - 1]; lv[k - 1] = tv;
+                    const int ti = li[k]; li[k] = li[k - 1]; li[k - 1] = ti;
+                }
+            }
+        }
+    }
+    // K rounds: block-wide arg-max over the threads' current heads; the winner pops its head
+    for (int round = 0; round < K; ++round) {
+        float bv = lv[0];
+        int bi = li[0];
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { wv[wave] = bv; wi[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (wv[w] > bv || (wv[w] == bv && wi[w] < bi)) { bv = wv[w]; bi = wi[w]; }
+            top_val[(size_t)row * BEAM_K + round] = bv;
+            top_tok[(size_t)row * BEAM_K + round] = bi;
+            winner = bi;
+        }
+        __syncthreads();
+        if (li[0] == winner) {
+#pragma unroll
+            for (int k = 0; k < BEAM_K - 1; ++k) { lv[k] = lv[k + 1]; li[k] = li[k + 1]; }
+            lv[BEAM_K - 1] = -INFINITY; li[BEAM_K - 1] = 0x7fffffff;
+        }
+    }
+    if (tid == 0) { row_max[row] = m; row_logsum[row] = logf(ssum); }
+}
+
+// Per batch item: log_softmax + beam score for the nb*K row candidates, then the top K = 2*nb
+// of the item (score desc; ties: lower flat index beam*V + token first) - language_model.py:545-561.
+__global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ row_max, const float* __restrict__ row_logsum,
+                                                        const float* __restrict__ top_val, const int* __restrict__ top_tok,
+                                                        const float* __restrict__ beam_scores, int nb, int K, int V,
+                                                        float* __restrict__ out_score, int* __restrict__ out_tok,
+                                                        int* __restrict__ out_beam) {
+    const int item = blockIdx.x, lane = threadIdx.x;
+    const int n = nb * K;
+    float sc = -INFINITY;
+    long long flat = 0x7fffffffffffLL;
+    int tok = 0, b = 0;
+    if (lane < n) {
+        b = lane / K;
+        const int row = item * nb + b;
+        const float v = top_val[(size_t)row * BEAM_K + (lane - b * K)];
+        tok = top_tok[(size_t)row * BEAM_K + (lane - b * K)];
+        sc = ((v - row_max[row]) - row_logsum[row]) + beam_scores[row];
+        flat = (long long)b * V + tok;
+    }
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+        const float oj = __shfl(sc, j, 64);
+        const int lo = __shfl((int)(flat & 0xffffffffLL), j, 64), hi = __shfl((int)(flat >> 32), j, 64);
+        const long long fj = ((long long)hi << 32) | (unsigned)lo;
+        if (oj > sc || (oj == sc && fj < flat)) ++rank;
+    }
+    if (lane < n && rank < K) {
+        out_score[item * K + rank] = sc;
+        out_tok[item * K + rank] = tok;
+        out_beam[item * K + rank] = b;
+    }
+}
+
+// New ancestor table after the host picked the surviving beams: row r continues beam parent[r];
+// slots 0..t come from the parent's table, slot t+1 (written this step) lives in the parent's row.
+__global__ __launch_bounds__(256) void beam_advance_kernel(const int* __restrict__ src_old, int* __restrict__ src_new,
+                                                           const int* __restrict__ parent, int* __restrict__ step, int T,
+                                                           int R) {
+    const int r = blockIdx.x, t = *step;
+    const int p = parent[r];
+    for (int j = threadIdx.x; j <= t; j += 256) src_new[(size_t)r * T + j] = src_old[(size_t)p * T + j];
+    if (threadIdx.x == 0) src_new[(size_t)r * T + t + 1] = p;
+    __syncthreads();
+    (void)R;
+}
+__global__ void beam_step_inc_kernel(int* __restrict__ step) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1;
+}
+__global__ __launch_bounds__(256) void beam_init_kernel(int* __restrict__ src, int T, int nb, int R, int* __restrict__ step) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < R) src[(size_t)r * T] = (r / nb) * nb;  // slot 0 (image key/value) is stored once per item, in its first beam row
+    if (r == 0) *step = 0;
+}
+
 // ------------------------------------------------------------------ decoder object
 struct Lin {
     const float* w = nullptr;  // [N,K]
@@ -654,6 +787,9 @@ struct rgrg_decoder {
     int ld_logits, ld_ukv;
     long long* ids;
     int *next, *finished, *step, *done_len, *sync;
+    // beam search
+    int *src_a, *src_b, *beam_tok, *beam_parent, *cand_tok, *cand_beam, *top_tok;
+    float *beam_scores, *row_max, *row_logsum, *top_val, *cand_score;
     int* h_done;  // pinned
     hipStream_t stream;
     hipEvent_t ev_in;
@@ -770,14 +906,15 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
 // One decode step.  <= 32 sequences: 1 + 24*7 + 2 = 171 launches (lm_head emits arg-max candidates)
 //   embed+ln1 | per layer: c_attn, attention, attn_proj(partials), resid+ln2, c_fc+gelu,
 //   mlp_proj(partials), resid+ln1(next layer / ln_f) | lm_head, argmax+bookkeeping
-static int enqueue_step(rgrg_decoder* d, int S, bool count) {
+static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_override = nullptr, const int* src = nullptr,
+                        bool beam = false) {
     if (count) { d->gemm_bytes_per_step = 0; d->gemm_launches_per_step = 0; }
     hipStream_t st = d->stream;
     const int D = d->D;
     const bool skinny = S <= skinny_max_rows();
     int rc;
     hipLaunchKernelGGL(embed_ln_kernel, dim3(S), dim3(256), 0, st, d->wte, d->ids, d->max_len, d->step,
-                       d->layers[0].ln1_g, d->layers[0].ln1_b, d->x, d->xn, D);
+                       d->layers[0].ln1_g, d->layers[0].ln1_b, d->x, d->xn, D, tok_override);
     RGRG_LAUNCH_CHECK();
     for (int l = 0; l < d->n_layer; ++l) {
         const LayerW& w = d->layers[l];
@@ -787,7 +924,7 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count) {
         const float* nb = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_b : d->lnf_b;
         if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, count))) return rc;
         hipLaunchKernelGGL(attn_decode_kernel, dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc, vc, d->step, d->att, S,
-                           d->H, d->T);
+                           d->H, d->T, src);
         RGRG_LAUNCH_CHECK();
         const bool defer_a = skinny && w.attn_proj.KS > 1, defer_m = skinny && w.mlp_proj.KS > 1;
         if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count, defer_a))) return rc;
@@ -800,7 +937,8 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count) {
                            w.mlp_proj.KS, w.mlp_proj.NT * w.mlp_proj.ntile, ng, nb, d->xn, D);
         RGRG_LAUNCH_CHECK();
     }
-    if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, false, true))) return rc;
+    if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, false, !beam))) return rc;
+    if (beam) return RGRG_OK;  // the caller ranks the logits (beam_row_topk / beam_merge)
     if (!(skinny && d->lm_head.KS == 1 && d->lm_head.ntile == 32)) {
         hipLaunchKernelGGL(logits_candidates_kernel, dim3((d->lm_head.NT + 255) / 256, S), dim3(256), 0, st, d->logits,
                            d->ld_logits, d->V, d->lm_head.NT, d->cand_val, d->cand_idx);
@@ -812,7 +950,7 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count) {
     return RGRG_OK;
 }
 
-static int enqueue_prefill(rgrg_decoder* d, const float* feats, int S) {
+static int enqueue_prefill(rgrg_decoder* d, const float* feats, int S, int row_mul = 1) {
     hipStream_t st = d->stream;
     const int D = d->D;
     hipLaunchKernelGGL(decode_reset_kernel, dim3(64), dim3(256), 0, st, d->ids, d->max_len, d->finished, d->step,
@@ -826,7 +964,7 @@ static int enqueue_prefill(rgrg_decoder* d, const float* feats, int S) {
     // uk / uv of all layers in one GEMM, then scatter to cache slot 0
     if ((rc = linear(d, d->ukv, d->img, nullptr, d->ukv_out, S, d->ld_ukv, RGRG_ACT_NONE, false))) return rc;
     hipLaunchKernelGGL(kv_slot0_kernel, dim3(1024), dim3(256), 0, st, d->ukv_out, d->ld_ukv, d->kv, d->kv_layer_stride,
-                       d->kv_kv_stride, S, d->H, d->T, d->n_layer);
+                       d->kv_kv_stride, S, d->H, d->T, d->n_layer, row_mul);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
@@ -896,6 +1034,18 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     TRY(dmalloc(d, (void**)&d->sync, 64, true));
     TRY(dmalloc(d, (void**)&d->cand_val, R * d->lm_head.NT * 4, true));
     TRY(dmalloc(d, (void**)&d->cand_idx, R * d->lm_head.NT * 4, true));
+    TRY(dmalloc(d, (void**)&d->src_a, R * d->T * 4, true));
+    TRY(dmalloc(d, (void**)&d->src_b, R * d->T * 4, true));
+    TRY(dmalloc(d, (void**)&d->beam_tok, R * 4, true));
+    TRY(dmalloc(d, (void**)&d->beam_parent, R * 4, true));
+    TRY(dmalloc(d, (void**)&d->beam_scores, R * 4, true));
+    TRY(dmalloc(d, (void**)&d->row_max, R * 4, true));
+    TRY(dmalloc(d, (void**)&d->row_logsum, R * 4, true));
+    TRY(dmalloc(d, (void**)&d->top_val, R * BEAM_K * 4, true));
+    TRY(dmalloc(d, (void**)&d->top_tok, R * BEAM_K * 4, true));
+    TRY(dmalloc(d, (void**)&d->cand_score, R * BEAM_K * 4, true));
+    TRY(dmalloc(d, (void**)&d->cand_tok, R * BEAM_K * 4, true));
+    TRY(dmalloc(d, (void**)&d->cand_beam, R * BEAM_K * 4, true));
     d->gemm_ws_floats = (d->max_seqs > 32) ? (size_t)16 * R * 4 * D : 0;  // split-K partials of the tiled GEMM
     d->gemm_ws = nullptr;
     if (d->gemm_ws_floats) TRY(dmalloc(d, (void**)&d->gemm_ws, d->gemm_ws_floats * 4, false));
@@ -967,6 +1117,151 @@ extern "C" int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S,
     RGRG_HIP(hipStreamSynchronize(d->stream));
     done = *d->h_done;
     *out_len = (done > 0 && done < limit) ? done : limit;
+    return RGRG_OK;
+}
+
+// ------------------------------------------------------------------ beam search (host side)
+// BeamHypotheses / BeamSearchScorer of transformers 4.19.2 (used by language_model.py:457-464, :570-578,
+// :597-605), restated on the host: hypothesis scores, worst_score and the is_done test are double arithmetic
+// (HF does them on Python floats obtained through .item()), beam scores stay float32.
+namespace rgrg {
+struct Hyp { double score; std::vector<long long> toks; };
+struct BeamHyps {
+    std::vector<Hyp> beams;
+    double worst = 1e9;
+    void add(const std::vector<long long>& toks, double sum_logprobs, int nb, double lp) {
+        const double score = sum_logprobs / std::pow((double)toks.size(), lp);
+        if ((int)beams.size() < nb || score > worst) {
+            beams.push_back({score, toks});
+            if ((int)beams.size() > nb) {
+                int i0 = 0;  // sorted([(score, idx)]): smallest (score, idx) is dropped, worst = the next one
+                for (int i = 1; i < (int)beams.size(); ++i)
+                    if (beams[i].score < beams[i0].score) i0 = i;
+                beams.erase(beams.begin() + i0);
+                double w = beams[0].score;
+                for (auto& h : beams) w = h.score < w ? h.score : w;
+                worst = w;
+            } else {
+                worst = score < worst ? score : worst;
+            }
+        }
+    }
+    bool is_done(double best_sum_logprobs, int cur_len, bool early, int nb, double lp) const {
+        if ((int)beams.size() < nb) return false;
+        if (early) return true;
+        return worst >= best_sum_logprobs / std::pow((double)cur_len, lp);
+    }
+};
+}  // namespace rgrg
+
+extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int S, int num_beams, int max_length,
+                                        int early_stopping, float length_penalty, int64_t* out_ids, int out_ld,
+                                        int* out_len, void* stream) {
+    RGRG_CHECK_ARG(d && feats && out_ids && out_len && S > 0 && num_beams > 1 && 2 * num_beams <= BEAM_K);
+    const int nb = num_beams, K = 2 * nb, R = S * nb;
+    RGRG_CHECK_ARG(R <= d->max_seqs && max_length >= 2 && max_length <= d->max_len && out_ld >= max_length);
+    hipStream_t st = d->stream;
+    RGRG_HIP(hipEventRecord(d->ev_in, as_stream(stream)));
+    RGRG_HIP(hipStreamWaitEvent(st, d->ev_in, 0));
+    // prefill for the S image features; the image key/value of item s is stored in cache row s*nb (slot 0)
+    int rc = enqueue_prefill(d, feats, S, nb);
+    if (rc) return rc;
+    hipLaunchKernelGGL(beam_init_kernel, dim3((R + 255) / 256), dim3(256), 0, st, d->src_a, d->T, nb, R, d->step);
+    RGRG_LAUNCH_CHECK();
+
+    std::vector<std::vector<long long>> ids(R, std::vector<long long>(1, BOS_ID));
+    std::vector<float> beam_scores(R, 0.f), h_score((size_t)S * K);
+    std::vector<int> beam_tok(R, BOS_ID), parent(R, 0), h_tok((size_t)S * K), h_beam((size_t)S * K);
+    for (int r = 0; r < R; ++r) beam_scores[r] = (r % nb == 0) ? 0.f : -1e9f;
+    std::vector<BeamHyps> hyps(S);
+    std::vector<char> done(S, 0);
+    const double lp = (double)length_penalty;
+    int* src_cur = d->src_a;
+    int* src_nxt = d->src_b;
+    int cur_len = 1;
+    std::vector<float> nscore(R);
+    std::vector<int> ntok(R), nidx(R);
+    while (true) {
+        RGRG_HIP(hipMemcpyAsync(d->beam_tok, beam_tok.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
+        RGRG_HIP(hipMemcpyAsync(d->beam_scores, beam_scores.data(), R * sizeof(float), hipMemcpyHostToDevice, st));
+        if ((rc = enqueue_step(d, R, false, d->beam_tok, src_cur, true))) return rc;
+        hipLaunchKernelGGL(beam_row_topk_kernel, dim3(R), dim3(256), 0, st, d->logits, d->ld_logits, d->V, K, d->row_max,
+                           d->row_logsum, d->top_val, d->top_tok);
+        RGRG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(beam_merge_kernel, dim3(S), dim3(64), 0, st, d->row_max, d->row_logsum, d->top_val, d->top_tok,
+                           d->beam_scores, nb, K, d->V, d->cand_score, d->cand_tok, d->cand_beam);
+        RGRG_LAUNCH_CHECK();
+        RGRG_HIP(hipMemcpyAsync(h_score.data(), d->cand_score, (size_t)S * K * sizeof(float), hipMemcpyDeviceToHost, st));
+        RGRG_HIP(hipMemcpyAsync(h_tok.data(), d->cand_tok, (size_t)S * K * sizeof(int), hipMemcpyDeviceToHost, st));
+        RGRG_HIP(hipMemcpyAsync(h_beam.data(), d->cand_beam, (size_t)S * K * sizeof(int), hipMemcpyDeviceToHost, st));
+        RGRG_HIP(hipStreamSynchronize(st));
+        // BeamSearchScorer.process
+        for (int b = 0; b < S; ++b) {
+            if (done[b]) {
+                for (int j = 0; j < nb; ++j) { nscore[b * nb + j] = 0.f; ntok[b * nb + j] = PAD_ID; nidx[b * nb + j] = 0; }
+                continue;
+            }
+            int beam_idx = 0;
+            for (int rank = 0; rank < K; ++rank) {
+                const int tok = h_tok[(size_t)b * K + rank];
+                const float sc = h_score[(size_t)b * K + rank];
+                const int row = b * nb + h_beam[(size_t)b * K + rank];
+                if (tok == EOS_ID) {
+                    if (rank >= nb) continue;
+                    hyps[b].add(ids[row], (double)sc, nb, lp);
+                } else {
+                    nscore[b * nb + beam_idx] = sc; ntok[b * nb + beam_idx] = tok; nidx[b * nb + beam_idx] = row;
+                    ++beam_idx;
+                }
+                if (beam_idx == nb) break;
+            }
+            if (beam_idx < nb) { set_error("beam search: fewer than num_beams non-EOS candidates"); return RGRG_ESTATE; }
+            done[b] = done[b] || hyps[b].is_done((double)h_score[(size_t)b * K], cur_len, early_stopping != 0, nb, lp);
+        }
+        // input_ids = cat(input_ids[beam_idx], tokens); cache "re-order" = new ancestor table
+        std::vector<std::vector<long long>> nids(R);
+        for (int r = 0; r < R; ++r) { nids[r] = ids[nidx[r]]; nids[r].push_back(ntok[r]); }
+        ids.swap(nids);
+        beam_scores = nscore;
+        for (int r = 0; r < R; ++r) { beam_tok[r] = ntok[r]; parent[r] = nidx[r]; }
+        ++cur_len;
+        bool all_done = true;
+        for (int b = 0; b < S; ++b) all_done = all_done && done[b];
+        if (all_done || cur_len >= max_length) break;
+        RGRG_HIP(hipMemcpyAsync(d->beam_parent, parent.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(beam_advance_kernel, dim3(R), dim3(256), 0, st, src_cur, src_nxt, d->beam_parent, d->step, d->T, R);
+        RGRG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(beam_step_inc_kernel, dim3(1), dim3(64), 0, st, d->step);
+        RGRG_LAUNCH_CHECK();
+        int* tmp = src_cur; src_cur = src_nxt; src_nxt = tmp;
+    }
+    // BeamSearchScorer.finalize (num_beam_hyps_to_keep = 1)
+    for (int b = 0; b < S; ++b) {
+        if (done[b]) continue;
+        for (int j = 0; j < nb; ++j) hyps[b].add(ids[b * nb + j], (double)beam_scores[b * nb + j], nb, lp);
+    }
+    std::vector<const std::vector<long long>*> best(S);
+    int max_sent = 0, min_sent = 1 << 30;
+    for (int b = 0; b < S; ++b) {
+        int j0 = 0;  // sorted(key=score) is stable and pop() takes the last: the LAST hypothesis among equal maxima
+        for (int j = 1; j < (int)hyps[b].beams.size(); ++j)
+            if (hyps[b].beams[j].score >= hyps[b].beams[j0].score) j0 = j;
+        best[b] = &hyps[b].beams[j0].toks;
+        const int len = (int)best[b]->size();
+        max_sent = len > max_sent ? len : max_sent;
+        min_sent = len < min_sent ? len : min_sent;
+    }
+    const int L = (max_sent + 1 < max_length) ? max_sent + 1 : max_length;
+    std::vector<long long> dec((size_t)S * L, PAD_ID);
+    for (int b = 0; b < S; ++b) {
+        const int len = (int)best[b]->size();
+        for (int j = 0; j < len && j < L; ++j) dec[(size_t)b * L + j] = (*best[b])[j];
+        if (len < max_length) dec[(size_t)b * L + len] = EOS_ID;
+    }
+    RGRG_HIP(hipMemcpy2DAsync(out_ids, (size_t)out_ld * sizeof(int64_t), dec.data(), (size_t)L * sizeof(long long),
+                              (size_t)L * sizeof(long long), S, hipMemcpyHostToDevice, st));
+    RGRG_HIP(hipStreamSynchronize(st));
+    *out_len = L;
     return RGRG_OK;
 }
 

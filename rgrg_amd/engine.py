@@ -355,6 +355,21 @@ class HipEngine:
                    "rgrg_decoder_generate")
         return out[:, :out_len.value].contiguous()
 
+    def beam_search(self, feats: Tensor, max_length: int, num_beams: int, early_stopping: bool = False,
+                    length_penalty: float = 1.0) -> Tensor:
+        """LanguageModel.generate(num_beams>1, num_return_sequences=1): feats [S,1024] -> int64 [S, L]."""
+        _require_gpu(feats.device)
+        S = feats.shape[0]
+        limit = int(max_length)
+        dec = self._get_decoder(S * num_beams, limit)
+        feats = feats.to(torch.float32).contiguous()
+        out = torch.empty((S, limit), dtype=torch.int64, device=feats.device)
+        out_len = C.c_int(0)
+        _hip.check(self.lib.rgrg_decoder_beam_search(dec, _hip.ptr(feats), S, int(num_beams), limit, 1 if early_stopping else 0,
+                                                     float(length_penalty), _hip.ptr(out), limit, C.byref(out_len), _stream()),
+                   "rgrg_decoder_beam_search")
+        return out[:, :out_len.value].contiguous()
+
     def last_logits(self, S: int) -> Tensor:
         dst = torch.empty((S, self.vocab), dtype=torch.float32, device=self.device)
         _hip.check(self.lib.rgrg_decoder_copy_last_logits(self._decoder, _hip.ptr(dst), S, _stream()), "copy_last_logits")

@@ -4,8 +4,7 @@
 including the three aliased copies of every GPT-2 tensor (``gpt_with_lm_head.transformer.*``,
 ``gpt.*``, ``gpt2_blocks.N.{0,1,2,3}.*``) and the pseudo-attention buffers - but holds
 parameters only.  ``generate`` (language_model.py:401-479) keeps the reference's mode
-checks and exceptions; the greedy mode runs on the HIP decoder, beam search is the next
-row of SURVEY.md 8(f).
+checks and exceptions; greedy and beam search run on the HIP decoder.
 """
 from __future__ import annotations
 
@@ -124,7 +123,13 @@ class LanguageModel(EngineOwner):
                 raise ValueError("'num_return_sequences' has to be smaller or equal to 'num_beams'.")
             if max_length is None:
                 raise ValueError("max_length has to be set for beam generation.")
-            raise NotImplementedError("beam search on the HIP path is the next row of SURVEY.md 8(f); use num_beams=1")
+            if num_return_sequences != 1:
+                raise NotImplementedError("the HIP beam search returns the best hypothesis per region (num_return_sequences=1), "
+                                          "which is what every caller in the reference uses")
+            if 2 * num_beams > 16:
+                raise NotImplementedError("the HIP beam search supports num_beams <= 8")
+            # length_penalty = 1.0 as in the reference (language_model.py:461)
+            return self.engine().beam_search(image_hidden_states, max_length, num_beams, early_stopping, 1.0)
         if is_beam_sample:
             raise NotImplementedError("Beam-search multinomial sampling is not implemented.")
         raise NotImplementedError("Diverse beam-search decoding is not implemented.")

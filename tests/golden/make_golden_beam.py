@@ -1,0 +1,49 @@
+"""Golden fixtures for beam search: the REAL reference's
+``LanguageModel.generate(num_beams=4)`` / ``beam_search`` loop (language_model.py:450-475,
+:529-607) run in the build container on top of the restated HF-4.19.2 ``BeamSearchScorer``
+(``oracle/beam_scorer.py``; the scorer itself is third-party and absent -> unpinned), and the
+oracle's ``beam_generate`` checked against it.
+
+    python tests/golden/make_golden_beam.py
+"""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+import ref_harness  # noqa: E402
+from oracle import language_model as o_lm  # noqa: E402
+from rgrg_amd import synth  # noqa: E402
+
+
+def main():
+    model = ref_harness.reference_model()
+    sd = synth.make_state_dict(0, "ragged")
+    model.load_state_dict(synth.to_reference_state_dict(sd), strict=True)
+    g = torch.Generator().manual_seed(99)
+    feats = torch.randn((5, 1024), generator=g)
+    out = {"meta": {"torch": str(torch.__version__), "reference": "ttanida/rgrg @ /root/reference", "weights_seed": 0,
+                    "profile": "ragged", "feat_seed": 99, "num_beams": 4,
+                    "scorer": "oracle/beam_scorer.py (restated transformers 4.19.2, unpinned)"}, "cases": {}}
+    ok_all = True
+    for name, max_length, early in (("early_stop_len20", 20, True), ("no_early_stop_len16", 16, False), ("len40_early", 40, True)):
+        with torch.no_grad():
+            ref = model.language_model.generate(feats, max_length=max_length, num_beams=4, early_stopping=early)
+        ora = o_lm.beam_generate(sd, feats, max_length, 4, early_stopping=early)
+        ok = ref.shape == ora.shape and torch.equal(ref, ora)
+        ok_all &= ok
+        print(f"{name}: reference {tuple(ref.shape)} oracle {tuple(ora.shape)} match={ok}")
+        out["cases"][name] = {"max_length": max_length, "early_stopping": early, "sequences": ref}
+    out["meta"]["oracle_matches_reference"] = bool(ok_all)
+    torch.save(out, os.path.join(HERE, "lm_beam4.pt"))
+    print("saved lm_beam4.pt; oracle matches reference:", ok_all)
+    return 0 if ok_all else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -5,8 +5,9 @@ reference does not exist there).
 Stubs installed (none of them carries hot-path arithmetic the reference
 authors):
   * ``torchinfo``                         - imported, unused on the path
-  * ``transformers.generation_beam_search`` - removed in transformers 5.x; only
-    the beam path (out of scope for the greedy metric) uses BeamSearchScorer
+  * ``transformers.generation_beam_search`` - removed in transformers 5.x; the
+    stub module carries ``oracle/beam_scorer.py`` (restated 4.19.2 BeamSearchScorer)
+    so that the reference's own ``beam_search`` loop can run
   * ``GPT2LMHeadModel.from_pretrained``   - no network: returns a random-init
     gpt2-medium skeleton whose weights are then overwritten by load_state_dict
   * ``torchvision``                       - ``tv_shim`` over ``oracle/tv013.py``
@@ -31,7 +32,8 @@ def install_stubs():
     sys.modules.setdefault("torchinfo", ti)
     import transformers  # noqa: F401
     gb = types.ModuleType("transformers.generation_beam_search")
-    gb.BeamSearchScorer = None
+    from oracle.beam_scorer import BeamSearchScorer  # restated 4.19.2 class: the installed 5.x no longer ships it
+    gb.BeamSearchScorer = BeamSearchScorer
     sys.modules.setdefault("transformers.generation_beam_search", gb)
     from transformers import GPT2Config, GPT2LMHeadModel
 

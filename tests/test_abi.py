@@ -106,6 +106,8 @@ def test_generation_mode_errors_match_reference(model):
         lm.generate(f, 8, do_sample=True)
     with pytest.raises(ValueError, match="max_length has to be set"):
         lm.generate(f, None, num_beams=4)
+    with pytest.raises(ValueError, match="num_return_sequences"):
+        lm.generate(f, 8, num_beams=2, num_return_sequences=3)
     with pytest.raises(NotImplementedError):
         lm.generate(f, 8, num_beams=4, num_beam_groups=2)
 

@@ -61,3 +61,29 @@ def test_empty_selection_returns_minus_one(sd_ragged):
     feats = torch.zeros((1, 29, 1024))
     sel, f, _ = o_full.region_selection(sd0, feats, torch.ones((1, 29), dtype=torch.bool))
     assert int(sel.sum()) == 0 and f.shape == (0, 1024)
+
+
+def test_beam_search_oracle_matches_reference_loop(sd_ragged):
+    """The reference's own beam_search loop (run over the restated scorer) is reproduced bit-exactly."""
+    fx = load_golden("lm_beam4.pt")
+    assert fx["meta"]["oracle_matches_reference"] is True
+    g = torch.Generator().manual_seed(99)
+    feats = torch.randn((5, 1024), generator=g)
+    c = fx["cases"]["early_stop_len20"]
+    seq = o_lm.beam_generate(sd_ragged, feats, c["max_length"], 4, early_stopping=c["early_stopping"])
+    assert torch.equal(seq, c["sequences"])
+
+
+def test_beam_scorer_hand_case():
+    """Known-answer test of the restated BeamHypotheses (third-party semantics, unpinned otherwise)."""
+    from oracle.beam_scorer import BeamHypotheses
+    h = BeamHypotheses(num_beams=2, length_penalty=1.0, early_stopping=False)
+    h.add(torch.tensor([1, 2, 3, 4]), -4.0)   # score -1.0
+    assert not h.is_done(-0.1, 4)
+    h.add(torch.tensor([1, 2]), -3.0)         # score -1.5 -> worst
+    assert h.worst_score == -1.5 and len(h) == 2
+    h.add(torch.tensor([1, 2, 3]), -1.5)      # score -0.5 replaces the worst (-1.5); new worst -1.0
+    assert len(h) == 2 and h.worst_score == -1.0
+    h.add(torch.tensor([1]), -5.0)            # worse than worst: ignored
+    assert len(h) == 2
+    assert h.is_done(-8.0, 4) and not h.is_done(-2.0, 4)   # -8/4 = -2 <= -1.0 done ; -2/4 = -0.5 > -1.0 not done
