@@ -33,7 +33,8 @@ def region_selection(sd: SD, top_region_features: Tensor, class_detected: Tensor
 
 
 @torch.no_grad()
-def generate(sd: SD, images: Tensor, max_length: Optional[int] = None, return_intermediates: bool = False):
+def generate(sd: SD, images: Tensor, max_length: Optional[int] = None, return_intermediates: bool = False,
+             num_beams: int = 1, early_stopping: bool = False):
     """ReportGenerationModel.generate(images, max_length, num_beams=1): returns
     ``(output_ids, selected_regions, detections, class_detected)`` or the int
     ``-1`` when no region is both detected and selected (:260-261)."""
@@ -41,7 +42,11 @@ def generate(sd: SD, images: Tensor, max_length: Optional[int] = None, return_in
     selected_regions, selected_feats, sel_logits = region_selection(sd, top_region_features, class_detected)
     if selected_feats.shape[0] == 0:
         return -1
-    ids = greedy_generate(sd, selected_feats, max_length)
+    if num_beams > 1:
+        from .language_model import beam_generate
+        ids = beam_generate(sd, selected_feats, max_length, num_beams, early_stopping)
+    else:
+        ids = greedy_generate(sd, selected_feats, max_length)
     if return_intermediates:
         return ids, selected_regions, detections, class_detected, {"top_region_features": top_region_features,
                                                                    "selection_logits": sel_logits}

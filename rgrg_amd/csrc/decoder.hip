@@ -765,8 +765,9 @@ struct LayerW {
 };
 
 struct GraphEntry {
-    int S;
+    int S;  // sequences (greedy) or beam rows; key2 = 0 greedy, 1/2 = beam step reading ancestor table A/B (num_beams in key3)
     hipGraphExec_t exec;
+    int key2 = 0, key3 = 0;
 };
 
 }  // namespace rgrg
@@ -1083,7 +1084,7 @@ extern "C" int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S,
     hipGraphExec_t exec = nullptr;
     if (use_graph) {
         for (auto& g : d->graphs)
-            if (g.S == S) exec = g.exec;
+            if (g.S == S && g.key2 == 0) exec = g.exec;
         if (!exec) {
             hipGraph_t graph = nullptr;
             RGRG_HIP(hipStreamBeginCapture(d->stream, hipStreamCaptureModeThreadLocal));
@@ -1093,7 +1094,7 @@ extern "C" int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S,
             if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return RGRG_EHIP; }
             RGRG_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             (void)hipGraphDestroy(graph);
-            d->graphs.push_back({S, exec});
+            d->graphs.push_back({S, exec, 0, 0});
         }
     }
     const int steps = limit - 1;
@@ -1184,13 +1185,31 @@ extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int
     while (true) {
         RGRG_HIP(hipMemcpyAsync(d->beam_tok, beam_tok.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
         RGRG_HIP(hipMemcpyAsync(d->beam_scores, beam_scores.data(), R * sizeof(float), hipMemcpyHostToDevice, st));
-        if ((rc = enqueue_step(d, R, false, d->beam_tok, src_cur, true))) return rc;
-        hipLaunchKernelGGL(beam_row_topk_kernel, dim3(R), dim3(256), 0, st, d->logits, d->ld_logits, d->V, K, d->row_max,
-                           d->row_logsum, d->top_val, d->top_tok);
-        RGRG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(beam_merge_kernel, dim3(S), dim3(64), 0, st, d->row_max, d->row_logsum, d->top_val, d->top_tok,
-                           d->beam_scores, nb, K, d->V, d->cand_score, d->cand_tok, d->cand_beam);
-        RGRG_LAUNCH_CHECK();
+        {
+            // the step body (embed .. lm_head .. ranking) is captured once per (rows, table parity) and replayed
+            const int parity = (src_cur == d->src_a) ? 1 : 2;
+            hipGraphExec_t exec = nullptr;
+            for (auto& g : d->graphs)
+                if (g.S == R && g.key2 == parity && g.key3 == nb) exec = g.exec;
+            if (!exec) {
+                hipGraph_t graph = nullptr;
+                RGRG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                rc = enqueue_step(d, R, false, d->beam_tok, src_cur, true);
+                if (!rc) {
+                    hipLaunchKernelGGL(beam_row_topk_kernel, dim3(R), dim3(256), 0, st, d->logits, d->ld_logits, d->V, K,
+                                       d->row_max, d->row_logsum, d->top_val, d->top_tok);
+                    hipLaunchKernelGGL(beam_merge_kernel, dim3(S), dim3(64), 0, st, d->row_max, d->row_logsum, d->top_val,
+                                       d->top_tok, d->beam_scores, nb, K, d->V, d->cand_score, d->cand_tok, d->cand_beam);
+                }
+                hipError_t e = hipStreamEndCapture(st, &graph);
+                if (rc) return rc;
+                if (e != hipSuccess) { set_error("beam: hipStreamEndCapture: %s", hipGetErrorString(e)); return RGRG_EHIP; }
+                RGRG_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+                d->graphs.push_back({R, exec, parity, nb});
+            }
+            RGRG_HIP(hipGraphLaunch(exec, st));
+        }
         RGRG_HIP(hipMemcpyAsync(h_score.data(), d->cand_score, (size_t)S * K * sizeof(float), hipMemcpyDeviceToHost, st));
         RGRG_HIP(hipMemcpyAsync(h_tok.data(), d->cand_tok, (size_t)S * K * sizeof(int), hipMemcpyDeviceToHost, st));
         RGRG_HIP(hipMemcpyAsync(h_beam.data(), d->cand_beam, (size_t)S * K * sizeof(int), hipMemcpyDeviceToHost, st));

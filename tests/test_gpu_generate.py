@@ -167,3 +167,15 @@ def test_beam_search_more_regions_vs_oracle():
     assert seq.shape == ref.shape
     bad = (seq.cpu() != ref).any(1)
     assert int(bad.sum()) == 0, f"{int(bad.sum())}/29 rows differ"
+
+
+def test_full_generate_with_beam_search_vs_oracle():
+    """ReportGenerationModel.generate(num_beams=4, early_stopping=True) - the mode of the reference's scripts
+    (generate_reports_for_images.py:108-114) - end to end vs the CPU oracle."""
+    from oracle import full_model as o_full
+    m = gpu_model("ragged")
+    images = synth.make_images(1, 77)
+    ref = o_full.generate(synth_sd("ragged"), images, 12, num_beams=4, early_stopping=True)
+    out = m.generate(images.to(DEV), max_length=12, num_beams=4, early_stopping=True)
+    assert torch.equal(out[1].cpu(), ref[1]) and torch.equal(out[3].cpu(), ref[3])
+    assert out[0].shape == ref[0].shape and torch.equal(out[0].cpu(), ref[0])
