@@ -97,3 +97,15 @@ def object_detector_forward(sd: SD, images: Tensor, p: str = "object_detector.",
         out["_features"], out["_proposals"] = feat, proposals
         return out
     return {}, out["detections"], out["top_region_features"], out["class_detected"]
+
+
+def bbox_features(sd: SD, images: Tensor, bbox_coordinates: List[Tensor], p: str = "object_detector.") -> Tensor:
+    """get_bbox_features (evaluate_bbox_variations/evaluate_bbox_variations.py:92-109): backbone ->
+    box_roi_pool on the GIVEN boxes -> AvgPool2d(8) -> squeeze -> dim_reduction."""
+    feat = tv013.resnet50_trunk(sd, p + "backbone.", images)
+    rois = torch.cat([torch.cat([torch.full((b.shape[0], 1), float(i), dtype=b.dtype), b], 1)
+                      for i, b in enumerate(bbox_coordinates)], 0)
+    scale = tv013.infer_scale(feat.shape[-1], images.shape[-1])
+    pooled = torch.squeeze(F.avg_pool2d(tv013.roi_align(feat, rois, scale, 8, 2), 8))
+    r = p + "roi_heads.dim_reduction."
+    return F.linear(pooled, sd[r + "weight"], sd[r + "bias"])

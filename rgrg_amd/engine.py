@@ -293,6 +293,27 @@ class HipEngine:
         top = self.linear(feats.view(B * NUM_REGIONS, Cf), self.dimred_w, self.dimred_b).view(B, NUM_REGIONS, -1)
         return cd.bool(), scores, boxes, top
 
+    def roi_align_boxes(self, feat_nhwc: Tensor, boxes: List[Tensor]) -> Tuple[Tensor, Tensor]:
+        """RoIAlign(8x8)+avg on caller-supplied boxes (one [n_i,4] xyxy tensor per image):
+        -> (maps [N,64,C] bin-major, pooled [N,C]).  Selection-based generation path
+        (evaluate_bbox_variations.py:92-109)."""
+        B, FH, FW, Cf = feat_nhwc.shape
+        assert len(boxes) == B
+        maxn = max(1, max(int(b.shape[0]) for b in boxes))
+        props = torch.zeros((B, maxn, 4), dtype=torch.float32, device=feat_nhwc.device)
+        offs = [0]
+        for i, b in enumerate(boxes):
+            props[i, : b.shape[0]] = b.to(torch.float32)
+            offs.append(offs[-1] + int(b.shape[0]))
+        offsets = torch.tensor(offs, dtype=torch.int32, device=feat_nhwc.device)
+        R = offs[-1]
+        maps = torch.empty((R, 64, Cf), dtype=torch.float32, device=feat_nhwc.device)
+        pooled = torch.empty((R, Cf), dtype=torch.float32, device=feat_nhwc.device)
+        scale = 2.0 ** round(__import__("math").log2(FH / IMAGE_INPUT_SIZE))
+        _hip.check(self.lib.rgrg_roi_align_avgpool_f32(_hip.ptr(feat_nhwc), _hip.ptr(props), _hip.ptr(offsets), _hip.ptr(maps),
+                                                       _hip.ptr(pooled), B, FH, FW, Cf, maxn, R, scale, _stream()), "rgrg_roi_align")
+        return maps, pooled
+
     def detect(self, images: Tensor, taps: Optional[dict] = None):
         """ObjectDetector.forward (inference): -> (detections, top_region_features, class_detected)."""
         _require_gpu(images.device)

@@ -40,6 +40,59 @@ class Bottleneck(_Holder):
             self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, bias=False), nn.BatchNorm2d(planes * 4))
 
 
+class _Backbone(nn.Sequential):
+    """``self.backbone`` of the reference is callable (evaluate_bbox_variations.py:93): NCHW in, NCHW
+    [B,2048,H/32,W/32] out.  The trunk itself runs NHWC in the HIP engine; the permute is a view."""
+
+    def forward(self, images: Tensor) -> Tensor:
+        eng = self.__dict__["_owner"].engine()
+        return eng.backbone(images.to(torch.float32)).permute(0, 3, 1, 2)
+
+
+class MultiScaleRoIAlign(nn.Module):
+    """Single-level ``box_roi_pool`` (object_detector.py:105-106): features {"0": NCHW}, boxes list of
+    [n_i,4] -> [N,2048,8,8]."""
+
+    def __init__(self):
+        super().__init__()
+        self.output_size = (8, 8)
+        self.sampling_ratio = 2
+
+    def forward(self, features, boxes, image_shapes):
+        heads = self.__dict__["_heads"]
+        eng = heads.__dict__["_owner"].engine()
+        feat = features["0"] if isinstance(features, dict) else features
+        maps, pooled = eng.roi_align_boxes(feat.permute(0, 2, 3, 1).contiguous(), list(boxes))
+        out = maps.view(maps.shape[0], 8, 8, maps.shape[2]).permute(0, 3, 1, 2)
+        heads.__dict__["_last_pool"] = (out, pooled)  # avg_pool of exactly this tensor is already computed (fused kernel)
+        return out
+
+
+class _AvgPool8(nn.Module):
+    """``self.avg_pool = nn.AvgPool2d(8)`` (custom_roi_heads.py:60): [N,C,8,8] -> [N,C,1,1]."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        heads = self.__dict__["_heads"]
+        last = heads.__dict__.get("_last_pool")
+        if last is not None and last[0] is x:
+            return last[1].view(x.shape[0], x.shape[1], 1, 1)
+        eng = heads.__dict__["_owner"].engine()
+        N, Cc = x.shape[:2]
+        w = torch.full((1, 64), 1.0 / 64.0, dtype=torch.float32, device=x.device)
+        return eng.linear(x.reshape(N * Cc, 64).contiguous().to(torch.float32), w, None).view(N, Cc, 1, 1)
+
+
+class _EngineLinear(nn.Linear):
+    """nn.Linear whose forward runs on the f32-MFMA GEMM of the HIP library."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        eng = self.__dict__["_owner"].engine()
+        lead = x.shape[:-1]
+        y = eng.linear(x.reshape(-1, x.shape[-1]).contiguous().to(torch.float32), self.weight.detach().contiguous(),
+                       self.bias.detach().contiguous())
+        return y.view(*lead, -1)
+
+
 def _resnet50_trunk() -> nn.Sequential:
     """children()[:-2] of a ResNet-50 with a 1-channel stem (object_detector.py:51-58)."""
     mods: List[nn.Module] = [nn.Conv2d(1, 64, 7, bias=False), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(3, 2, 1)]
@@ -50,7 +103,7 @@ def _resnet50_trunk() -> nn.Sequential:
             layer.append(Bottleneck(inpl, planes, downsample=(b == 0)))
             inpl = planes * 4
         mods.append(nn.Sequential(*layer))
-    seq = nn.Sequential(*mods)
+    seq = _Backbone(*mods)
     seq.out_channels = 2048
     return seq
 
@@ -87,9 +140,11 @@ class CustomRoIHeads(_Holder):
     def __init__(self, return_feature_vectors: bool):
         super().__init__()
         self.return_feature_vectors = return_feature_vectors
+        self.box_roi_pool = MultiScaleRoIAlign()
         self.box_head = TwoMLPHead(2048 * 8 * 8, 1024)
         self.box_predictor = FastRCNNPredictor(1024, 30)
-        self.dim_reduction = nn.Linear(2048, 1024)
+        self.avg_pool = _AvgPool8()
+        self.dim_reduction = _EngineLinear(2048, 1024)
 
 
 class ImageList:
@@ -113,6 +168,12 @@ class ObjectDetector(EngineOwner):
         self.backbone = _resnet50_trunk()
         self.rpn = CustomRegionProposalNetwork(2048, 160)
         self.roi_heads = CustomRoIHeads(return_feature_vectors)
+        # callable pieces the reference's selection-based generation reaches into (plain attributes: no module cycle)
+        self.backbone.__dict__["_owner"] = self
+        self.roi_heads.__dict__["_owner"] = self
+        self.roi_heads.box_roi_pool.__dict__["_heads"] = self.roi_heads
+        self.roi_heads.avg_pool.__dict__["_heads"] = self.roi_heads
+        self.roi_heads.dim_reduction.__dict__["_owner"] = self
 
     def _transform_inputs_for_rpn_and_roi(self, images, features):
         return ImageList(images), OrderedDict([("0", features)])

@@ -179,3 +179,25 @@ def test_full_generate_with_beam_search_vs_oracle():
     out = m.generate(images.to(DEV), max_length=12, num_beams=4, early_stopping=True)
     assert torch.equal(out[1].cpu(), ref[1]) and torch.equal(out[3].cpu(), ref[3])
     assert out[0].shape == ref[0].shape and torch.equal(out[0].cpu(), ref[0])
+
+
+def test_selection_based_generation_path():
+    """get_bbox_features (user boxes -> RoIAlign -> avgpool -> dim_reduction) + LM generate,
+    through the same attribute accesses the reference's evaluate_bbox_variations.py makes."""
+    from oracle import detector as o_det
+    from rgrg_amd.evaluate_bbox_variations import get_bbox_features
+    m = gpu_model("bench")
+    sd = synth_sd("bench")
+    images = synth.make_images(2, 1234)
+    g = torch.Generator().manual_seed(31)
+    boxes = []
+    for _ in range(2):
+        xy = torch.rand((29, 2), generator=g) * 300
+        boxes.append(torch.cat([xy, xy + 20 + torch.rand((29, 2), generator=g) * 190], 1))
+    ref = o_det.bbox_features(sd, images, boxes)
+    got = get_bbox_features(m, images.to(DEV), [b.to(DEV) for b in boxes])
+    assert got.shape == (58, 1024)
+    err = (got.cpu() - ref).abs().max().item()
+    assert err <= 1e-3 * ref.abs().max().item() + 1e-4, err   # 53 fp32 convs + GEMM, different summation order
+    ids = m.language_model.generate(got[:5], max_length=6)
+    assert torch.equal(ids.cpu(), o_lm.greedy_generate(sd, ref[:5], 6))
