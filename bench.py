@@ -67,7 +67,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (also with one process): one rank per GPU over RCCL ("nccl" on ROCm)
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -84,12 +86,12 @@ def main():
     images = images_cpu.to(dev)
 
     def step():
-        if world > 1:
+        if use_dist:
             return generate_sharded(model, images, args.max_length)
         return model.generate(images, max_length=args.max_length, num_beams=1)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -102,7 +104,7 @@ def main():
         out = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -119,7 +121,7 @@ def main():
             "config": {"workload": f"full_model.generate() batch={args.batch}/GPU, 29 regions, greedy max_len={args.max_length}, fp32"
                                    + (" (BASELINE configs[1])" if args.batch == 1 and args.max_length == 128 else ""),
                        "global_batch": args.batch * world, "regions_generated": S, "tokens_per_region": Lp,
-                       "parallelism": f"dp{world} (image shards, one RCCL all_gather of token ids)" if world > 1 else "single GPU",
+                       "parallelism": f"dp{world} (image shards, one RCCL all_gather of token ids)" if use_dist else "single GPU",
                        "weights": "seeded random init (rgrg_amd.synth, profile bench)", "hipGraph_decode": True},
         }
         # roofline of the dominant kernel: the weight-streaming decode GEMM (HBM-bound at <=32 sequences)
@@ -139,7 +141,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, images_cpu, args.max_length)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 
