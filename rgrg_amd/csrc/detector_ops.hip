@@ -311,6 +311,7 @@ struct RoiTables {
     float l[2][16], h[2][16];
     int dead[2][16];
 };
+constexpr int ROI_SUB = 24;  // RoIs whose sampling tables are resident at once (8 are processed concurrently)
 
 __global__ __launch_bounds__(256) void roi_align_avg_kernel(const float* __restrict__ feat,
                                                             const float* __restrict__ proposals,
@@ -319,9 +320,8 @@ __global__ __launch_bounds__(256) void roi_align_avg_kernel(const float* __restr
                                                             int max_props, float spatial_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int npos = FH * FW;
-    float* slab = reinterpret_cast<float*>(smem_raw);                       // [npos][128]
-    float* red = slab + (size_t)npos * 128;                                  // [8][128]
-    RoiTables* tabs = reinterpret_cast<RoiTables*>(red + 8 * 128);           // [2]
+    float* slab = reinterpret_cast<float*>(smem_raw);                          // [npos][128]
+    RoiTables* tabs = reinterpret_cast<RoiTables*>(slab + (size_t)npos * 128);  // [ROI_SUB]
     const int tid = threadIdx.x;
     const int slab_i = blockIdx.x, chunk = blockIdx.y, nchunk = gridDim.y, b = blockIdx.z;
     const int off = offsets[b], nb = offsets[b + 1] - off;
@@ -335,13 +335,17 @@ __global__ __launch_bounds__(256) void roi_align_avg_kernel(const float* __restr
         *reinterpret_cast<f32x4*>(slab + pos * 128 + c4 * 4) =
             *reinterpret_cast<const f32x4*>(fsrc + (size_t)pos * C + c4 * 4);
     }
-    const int c4 = tid & 31, ph = tid >> 5;  // this thread: bin row ph, channels c4*4..+3
-    for (int r = r0; r < r1; ++r) {
-        RoiTables& T = tabs[r & 1];
-        if (tid < 32) {
-            const int ax = tid >> 4;  // 0: y, 1: x
-            const int sidx = tid & 15, bin = sidx >> 1, g = sidx & 1;
-            const float* pb = proposals + ((size_t)b * max_props + r) * 4;
+    // a 32-lane group owns ONE RoI (all 64 bins of its 4 channels): 8 RoIs in flight per workgroup, no
+    // barrier inside the RoI loop, the 8x8 average stays in registers
+    const int c4 = tid & 31, grp = tid >> 5;
+    for (int s0 = r0; s0 < r1; s0 += ROI_SUB) {
+        const int ns = (r1 - s0 < ROI_SUB) ? r1 - s0 : ROI_SUB;
+        __syncthreads();  // previous sub-chunk's tables are no longer read (also orders the slab fill)
+        for (int i = tid; i < ns * 32; i += 256) {
+            const int rr = i >> 5, t32 = i & 31;
+            const int ax = t32 >> 4;  // 0: y, 1: x
+            const int sidx = t32 & 15, bin = sidx >> 1, g = sidx & 1;
+            const float* pb = proposals + ((size_t)b * max_props + s0 + rr) * 4;
             const float start = (ax ? pb[0] : pb[1]) * spatial_scale;
             const float end = (ax ? pb[2] : pb[3]) * spatial_scale;
             const float roi = fmaxf(end - start, 1.0f);
@@ -353,51 +357,54 @@ __global__ __launch_bounds__(256) void roi_align_avg_kernel(const float* __restr
             int lo = (int)v, hi;
             if (lo >= size - 1) { lo = hi = size - 1; v = (float)lo; } else { hi = lo + 1; }
             const float l = v - (float)lo;
+            RoiTables& T = tabs[rr];
             T.lo[ax][sidx] = lo; T.hi[ax][sidx] = hi; T.l[ax][sidx] = l; T.h[ax][sidx] = 1.0f - l; T.dead[ax][sidx] = dead;
         }
         __syncthreads();
-        float* orow = out + ((size_t)(off + r) * 64 + ph * 8) * C + slab_i * 128 + c4 * 4;
-        f32x4 psum = {0.f, 0.f, 0.f, 0.f};
-        for (int pw = 0; pw < 8; ++pw) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int rr = grp; rr < ns; rr += 8) {
+            const RoiTables& T = tabs[rr];
+            const int r = s0 + rr;
+            float* obase = out + (size_t)(off + r) * 64 * C + slab_i * 128 + c4 * 4;
+            f32x4 total = {0.f, 0.f, 0.f, 0.f};
+            for (int ph = 0; ph < 8; ++ph) {
+                f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+                for (int pw = 0; pw < 8; ++pw) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int iy = 0; iy < 2; ++iy) {
-                const int sy = ph * 2 + iy;
-                const int ylo = T.lo[0][sy], yhi = T.hi[0][sy];
-                const float ly = T.l[0][sy], hy = T.h[0][sy];
-                const int ydead = T.dead[0][sy];
+                    for (int iy = 0; iy < 2; ++iy) {
+                        const int sy = ph * 2 + iy;
+                        const int ylo = T.lo[0][sy], yhi = T.hi[0][sy];
+                        const float ly = T.l[0][sy], hy = T.h[0][sy];
+                        const int ydead = T.dead[0][sy];
 #pragma unroll
-                for (int ix = 0; ix < 2; ++ix) {
-                    const int sx = pw * 2 + ix;
-                    if (ydead | T.dead[1][sx]) continue;  // contributes exactly 0
-                    const int xlo = T.lo[1][sx], xhi = T.hi[1][sx];
-                    const float lx = T.l[1][sx], hx = T.h[1][sx];
-                    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + (ylo * FW + xlo) * 128 + c4 * 4);
-                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(slab + (ylo * FW + xhi) * 128 + c4 * 4);
-                    const f32x4 v3 = *reinterpret_cast<const f32x4*>(slab + (yhi * FW + xlo) * 128 + c4 * 4);
-                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(slab + (yhi * FW + xhi) * 128 + c4 * 4);
+                        for (int ix = 0; ix < 2; ++ix) {
+                            const int sx = pw * 2 + ix;
+                            if (ydead | T.dead[1][sx]) continue;  // contributes exactly 0
+                            const int xlo = T.lo[1][sx], xhi = T.hi[1][sx];
+                            const float lx = T.l[1][sx], hx = T.h[1][sx];
+                            const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                            const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + (ylo * FW + xlo) * 128 + c4 * 4);
+                            const f32x4 v2 = *reinterpret_cast<const f32x4*>(slab + (ylo * FW + xhi) * 128 + c4 * 4);
+                            const f32x4 v3 = *reinterpret_cast<const f32x4*>(slab + (yhi * FW + xlo) * 128 + c4 * 4);
+                            const f32x4 v4 = *reinterpret_cast<const f32x4*>(slab + (yhi * FW + xhi) * 128 + c4 * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float val = w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
-                        acc[e] = acc[e] + val;
+                            for (int e = 0; e < 4; ++e) {
+                                const float val = w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+                                acc[e] = acc[e] + val;
+                            }
+                        }
                     }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc[e] = acc[e] / 4.0f; psum[e] += acc[e]; }
+                    *reinterpret_cast<f32x4*>(obase + (size_t)(ph * 8 + pw) * C) = acc;
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) total[e] += psum[e];  // row sums added in row order (same association as before)
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { acc[e] = acc[e] / 4.0f; psum[e] += acc[e]; }
-            *reinterpret_cast<f32x4*>(orow + (size_t)pw * C) = acc;
+            for (int e = 0; e < 4; ++e) total[e] = total[e] / 64.0f;
+            *reinterpret_cast<f32x4*>(pooled + (size_t)(off + r) * C + slab_i * 128 + c4 * 4) = total;
         }
-        // 8x8 average: reduce the 8 bin rows through LDS
-        *reinterpret_cast<f32x4*>(red + ph * 128 + c4 * 4) = psum;
-        __syncthreads();
-        if (tid < 128) {
-            float t = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) t += red[q * 128 + tid];
-            pooled[(size_t)(off + r) * C + slab_i * 128 + tid] = t / 64.0f;
-        }
-        // red is rewritten only after the next iteration's table barrier -> safe
     }
 }
 
@@ -560,7 +567,7 @@ extern "C" int rgrg_roi_align_avgpool_f32(const float* feat, const float* propos
                                           float* pooled, int B, int FH, int FW, int C, int max_props, int R_total,
                                           float spatial_scale, void* stream) {
     RGRG_CHECK_ARG(feat && proposals && offsets && out && pooled && B > 0 && C % 128 == 0);
-    const size_t lds = (size_t)FH * FW * 128 * 4 + 8 * 128 * 4 + 2 * sizeof(RoiTables);
+    const size_t lds = (size_t)FH * FW * 128 * 4 + ROI_SUB * sizeof(RoiTables);
     RGRG_CHECK_ARG(lds <= 160 * 1024);
     if (R_total <= 0) return RGRG_OK;
     static bool attr_set = false;
