@@ -34,10 +34,10 @@ int launch_gemm_dense(const float* A, const float* W, const float* shift, const 
 int init_gemm_attrs();
 
 constexpr int PAD_ROWS = 32;
-constexpr int SKINNY_MAX_ROWS = 256;  // hard cap of the row-tiled weight-streaming path (RGRG_SKINNY_MAX_ROWS)
+constexpr int SKINNY_MAX_ROWS = 128;  // 4 row tiles of 32 sequences per weight-streaming launch (RGRG_SKINNY_MAX_ROWS)
 static int skinny_max_rows() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("RGRG_SKINNY_MAX_ROWS"); v = e ? atoi(e) : 32;  // measured: beyond one row tile the split-K tiled GEMM wins (10.8 vs 8.7 img/s at batch 4)
+    if (v < 0) { const char* e = getenv("RGRG_SKINNY_MAX_ROWS"); v = e ? atoi(e) : SKINNY_MAX_ROWS;
         if (v > SKINNY_MAX_ROWS) v = SKINNY_MAX_ROWS; if (v < 32) v = 32; }
     return v;
 }
@@ -114,116 +114,131 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 //      order; the 8 per-wave accumulators are summed through LDS in a fixed order.
 // KS == 1: bias / residual / activation epilogue (+ per-tile arg-max candidates for lm_head);
 // KS  > 1: partial sums to a.part, combined by the consumer kernel.
-template <int NTILE, int PW>
+template <int NTILE, int PW, int MT>
 __global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32(const SkinnyArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KC = (NTILE == 32) ? 8 : 16;  // k per weight chunk
     constexpr int KWG = PW * SK_WAVES * KC;      // K slice of this workgroup
     constexpr int LDX = KWG + 4;
     constexpr int XQ = KWG / 64;                 // float4 staging loads per thread (32*KWG/4/512)
+    constexpr int NACC = (NTILE == 32) ? 16 : 8; // accumulator registers per row tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, ks = blockIdx.y;
     const int chunks = a.K / KC;
     const int kc0 = (ks * SK_WAVES + wave) * PW;
     const float* xsrc = a.X + (size_t)ks * KWG;
     f32x4 xr[XQ];
+    auto load_x = [&](int mt) {  // 32 activation rows of row tile mt, fully coalesced
 #pragma unroll
-    for (int q = 0; q < XQ; ++q) {
-        const int idx = tid + 512 * q;
-        const int row = idx / (KWG / 4), c4 = idx - row * (KWG / 4);
-        xr[q] = *reinterpret_cast<const f32x4*>(xsrc + (size_t)row * a.K + c4 * 4);
-    }
+        for (int q = 0; q < XQ; ++q) {
+            const int idx = tid + 512 * q;
+            const int row = idx / (KWG / 4), c4 = idx - row * (KWG / 4);
+            xr[q] = *reinterpret_cast<const f32x4*>(xsrc + (size_t)(mt * 32 + row) * a.K + c4 * 4);
+        }
+    };
+    load_x(0);
     __builtin_amdgcn_sched_barrier(0);  // activations first: they gate the first MFMA
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.P) + ((size_t)nt * chunks + kc0) * 64 + lane;
     f32x4 w[PW];
 #pragma unroll
     for (int c = 0; c < PW; ++c) w[c] = __builtin_nontemporal_load(wp + (size_t)c * 64);
     __builtin_amdgcn_sched_barrier(0);
+    // The weights stay in registers while up to MT row tiles (32 sequences each) are streamed through LDS:
+    // W is fetched from HBM once for up to 128 sequences.
+    float acc[MT][NACC];
 #pragma unroll
-    for (int q = 0; q < XQ; ++q) {
-        const int idx = tid + 512 * q;
-        const int row = idx / (KWG / 4), c4 = idx - row * (KWG / 4);
-        *reinterpret_cast<f32x4*>(&smem[row * LDX + c4 * 4]) = xr[q];
-    }
-    __syncthreads();
-    float* red = smem;  // re-used after the MFMA loop
-    if constexpr (NTILE == 32) {
-        f32x16 acc;
+    for (int mt = 0; mt < MT; ++mt) {
+        if (mt > 0) __syncthreads();  // every wave has finished reading the previous tile
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* xa = &smem[(lane & 31) * LDX + wave * PW * KC + (lane >> 5) * 4];
-#pragma unroll
-        for (int c = 0; c < PW; ++c) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(xa + c * KC);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], w[c][j], acc, 0, 0, 0);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < XQ; ++q) {
             const int idx = tid + 512 * q;
-            const int r = idx >> 6, l = idx & 63;
-            float v = red[r * 64 + l];
+            const int row = idx / (KWG / 4), c4 = idx - row * (KWG / 4);
+            *reinterpret_cast<f32x4*>(&smem[row * LDX + c4 * 4]) = xr[q];
+        }
+        __syncthreads();
+        if (mt + 1 < MT) load_x(mt + 1);  // in flight during this tile's MFMAs
+        if constexpr (NTILE == 32) {
+            f32x16 c16;
 #pragma unroll
-            for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[(w2 * 16 + r) * 64 + l];
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-            const int col = nt * 32 + (l & 31);
-            if (a.KS == 1) {
-                skinny_store(a, row, col, v);
-                if (a.cand_val) {
-                    // fused arg-max: the 32 columns of `row` in this tile live in one 32-lane half; first max wins
-                    float bv = (col < a.N) ? v + (a.bias ? a.bias[col] : 0.f) : -INFINITY;
-                    int bi = col;
+            for (int r = 0; r < 16; ++r) c16[r] = 0.f;
+            const float* xa = &smem[(lane & 31) * LDX + wave * PW * KC + (lane >> 5) * 4];
 #pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) {
-                        const float ov = __shfl_xor(bv, o, 64);
-                        const int oi = __shfl_xor(bi, o, 64);
-                        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                    }
-                    if ((l & 31) == 0 && row < a.M) {
-                        a.cand_val[(size_t)row * a.NT + nt] = bv;
-                        a.cand_idx[(size_t)row * a.NT + nt] = bi;
-                    }
+            for (int c = 0; c < PW; ++c) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(xa + c * KC);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c16 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], w[c][j], c16, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = c16[r];
+        } else {
+            f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const float* xa = &smem[(lane & 15) * LDX + wave * PW * KC + (lane >> 4) * 4];
+#pragma unroll
+            for (int c = 0; c < PW; ++c) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xa + c * KC);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(xa + 16 * LDX + c * KC);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], w[c][j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], w[c][j], acc1, 0, 0, 0);
                 }
-            } else {
-                a.part[((size_t)ks * PAD_ROWS + row) * (a.NT * NTILE) + col] = v;
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc[mt][r] = acc0[r]; acc[mt][4 + r] = acc1[r]; }
         }
-    } else {
-        f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        const float* xa = &smem[(lane & 15) * LDX + wave * PW * KC + (lane >> 4) * 4];
+    }
+    float* red = smem;  // re-used after the MFMA loop
 #pragma unroll
-        for (int c = 0; c < PW; ++c) {
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xa + c * KC);
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(xa + 16 * LDX + c * KC);
+    for (int mt = 0; mt < MT; ++mt) {
+        __syncthreads();  // LDS free: MFMA reads (mt == 0) or the previous tile's reduction are done
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], w[c][j], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], w[c][j], acc1, 0, 0, 0);
+        for (int r = 0; r < NACC; ++r) red[(wave * NACC + r) * 64 + lane] = acc[mt][r];
+        __syncthreads();
+        const int row0 = mt * 32;
+        if constexpr (NTILE == 32) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int idx = tid + 512 * q;
+                const int r = idx >> 6, l = idx & 63;
+                float v = red[r * 64 + l];
+#pragma unroll
+                for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[(w2 * 16 + r) * 64 + l];
+                const int lrow = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                const int row = row0 + lrow;
+                const int col = nt * 32 + (l & 31);
+                if (a.KS == 1) {
+                    skinny_store(a, row, col, v);
+                    if (a.cand_val) {
+                        // fused arg-max: the 32 columns of `row` in this tile live in one 32-lane half; first max wins
+                        float bv = (col < a.N) ? v + (a.bias ? a.bias[col] : 0.f) : -INFINITY;
+                        int bi = col;
+#pragma unroll
+                        for (int o = 16; o > 0; o >>= 1) {
+                            const float ov = __shfl_xor(bv, o, 64);
+                            const int oi = __shfl_xor(bi, o, 64);
+                            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                        }
+                        if ((l & 31) == 0 && row < a.M) {
+                            a.cand_val[(size_t)row * a.NT + nt] = bv;
+                            a.cand_idx[(size_t)row * a.NT + nt] = bi;
+                        }
+                    }
+                } else {
+                    a.part[(((size_t)mt * a.KS + ks) * PAD_ROWS + lrow) * (a.NT * NTILE) + col] = v;
+                }
             }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            red[((wave * 2 + 0) * 4 + r) * 64 + lane] = acc0[r];
-            red[((wave * 2 + 1) * 4 + r) * 64 + lane] = acc1[r];
-        }
-        __syncthreads();
-        {
+        } else {
             // 32 rows x 16 cols = 512 outputs, one per thread.  C/D map of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
-            const int mt = tid >> 8, r = (tid >> 6) & 3, l = tid & 63;
-            float v = red[((0 * 2 + mt) * 4 + r) * 64 + l];
+            const int half = tid >> 8, r = (tid >> 6) & 3, l = tid & 63;
+            float v = red[(0 * 8 + half * 4 + r) * 64 + l];
 #pragma unroll
-            for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[((w2 * 2 + mt) * 4 + r) * 64 + l];
-            const int row = mt * 16 + (l >> 4) * 4 + r;
+            for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[(w2 * 8 + half * 4 + r) * 64 + l];
+            const int lrow = half * 16 + (l >> 4) * 4 + r;
             const int col = nt * 16 + (l & 15);
             if (a.KS == 1)
-                skinny_store(a, row, col, v);
+                skinny_store(a, row0 + lrow, col, v);
             else
-                a.part[((size_t)ks * PAD_ROWS + row) * (a.NT * NTILE) + col] = v;
+                a.part[(((size_t)mt * a.KS + ks) * PAD_ROWS + lrow) * (a.NT * NTILE) + col] = v;
         }
     }
 }
@@ -322,15 +337,26 @@ constexpr int WIDE_MAX_ROWS = 31;  // 31 staged rows + the 32 KiB reduction buff
 constexpr size_t WIDE_LDS = (size_t)(WIDE_MAX_ROWS * (16 * SK_WAVES * 8 + 4) + SK_WAVES * 16 * 64) * sizeof(float);
 static_assert(WIDE_LDS <= 160 * 1024, "wide skinny GEMM must fit the 160 KiB LDS");
 
-template <int NTILE, int PW>
+template <int NTILE, int PW, int MT>
 static int launch_skinny(const SkinnyArgs& a, hipStream_t st) {
     constexpr int KC = (NTILE == 32) ? 8 : 16;
     constexpr size_t lds_x = (size_t)32 * (PW * SK_WAVES * KC + 4) * sizeof(float);
     constexpr size_t lds_r = (size_t)SK_WAVES * (NTILE == 32 ? 16 : 8) * 64 * sizeof(float);
     constexpr size_t lds = lds_x > lds_r ? lds_x : lds_r;
-    hipLaunchKernelGGL((rgrg_skinny_gemm_f32<NTILE, PW>), dim3(a.NT, a.KS), dim3(64 * SK_WAVES), lds, st, a);
+    hipLaunchKernelGGL((rgrg_skinny_gemm_f32<NTILE, PW, MT>), dim3(a.NT, a.KS), dim3(64 * SK_WAVES), lds, st, a);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
+}
+
+template <int NTILE, int PW>
+static int launch_skinny_mt(const SkinnyArgs& a, hipStream_t st) {
+    const int mt = (a.M + PAD_ROWS - 1) / PAD_ROWS;
+    if (mt <= 1) return launch_skinny<NTILE, PW, 1>(a, st);
+    if (mt == 2) return launch_skinny<NTILE, PW, 2>(a, st);
+    if (mt == 3) return launch_skinny<NTILE, PW, 3>(a, st);
+    if (mt == 4) return launch_skinny<NTILE, PW, 4>(a, st);
+    set_error("skinny GEMM: %d rows exceed 4 row tiles", a.M);
+    return RGRG_EINVAL;
 }
 
 // chunks-per-wave PW = K / (KC * KS * 8) must be one of the instantiated values
@@ -343,12 +369,12 @@ static int launch_skinny_any(int ntile, const SkinnyArgs& a, hipStream_t st) {
         return RGRG_OK;
     }
     if (ntile == 32) {
-        if (pw == 4) return launch_skinny<32, 4>(a, st);
-        if (pw == 8) return launch_skinny<32, 8>(a, st);
-        if (pw == 16) return launch_skinny<32, 16>(a, st);
+        if (pw == 4) return launch_skinny_mt<32, 4>(a, st);
+        if (pw == 8) return launch_skinny_mt<32, 8>(a, st);
+        if (pw == 16) return launch_skinny_mt<32, 16>(a, st);
     } else {
-        if (pw == 4) return launch_skinny<16, 4>(a, st);
-        if (pw == 8) return launch_skinny<16, 8>(a, st);
+        if (pw == 4) return launch_skinny_mt<16, 4>(a, st);
+        if (pw == 8) return launch_skinny_mt<16, 8>(a, st);
     }
     set_error("skinny GEMM: unsupported shape K=%d KS=%d ntile=%d (chunks per wave %d)", a.K, a.KS, ntile, pw);
     return RGRG_EINVAL;
@@ -360,7 +386,8 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const SkinnyArgs a) 
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int row = i / a.N, col = i - row * a.N;
         float v = 0.f;
-        for (int ks = 0; ks < a.KS; ++ks) v += a.part[((size_t)ks * PAD_ROWS + row) * ldp + col];
+        const float* pt = a.part + ((size_t)(row >> 5) * a.KS * PAD_ROWS + (row & 31)) * ldp + col;
+        for (int ks = 0; ks < a.KS; ++ks) v += pt[(size_t)ks * PAD_ROWS * ldp];
         skinny_store(a, row, col, v);
     }
 }
@@ -851,13 +878,21 @@ static int make_lin(rgrg_decoder* d, Lin& l, const float* w, const float* b, int
 }
 
 // hipFuncSetAttribute is not capturable: raise the dynamic-LDS limit of every instance up front
-template <int NTILE, int PW>
-static int skinny_attr() {
+template <int NTILE, int PW, int MT>
+static int skinny_attr1() {
     constexpr int KC = (NTILE == 32) ? 8 : 16;
     constexpr size_t lds_x = (size_t)32 * (PW * SK_WAVES * KC + 4) * sizeof(float);
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_gemm_f32<NTILE, PW>),
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_gemm_f32<NTILE, PW, MT>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_x > 65536 ? lds_x : 65536)));
     return RGRG_OK;
+}
+template <int NTILE, int PW>
+static int skinny_attr() {
+    int rc;
+    if ((rc = skinny_attr1<NTILE, PW, 1>())) return rc;
+    if ((rc = skinny_attr1<NTILE, PW, 2>())) return rc;
+    if ((rc = skinny_attr1<NTILE, PW, 3>())) return rc;
+    return skinny_attr1<NTILE, PW, 4>();
 }
 static int init_skinny_attrs() {
     int rc;
@@ -877,27 +912,19 @@ static int init_skinny_attrs() {
 static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R, float* Y, int M, int ldy, int act,
                   bool count, bool defer = false, bool cand = false) {
     if (M <= skinny_max_rows() && l.packed) {
-        // row tiles of 32 sequences: the weights of the 2nd..nth tile are re-read from L2 / Infinity Cache
-        const int ldp = l.NT * l.ntile;
-        for (int m0 = 0; m0 < M; m0 += PAD_ROWS) {
-            const int mt = m0 / PAD_ROWS, rows = (M - m0 < PAD_ROWS) ? M - m0 : PAD_ROWS;
-            SkinnyArgs a{X + (size_t)m0 * l.K, l.packed, l.b, R ? R + (size_t)m0 * ldy : nullptr, Y + (size_t)m0 * ldy,
-                         d->part + (size_t)mt * l.KS * PAD_ROWS * ldp, rows, l.K, l.N, l.NT, l.KS, ldy, act, nullptr, nullptr, l.ntile};
-            if (cand && l.KS == 1 && l.ntile == 32) {
-                a.cand_val = d->cand_val + (size_t)m0 * l.NT;
-                a.cand_idx = d->cand_idx + (size_t)m0 * l.NT;
-            }
-            int rc = launch_skinny_any(l.ntile, a, d->stream);
-            if (rc) return rc;
-            if (l.KS > 1 && !defer) {
-                const int total = rows * l.N;
-                hipLaunchKernelGGL(skinny_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, d->stream, a);
-                RGRG_LAUNCH_CHECK();
-            }
+        // up to 4 row tiles of 32 sequences in ONE launch: the weights stay in registers across the tiles
+        SkinnyArgs a{X, l.packed, l.b, R, Y, d->part, M, l.K, l.N, l.NT, l.KS, ldy, act, nullptr, nullptr, l.ntile};
+        if (cand && l.KS == 1 && l.ntile == 32) { a.cand_val = d->cand_val; a.cand_idx = d->cand_idx; }
+        int rc = launch_skinny_any(l.ntile, a, d->stream);
+        if (rc) return rc;
+        if (l.KS > 1 && !defer) {
+            const int total = M * l.N;
+            hipLaunchKernelGGL(skinny_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, d->stream, a);
+            RGRG_LAUNCH_CHECK();
         }
         if (count) {
             d->gemm_bytes_per_step += (size_t)l.N * l.K * sizeof(float);
-            d->gemm_launches_per_step += (M + PAD_ROWS - 1) / PAD_ROWS;
+            d->gemm_launches_per_step += 1;
         }
         return RGRG_OK;
     }
@@ -1023,7 +1050,7 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     TRY(dmalloc(d, (void**)&d->att, R * D * 4, true));
     TRY(dmalloc(d, (void**)&d->ff, R * 4 * D * 4, true));
     TRY(dmalloc(d, (void**)&d->logits, R * d->ld_logits * 4, true));
-    TRY(dmalloc(d, (void**)&d->part, (size_t)(SKINNY_MAX_ROWS / PAD_ROWS) * 8 * PAD_ROWS * D * 4, true));  // [tiles][KS<=8][32][N=1024]
+    TRY(dmalloc(d, (void**)&d->part, (size_t)(SKINNY_MAX_ROWS / PAD_ROWS) * 8 * PAD_ROWS * D * 4, true));  // [tiles<=4][KS<=8][32][N=1024]
     d->kv_kv_stride = (size_t)d->max_seqs * d->H * d->T * 64;
     d->kv_layer_stride = 2 * d->kv_kv_stride;
     TRY(dmalloc(d, (void**)&d->kv, (size_t)d->n_layer * d->kv_layer_stride * 4, true));
