@@ -311,9 +311,10 @@ struct RoiTables {
     float l[2][16], h[2][16];
     int dead[2][16];
 };
-constexpr int ROI_SUB = 24;  // RoIs whose sampling tables are resident at once (8 are processed concurrently)
+constexpr int ROI_THREADS = 1024;  // 16 waves per CU hide the LDS latency of the 16-tap gathers
+constexpr int ROI_SUB = 32;        // RoIs per sub-chunk = 32-lane groups per workgroup: all processed concurrently
 
-__global__ __launch_bounds__(256) void roi_align_avg_kernel(const float* __restrict__ feat,
+__global__ __launch_bounds__(ROI_THREADS) void roi_align_avg_kernel(const float* __restrict__ feat,
                                                             const float* __restrict__ proposals,
                                                             const int* __restrict__ offsets, float* __restrict__ out,
                                                             float* __restrict__ pooled, int FH, int FW, int C,
@@ -330,18 +331,18 @@ __global__ __launch_bounds__(256) void roi_align_avg_kernel(const float* __restr
     if (r0 >= r1) return;
 
     const float* fsrc = feat + (size_t)b * npos * C + slab_i * 128;
-    for (int i = tid; i < npos * 32; i += 256) {
+    for (int i = tid; i < npos * 32; i += ROI_THREADS) {
         const int pos = i >> 5, c4 = i & 31;
         *reinterpret_cast<f32x4*>(slab + pos * 128 + c4 * 4) =
             *reinterpret_cast<const f32x4*>(fsrc + (size_t)pos * C + c4 * 4);
     }
-    // a 32-lane group owns ONE RoI (all 64 bins of its 4 channels): 8 RoIs in flight per workgroup, no
+    // a 32-lane group owns ONE RoI (all 64 bins of its 4 channels): 32 RoIs in flight per workgroup, no
     // barrier inside the RoI loop, the 8x8 average stays in registers
     const int c4 = tid & 31, grp = tid >> 5;
     for (int s0 = r0; s0 < r1; s0 += ROI_SUB) {
         const int ns = (r1 - s0 < ROI_SUB) ? r1 - s0 : ROI_SUB;
         __syncthreads();  // previous sub-chunk's tables are no longer read (also orders the slab fill)
-        for (int i = tid; i < ns * 32; i += 256) {
+        for (int i = tid; i < ns * 32; i += ROI_THREADS) {
             const int rr = i >> 5, t32 = i & 31;
             const int ax = t32 >> 4;  // 0: y, 1: x
             const int sidx = t32 & 15, bin = sidx >> 1, g = sidx & 1;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void roi_align_avg_kernel(const float* __restr
             T.lo[ax][sidx] = lo; T.hi[ax][sidx] = hi; T.l[ax][sidx] = l; T.h[ax][sidx] = 1.0f - l; T.dead[ax][sidx] = dead;
         }
         __syncthreads();
-        for (int rr = grp; rr < ns; rr += 8) {
+        for (int rr = grp; rr < ns; rr += ROI_THREADS / 32) {
             const RoiTables& T = tabs[rr];
             const int r = s0 + rr;
             float* obase = out + (size_t)(off + r) * 64 * C + slab_i * 128 + c4 * 4;
@@ -577,10 +578,10 @@ extern "C" int rgrg_roi_align_avgpool_f32(const float* feat, const float* propos
         attr_set = true;
     }
     const int slabs = C / 128;
-    int nchunk = (512 + slabs * B - 1) / (slabs * B);  // ~2 workgroups per CU worth of blocks
+    // chunks of <= 32 RoIs (one per 32-lane group); chunks beyond an image's RoI count exit immediately
+    int nchunk = (max_props + ROI_SUB - 1) / ROI_SUB;
     if (nchunk < 1) nchunk = 1;
-    if (nchunk > 64) nchunk = 64;
-    hipLaunchKernelGGL(roi_align_avg_kernel, dim3(slabs, nchunk, B), dim3(256), lds, as_stream(stream), feat, proposals,
+    hipLaunchKernelGGL(roi_align_avg_kernel, dim3(slabs, nchunk, B), dim3(ROI_THREADS), lds, as_stream(stream), feat, proposals,
                        offsets, out, pooled, FH, FW, C, max_props, spatial_scale);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
