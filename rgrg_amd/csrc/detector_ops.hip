@@ -306,10 +306,12 @@ __global__ void prefix_counts_kernel(const int* __restrict__ counts, int* __rest
 // and every RoI of the chunk is then served from LDS: 16 weighted ds_read_b128 per
 // output float4, output rows written as 512-B coalesced runs in [bin][channel] order.
 // ----------------------------------------------------------------------------------
+// Sampling tables of one RoI: per y / x sample (bin*2 + sample) one 16-byte record
+// {lo, hi (int bits), l, h}; a sample outside the map ("dead") gets l = h = 0, so all four of
+// its bilinear weights are exactly 0 and it adds exactly 0 - same result as skipping it.
 struct RoiTables {
-    int lo[2][16], hi[2][16];  // [0]=y samples, [1]=x samples; index = bin*2 + sample
-    float l[2][16], h[2][16];
-    int dead[2][16];
+    f32x4 y[16];
+    f32x4 x[16];
 };
 constexpr int ROI_THREADS = 1024;  // 16 waves per CU hide the LDS latency of the 16-tap gathers
 constexpr int ROI_SUB = 32;        // RoIs per sub-chunk = 32-lane groups per workgroup: all processed concurrently
@@ -358,8 +360,10 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_avg_kernel(const float*
             int lo = (int)v, hi;
             if (lo >= size - 1) { lo = hi = size - 1; v = (float)lo; } else { hi = lo + 1; }
             const float l = v - (float)lo;
-            RoiTables& T = tabs[rr];
-            T.lo[ax][sidx] = lo; T.hi[ax][sidx] = hi; T.l[ax][sidx] = l; T.h[ax][sidx] = 1.0f - l; T.dead[ax][sidx] = dead;
+            f32x4 rec;
+            rec[0] = __int_as_float(lo); rec[1] = __int_as_float(hi);
+            rec[2] = dead ? 0.0f : l; rec[3] = dead ? 0.0f : 1.0f - l;
+            if (ax) tabs[rr].x[sidx] = rec; else tabs[rr].y[sidx] = rec;
         }
         __syncthreads();
         for (int rr = grp; rr < ns; rr += ROI_THREADS / 32) {
@@ -369,20 +373,20 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_avg_kernel(const float*
             f32x4 total = {0.f, 0.f, 0.f, 0.f};
             for (int ph = 0; ph < 8; ++ph) {
                 f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 ty0 = T.y[ph * 2], ty1 = T.y[ph * 2 + 1];
                 for (int pw = 0; pw < 8; ++pw) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 tx0 = T.x[pw * 2], tx1 = T.x[pw * 2 + 1];
 #pragma unroll
                     for (int iy = 0; iy < 2; ++iy) {
-                        const int sy = ph * 2 + iy;
-                        const int ylo = T.lo[0][sy], yhi = T.hi[0][sy];
-                        const float ly = T.l[0][sy], hy = T.h[0][sy];
-                        const int ydead = T.dead[0][sy];
+                        const f32x4 ty = iy ? ty1 : ty0;
+                        const int ylo = __float_as_int(ty[0]), yhi = __float_as_int(ty[1]);
+                        const float ly = ty[2], hy = ty[3];
 #pragma unroll
                         for (int ix = 0; ix < 2; ++ix) {
-                            const int sx = pw * 2 + ix;
-                            if (ydead | T.dead[1][sx]) continue;  // contributes exactly 0
-                            const int xlo = T.lo[1][sx], xhi = T.hi[1][sx];
-                            const float lx = T.l[1][sx], hx = T.h[1][sx];
+                            const f32x4 tx = ix ? tx1 : tx0;
+                            const int xlo = __float_as_int(tx[0]), xhi = __float_as_int(tx[1]);
+                            const float lx = tx[2], hx = tx[3];
                             const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
                             const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + (ylo * FW + xlo) * 128 + c4 * 4);
                             const f32x4 v2 = *reinterpret_cast<const f32x4*>(slab + (ylo * FW + xhi) * 128 + c4 * 4);
