@@ -201,3 +201,37 @@ def test_selection_based_generation_path():
     assert err <= 1e-3 * ref.abs().max().item() + 1e-4, err   # 53 fp32 convs + GEMM, different summation order
     ids = m.language_model.generate(got[:5], max_length=6)
     assert torch.equal(ids.cpu(), o_lm.greedy_generate(sd, ref[:5], 6))
+
+
+# ------------------------------------------------------------------------- shape boundaries of the decode kernels
+@pytest.mark.parametrize("S", [2, 29, 31, 32, 33, 64, 65, 97, 128, 129])
+def test_decoder_sequence_count_boundaries(S):
+    """31/32: persistent lm_head vs tiled fallback; 33..128: 2-4 row tiles per weight-streaming launch;
+    129: split-K tiled GEMM.  Token ids bit-exact vs the CPU oracle in every regime."""
+    m = gpu_model("ragged")
+    g = torch.Generator().manual_seed(1000 + S)
+    feats = torch.randn((S, 1024), generator=g)
+    ref = o_lm.greedy_generate(synth_sd("ragged"), feats, 5)
+    out = m.language_model.generate(feats.to(DEV), max_length=5)
+    assert out.shape == ref.shape
+    bad = (out.cpu() != ref).any(1)
+    assert int(bad.sum()) == 0, f"S={S}: rows {bad.nonzero().flatten().tolist()} differ"
+
+
+def test_decoder_single_step_and_unbounded_length():
+    m = gpu_model("ragged")
+    sd = synth_sd("ragged")
+    feats = _lm_feats()
+    assert torch.equal(m.language_model.generate(feats.to(DEV), max_length=2).cpu(), o_lm.greedy_generate(sd, feats, 2))
+    # max_length=None: the reference stops only when every row has emitted EOS (language_model.py:649)
+    out = m.language_model.generate(feats.to(DEV), max_length=None)
+    assert torch.equal(out.cpu(), o_lm.greedy_generate(sd, feats, None))
+
+
+@pytest.mark.parametrize("nb", [2, 3])
+def test_beam_search_other_beam_widths(nb):
+    m = gpu_model("ragged")
+    feats = _lm_feats()
+    ref = o_lm.beam_generate(synth_sd("ragged"), feats, 14, nb, early_stopping=False)
+    out = m.language_model.generate(feats.to(DEV), max_length=14, num_beams=nb, early_stopping=False)
+    assert out.shape == ref.shape and torch.equal(out.cpu(), ref)
