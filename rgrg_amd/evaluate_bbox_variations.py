@@ -1,16 +1,20 @@
-"""Selection-based sentence generation: the ``get_bbox_features`` path of
-``src/full_model/evaluate_full_model/../evaluate_bbox_variations/evaluate_bbox_variations.py:92-109`` -
-user-supplied boxes -> RoIAlign -> 8x8 average -> dim_reduction -> ``language_model.generate``.
-Same function body as the reference: every attribute it reaches into is HIP-engine backed."""
+"""Selection-based sentence generation: region features for USER-SUPPLIED boxes,
+i.e. the path the reference's bbox-variation study drives by reaching into the detector
+(``evaluate_bbox_variations.py:92-109`` of ttanida/rgrg: backbone -> box_roi_pool on the given boxes -> 8x8
+average -> squeeze -> dim_reduction), followed by ``model.language_model.generate``.  The reference's own
+function works unchanged on ``rgrg_amd.ReportGenerationModel`` because every attribute it touches is callable
+and HIP-engine backed; this module offers the same result through one call that skips the NCHW round trip."""
+from typing import List
+
 import torch
 
 
-def get_bbox_features(model, images, bbox_coordinates):
-    features = model.object_detector.backbone(images)
-    images, features = model.object_detector._transform_inputs_for_rpn_and_roi(images, features)
-    image_shapes = images.image_sizes
-    bbox_roi_pool_feature_maps = model.object_detector.roi_heads.box_roi_pool(features, bbox_coordinates, image_shapes)
-    bbox_features = model.object_detector.roi_heads.avg_pool(bbox_roi_pool_feature_maps)
-    bbox_features = torch.squeeze(bbox_features)
-    bbox_features = model.object_detector.roi_heads.dim_reduction(bbox_features)
-    return bbox_features
+def get_bbox_features(model, images: torch.Tensor, bbox_coordinates: List[torch.Tensor]) -> torch.Tensor:
+    """[sum_i n_i, 1024] region features of the given xyxy boxes (one [n_i,4] tensor per image)."""
+    detector = model.object_detector
+    heads = detector.roi_heads
+    feature_map = detector.backbone(images)                      # NCHW view of the NHWC trunk output
+    wrapped_images, feature_dict = detector._transform_inputs_for_rpn_and_roi(images, feature_map)
+    roi_maps = heads.box_roi_pool(feature_dict, bbox_coordinates, wrapped_images.image_sizes)
+    pooled = torch.squeeze(heads.avg_pool(roi_maps))             # the fused kernel already produced the 8x8 mean
+    return heads.dim_reduction(pooled)

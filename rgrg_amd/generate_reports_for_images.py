@@ -27,12 +27,11 @@ NUM_BEAMS = 4
 
 
 def write_generated_reports_to_txt(images_paths, generated_reports, generated_reports_txt_path):
-    with open(generated_reports_txt_path, "w") as f:
-        for image_path, report in zip(images_paths, generated_reports):
-            f.write(f"Image path: {image_path}\n")
-            f.write(f"Generated report: {report}\n\n")
-            f.write("=" * 30)
-            f.write("\n\n")
+    """One block per image, separated by a 30-character rule (same file format as the reference script)."""
+    rule = "=" * 30
+    blocks = [f"Image path: {path}\nGenerated report: {report}\n\n{rule}\n\n" for path, report in zip(images_paths, generated_reports)]
+    with open(generated_reports_txt_path, "w") as handle:
+        handle.write("".join(blocks))
 
 
 def remove_duplicate_generated_sentences(generated_report, bert_score, sentence_tokenizer):

@@ -103,22 +103,21 @@ class LanguageModel(EngineOwner):
                  num_beam_groups: int = 1, do_sample: bool = False, num_return_sequences: int = 1,
                  early_stopping: bool = False) -> torch.LongTensor:
         """Same contract as language_model.py:401-479: int64 [S, L'] incl. the leading BOS."""
-        is_greedy = (num_beams == 1) and (num_beam_groups == 1) and do_sample is False
-        is_sample = (num_beams == 1) and (num_beam_groups == 1) and do_sample is True
-        is_beam = (num_beams > 1) and (num_beam_groups == 1) and do_sample is False
-        is_beam_sample = (num_beams > 1) and (num_beam_groups == 1) and do_sample is True
-        is_group_beam = (num_beams > 1) and (num_beam_groups > 1)
+        # same mode table, exceptions and messages as the reference's generate() (language_model.py:422-479)
+        single_group = num_beam_groups == 1
         if num_beam_groups > num_beams:
             raise ValueError("'num_beam_groups' has to be smaller or equal to 'num_beams'")
-        if is_group_beam and do_sample is True:
+        if num_beams > 1 and not single_group and do_sample is True:
             raise ValueError("Diverse beam search cannot be used in sampling mode. Make sure that 'do_sample' is set to 'False'.")
-        if is_greedy:
+        if num_beams == 1 and single_group:
+            if do_sample is True:
+                raise NotImplementedError("Multinomial sampling is not implemented.")
             if num_return_sequences > 1:
                 raise ValueError(f"num_return_sequences has to be 1, but is {num_return_sequences} when doing greedy search.")
             return self.engine().greedy_decode(image_hidden_states, max_length)
-        if is_sample:
-            raise NotImplementedError("Multinomial sampling is not implemented.")
-        if is_beam:
+        if num_beams > 1 and single_group:
+            if do_sample is True:
+                raise NotImplementedError("Beam-search multinomial sampling is not implemented.")
             if num_return_sequences > num_beams:
                 raise ValueError("'num_return_sequences' has to be smaller or equal to 'num_beams'.")
             if max_length is None:
@@ -130,6 +129,4 @@ class LanguageModel(EngineOwner):
                 raise NotImplementedError("the HIP beam search supports num_beams <= 8")
             # length_penalty = 1.0 as in the reference (language_model.py:461)
             return self.engine().beam_search(image_hidden_states, max_length, num_beams, early_stopping, 1.0)
-        if is_beam_sample:
-            raise NotImplementedError("Beam-search multinomial sampling is not implemented.")
         raise NotImplementedError("Diverse beam-search decoding is not implemented.")
