@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (BASELINE configs[1]: 1)")
     ap.add_argument("--max-length", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="bf16: run generate() under torch.autocast(bfloat16) - bf16 MFMA decode GEMMs for > 128 sequences "
+                         "(BASELINE configs[2]); not bit-exact, never the default")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,10 +102,14 @@ def main():
     images_cpu = synth.make_images(args.batch, 1234)  # same synthetic shard on every rank (weak scaling)
     images = images_cpu.to(dev)
 
+    import contextlib
+
     def step():
-        if use_dist:
-            return generate_sharded(model, images, args.max_length)
-        return model.generate(images, max_length=args.max_length, num_beams=1)
+        ctx = torch.autocast("cuda", dtype=torch.bfloat16) if args.dtype == "bf16" else contextlib.nullcontext()
+        with ctx:
+            if use_dist:
+                return generate_sharded(model, images, args.max_length)
+            return model.generate(images, max_length=args.max_length, num_beams=1)
 
     def barrier():
         if use_dist:
@@ -131,8 +138,8 @@ def main():
             "metric": "images/sec full 29-region report gen, 512x512 CXR, greedy max_len=128",
             "value": n_images / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"full_model.generate() batch={args.batch}/GPU, 29 regions, greedy max_len={args.max_length}, fp32"
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"full_model.generate() batch={args.batch}/GPU, 29 regions, greedy max_len={args.max_length}, {'fp32' if args.dtype == 'f32' else 'bf16 decode GEMMs (fp32 detector/LN/attention)'}"
                                    + (" (BASELINE configs[1])" if args.batch == 1 and args.max_length == 128 else ""),
                        "global_batch": args.batch * world, "regions_generated": S, "tokens_per_region": Lp,
                        "parallelism": f"dp{world} (image shards, one RCCL all_gather of token ids)" if use_dist else "single GPU",

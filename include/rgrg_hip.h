@@ -160,6 +160,16 @@ int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S, int max_le
 int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int S, int num_beams, int max_length,
                              int early_stopping, float length_penalty, int64_t* out_ids, int out_ld, int* out_len,
                              void* stream);
+/* Opt-in reduced precision for MANY sequences (BASELINE configs[2], batch 32): bf16_gemms = 1 makes the
+ * decode projections of the > 128-sequence path run on the bf16 MFMA (bf16 weights, activations rounded to
+ * bf16 in LDS, fp32 accumulate / LayerNorm / attention / residual).  NOT bit-exact with the fp32 reference;
+ * the <= 128-sequence path (launch-latency bound) always stays fp32.  May allocate and synchronise. */
+int rgrg_decoder_set_precision(rgrg_decoder* d, int bf16_gemms);
+/* fp32 -> bf16 (round to nearest even), and Y = act(bf16(A) Wb^T + shift + R) on v_mfma_f32_32x32x16_bf16
+ * (A fp32 [M,K], Wb bf16 [N,K], K % 64 == 0). */
+int rgrg_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
+int rgrg_linear_bf16w_f32(const float* A, const uint16_t* Wb, const float* shift, const float* R, float* Y, int M,
+                          int N, int K, int ldy, int act, void* stream);
 /* Debug/parity taps: logits of the LAST executed step [S, vocab] -> dst (device). */
 int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S, void* stream);
 /* Times `iters` replays of one decode step's weight-streaming GEMM launches with HIP

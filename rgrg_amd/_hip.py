@@ -51,6 +51,9 @@ SIGNATURES = {
     "rgrg_decoder_destroy": (None, [_p]),
     "rgrg_decoder_generate": (_i, [_p, _p, _i, _i, _p, _i, C.POINTER(_i), _i, _p]),
     "rgrg_decoder_beam_search": (_i, [_p, _p, _i, _i, _i, _i, _f, _p, _i, C.POINTER(_i), _p]),
+    "rgrg_decoder_set_precision": (_i, [_p, _i]),
+    "rgrg_f32_to_bf16": (_i, [_p, _p, C.c_int64, _p]),
+    "rgrg_linear_bf16w_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rgrg_decoder_copy_last_logits": (_i, [_p, _p, _i, _p]),
     "rgrg_decoder_time_gemms": (_i, [_p, _i, _i, C.POINTER(_f), C.POINTER(C.c_double), C.POINTER(_i)]),
     "rgrg_debug_chain": (_i, [_i, _i, _i, C.POINTER(_f)]),

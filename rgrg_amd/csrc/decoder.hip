@@ -32,6 +32,10 @@ struct GemmParams;
 int launch_gemm_dense(const float* A, const float* W, const float* shift, const float* R, float* Y, int M, int N, int K,
                       int ldy, int act, float* ws, size_t ws_floats, hipStream_t st);
 int init_gemm_attrs();
+int init_gemm_bf16_attrs();
+int launch_gemm_bf16w(const float* A, const void* Wb, const float* shift, const float* R, float* Y, int M, int N, int K,
+                      int ldy, int act, hipStream_t st);
+int convert_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st);
 
 constexpr int PAD_ROWS = 32;
 constexpr int SKINNY_MAX_ROWS = 128;  // 4 row tiles of 32 sequences per weight-streaming launch (RGRG_SKINNY_MAX_ROWS)
@@ -783,6 +787,7 @@ struct Lin {
     const float* w = nullptr;  // [N,K]
     const float* b = nullptr;  // [N]
     float* packed = nullptr;   // skinny layout
+    void* wb = nullptr;        // bf16 copy of w (opt-in many-sequence path)
     int N = 0, K = 0, NT = 0, KS = 1, ntile = 32;
 };
 
@@ -824,6 +829,7 @@ struct rgrg_decoder {
     std::vector<GraphEntry> graphs;
     std::vector<void*> allocs;
     size_t gemm_bytes_per_step = 0;
+    int bf16_gemms = 0;  // 1: bf16-weight MFMA GEMMs on the many-sequence path (not bit-exact; opt-in)
     int gemm_launches_per_step = 0;
 };
 
@@ -928,6 +934,7 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
         }
         return RGRG_OK;
     }
+    if (d->bf16_gemms && l.wb && l.K % 64 == 0) return launch_gemm_bf16w(X, l.wb, l.b, R, Y, M, l.N, l.K, ldy, act, d->stream);
     return launch_gemm_dense(X, l.w, l.b, R, Y, M, l.N, l.K, ldy, act, d->gemm_ws, d->gemm_ws_floats, d->stream);
 }
 
@@ -1308,6 +1315,32 @@ extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int
                               (size_t)L * sizeof(long long), S, hipMemcpyHostToDevice, st));
     RGRG_HIP(hipStreamSynchronize(st));
     *out_len = L;
+    return RGRG_OK;
+}
+
+extern "C" int rgrg_decoder_set_precision(rgrg_decoder* d, int bf16_gemms) {
+    RGRG_CHECK_ARG(d && (bf16_gemms == 0 || bf16_gemms == 1));
+    if (bf16_gemms == d->bf16_gemms) return RGRG_OK;
+    if (bf16_gemms) {
+        int rc = init_gemm_bf16_attrs();
+        if (rc) return rc;
+        auto mk = [&](Lin& l) -> int {
+            if (l.wb) return RGRG_OK;
+            int r = dmalloc(d, &l.wb, (size_t)l.N * l.K * 2, false);
+            if (r) return r;
+            return convert_f32_to_bf16(l.w, l.wb, (size_t)l.N * l.K, d->stream);
+        };
+        int rc2;
+        if ((rc2 = mk(d->lm_head))) return rc2;
+        for (auto& w : d->layers) {
+            if ((rc2 = mk(w.c_attn)) || (rc2 = mk(w.attn_proj)) || (rc2 = mk(w.c_fc)) || (rc2 = mk(w.mlp_proj))) return rc2;
+        }
+        RGRG_HIP(hipStreamSynchronize(d->stream));
+    }
+    // captured graphs bake the GEMM choice in: drop them
+    for (auto& g : d->graphs) (void)hipGraphExecDestroy(g.exec);
+    d->graphs.clear();
+    d->bf16_gemms = bf16_gemms;
     return RGRG_OK;
 }
 

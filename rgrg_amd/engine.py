@@ -362,12 +362,14 @@ class HipEngine:
             self._decoder, self._decoder_caps = h, (cap_s, cap_l)
         return self._decoder
 
-    def greedy_decode(self, feats: Tensor, max_length: Optional[int], use_graph: bool = True) -> Tensor:
-        """LanguageModel.generate(num_beams=1): feats [S,1024] -> int64 [S, L']."""
+    def greedy_decode(self, feats: Tensor, max_length: Optional[int], use_graph: bool = True, bf16: bool = False) -> Tensor:
+        """LanguageModel.generate(num_beams=1): feats [S,1024] -> int64 [S, L'].  bf16=True (opt-in through
+        torch.autocast) lets the > 128-sequence path use bf16-weight MFMA GEMMs (not bit-exact)."""
         _require_gpu(feats.device)
         S = feats.shape[0]
         limit = int(max_length) if max_length else 1024  # reference has no bound when None; positions stop at 1024
         dec = self._get_decoder(S, limit)
+        _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")
         feats = feats.to(torch.float32).contiguous()
         out = torch.empty((S, limit), dtype=torch.int64, device=feats.device)
         out_len = C.c_int(0)

@@ -114,7 +114,10 @@ class LanguageModel(EngineOwner):
                 raise NotImplementedError("Multinomial sampling is not implemented.")
             if num_return_sequences > 1:
                 raise ValueError(f"num_return_sequences has to be 1, but is {num_return_sequences} when doing greedy search.")
-            return self.engine().greedy_decode(image_hidden_states, max_length)
+            # like the reference's scripts, callers may wrap generate() in torch.autocast: a reduced-precision
+            # autocast dtype opts the many-sequence decode GEMMs into the bf16 MFMA path
+            low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
+            return self.engine().greedy_decode(image_hidden_states, max_length, bf16=bool(low))
         if num_beams > 1 and single_group:
             if do_sample is True:
                 raise NotImplementedError("Beam-search multinomial sampling is not implemented.")

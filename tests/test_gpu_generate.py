@@ -235,3 +235,25 @@ def test_beam_search_other_beam_widths(nb):
     ref = o_lm.beam_generate(synth_sd("ragged"), feats, 14, nb, early_stopping=False)
     out = m.language_model.generate(feats.to(DEV), max_length=14, num_beams=nb, early_stopping=False)
     assert out.shape == ref.shape and torch.equal(out.cpu(), ref)
+
+
+def test_decoder_bf16_opt_in_for_many_sequences():
+    """BASELINE configs[2] dtype: under torch.autocast(bf16) the > 128-sequence path runs its projections on the bf16
+    MFMA.  Not bit-exact by construction: logits within 3e-2 (bf16 has 8 mantissa bits, 24 layers) and >= 90 % of the
+    greedy tokens equal to the fp32 path over 6 steps; outside autocast the SAME model is exact again."""
+    m = gpu_model("ragged")
+    g = torch.Generator().manual_seed(77)
+    feats = torch.randn((200, 1024), generator=g).to(DEV)
+    exact = m.language_model.generate(feats, max_length=7)
+    ref_logits = m.engine().last_logits(200)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        low = m.language_model.generate(feats, max_length=7)
+    low_logits = m.engine().last_logits(200)
+    L = min(exact.shape[1], low.shape[1])
+    agree = (exact[:, :L] == low[:, :L]).float().mean().item()
+    assert agree >= 0.9, agree
+    rel = ((low_logits - ref_logits).abs().max() / ref_logits.abs().max()).item()
+    assert rel <= 3e-2, rel
+    assert rel > 0.0  # the reduced-precision path really ran
+    again = m.language_model.generate(feats, max_length=7)
+    assert torch.equal(again, exact)

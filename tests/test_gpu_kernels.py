@@ -304,3 +304,37 @@ def test_detector_end_to_end_vs_oracle(eng, oracle_bench):
     assert (det["top_region_boxes"].cpu() - oracle_bench["detections"]["top_region_boxes"]).abs().max() <= 5e-2
     assert (det["top_scores"].cpu() - oracle_bench["detections"]["top_scores"]).abs().max() <= 1e-4
     close(top, oracle_bench["top_region_features"], 1e-3, 1e-4, "top_region_features")
+
+
+# ------------------------------------------------------------------------- bf16-weight GEMM (opt-in path)
+def test_f32_to_bf16_is_round_to_nearest_even(eng):
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn((4099,), generator=g) * 37.0
+    x[:4] = torch.tensor([1.0 + 2 ** -8, 1.0 + 3 * 2 ** -8, -0.0, 65504.0])  # exact ties -> even mantissa
+    xd = x.to(DEV)
+    out = torch.empty((4099,), dtype=torch.int16, device=DEV)
+    _hip.check(eng.lib.rgrg_f32_to_bf16(xd.data_ptr(), out.data_ptr(), 4099, _stream()))
+    assert torch.equal(out.cpu(), x.bfloat16().view(torch.int16))
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(300, 512, 1024, 0, True), (928, 1024, 4096, 2, False), (129, 50257, 1024, 0, False)])
+def test_linear_bf16w(eng, M, N, K, act, res):
+    """bf16 MFMA path (v_mfma_f32_32x32x16_bf16): products of bf16-rounded operands are exact in fp32, so the only
+    difference to a float64 reference on the SAME rounded operands is the fp32 summation order."""
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn((M, K), generator=g)
+    W = torch.randn((N, K), generator=g) / math.sqrt(K)
+    b = torch.randn((N,), generator=g)
+    R = torch.randn((M, N), generator=g) if res else None
+    ref = A.bfloat16().double() @ W.bfloat16().double().t() + b.double()
+    if res:
+        ref = ref + R.double()
+    ref = {0: lambda x: x, 2: lambda x: F.gelu(x, approximate="tanh")}[act](ref)
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), b.to(DEV)
+    Rd = R.to(DEV) if res else None
+    Wb = torch.empty((N, K), dtype=torch.int16, device=DEV)
+    _hip.check(eng.lib.rgrg_f32_to_bf16(Wd.data_ptr(), Wb.data_ptr(), N * K, _stream()))
+    y = torch.empty((M, N), device=DEV)
+    _hip.check(eng.lib.rgrg_linear_bf16w_f32(Ad.data_ptr(), Wb.data_ptr(), bd.data_ptr(), Rd.data_ptr() if res else None,
+                                             y.data_ptr(), M, N, K, N, act, _stream()))
+    close(y, ref, 2e-5, 2e-6, f"bf16w linear {M}x{N}x{K}")
