@@ -630,19 +630,29 @@ __global__ __launch_bounds__(256) void argmax_update_kernel(const float* __restr
     }
 }
 
-// tiled-GEMM path (> 32 sequences): reduce the logits row to per-32-column candidates first
+// tiled-GEMM path (> 128 sequences): reduce the logits row to per-32-column candidates first.  A wave covers two
+// adjacent tiles (64 consecutive logits, one coalesced 256-B load); each 32-lane half reduces with shuffles.
 __global__ __launch_bounds__(256) void logits_candidates_kernel(const float* __restrict__ logits, int ld, int V, int NT,
                                                                 float* __restrict__ cand_val, int* __restrict__ cand_idx) {
-    const int row = blockIdx.y;
-    const int nt = blockIdx.x * 256 + threadIdx.x;
-    if (nt >= NT) return;
-    const float* x = logits + (size_t)row * ld + nt * 32;
-    float best = -INFINITY;
-    int idx = nt * 32;
-    for (int i = 0; i < 32 && nt * 32 + i < V; ++i)
-        if (x[i] > best) { best = x[i]; idx = nt * 32 + i; }
-    cand_val[(size_t)row * NT + nt] = best;
-    cand_idx[(size_t)row * NT + nt] = idx;
+    const int row = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int npair = (NT + 1) / 2;
+    const float* x = logits + (size_t)row * ld;
+    for (int pair = blockIdx.x * 4 + wave; pair < npair; pair += gridDim.x * 4) {
+        const int nt = pair * 2 + (lane >> 5);
+        const int col = nt * 32 + (lane & 31);
+        float bv = (nt < NT && col < V) ? x[col] : -INFINITY;
+        int bi = col;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if ((lane & 31) == 0 && nt < NT) {
+            cand_val[(size_t)row * NT + nt] = bv;
+            cand_idx[(size_t)row * NT + nt] = bi;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void decode_reset_kernel(long long* __restrict__ ids, int ld_ids, int* __restrict__ finished,
@@ -975,8 +985,8 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
     if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, false, !beam))) return rc;
     if (beam) return RGRG_OK;  // the caller ranks the logits (beam_row_topk / beam_merge)
     if (!(skinny && d->lm_head.KS == 1 && d->lm_head.ntile == 32)) {
-        hipLaunchKernelGGL(logits_candidates_kernel, dim3((d->lm_head.NT + 255) / 256, S), dim3(256), 0, st, d->logits,
-                           d->ld_logits, d->V, d->lm_head.NT, d->cand_val, d->cand_idx);
+        hipLaunchKernelGGL(logits_candidates_kernel, dim3(16, S), dim3(256), 0, st, d->logits, d->ld_logits, d->V,
+                           d->lm_head.NT, d->cand_val, d->cand_idx);
         RGRG_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(argmax_update_kernel, dim3(S), dim3(256), 0, st, d->cand_val, d->cand_idx, d->lm_head.NT, d->ids,
