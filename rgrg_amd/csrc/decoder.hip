@@ -465,10 +465,13 @@ __global__ __launch_bounds__(256) void resid_ln_kernel(float* __restrict__ x, co
 // lane), so a wave covers 4 keys and the workgroup 16 keys per iteration.  All K rows (and
 // the V rows of the first 144 keys) are requested up front, so the kernel pays ~2 HBM/L2
 // latencies instead of one per key.
-constexpr int ATT_NI = 9;            // iterations per chunk
-constexpr int ATT_CHUNK = 16 * ATT_NI;  // 144 keys
 constexpr int ATT_MAXKEYS = 1040;
 
+// PRELOAD_V: request the V rows of the first 144 keys together with the K rows (one memory latency per
+// workgroup: best when the grid is < 1 round, i.e. few sequences).  !PRELOAD_V: fetch V after the softmax
+// statistics - half the registers, twice the resident workgroups: best when thousands of (sequence, head)
+// workgroups queue up (batch 32: 14848) and the kernel is throughput bound.
+template <bool PRELOAD_V, int ATT_NI>  // a chunk = 16 * ATT_NI keys (9 -> 144 keys: one chunk up to max_length 142)
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                           float* __restrict__ kc, float* __restrict__ vc,
                                                           const int* __restrict__ step, float* __restrict__ out,
@@ -497,8 +500,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
         *reinterpret_cast<f32x4*>(kbase + (size_t)slot * 64 + d4 * 4) = k4;
         *reinterpret_cast<f32x4*>(vbase + (size_t)slot * 64 + d4 * 4) = v4;
     }
+    constexpr int ATT_CHUNK = 16 * ATT_NI;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 vv0[ATT_NI];
+    if (!PRELOAD_V) {
+#pragma unroll
+        for (int i = 0; i < ATT_NI; ++i) vv0[i] = zero4;
+    }
     for (int base = 0; base < nkeys; base += ATT_CHUNK) {
         f32x4 kk[ATT_NI];
 #pragma unroll
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
             kk[i] = zero4;
             if (j < nkeys) kk[i] = (j == slot) ? k4 : *reinterpret_cast<const f32x4*>(kc + kv_off(j));
         }
-        if (base == 0) {
+        if (PRELOAD_V && base == 0) {
 #pragma unroll
             for (int i = 0; i < ATT_NI; ++i) {
                 const int j = (i * 4 + wave) * 4 + g;
@@ -540,7 +548,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
             const int j = base + (i * 4 + wave) * 4 + g;
             if (j < nkeys) {
                 f32x4 vv = vv0[i];
-                if (base > 0) vv = (j == slot) ? v4 : *reinterpret_cast<const f32x4*>(vc + kv_off(j));
+                if (!PRELOAD_V || base > 0) vv = (j == slot) ? v4 : *reinterpret_cast<const f32x4*>(vc + kv_off(j));
                 const float p = expf(sc[j] - m) / sum;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] += p * vv[e];
@@ -968,8 +976,12 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
         const float* ng = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_g : d->lnf_g;
         const float* nb = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_b : d->lnf_b;
         if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, count))) return rc;
-        hipLaunchKernelGGL(attn_decode_kernel, dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc, vc, d->step, d->att, S,
-                           d->H, d->T, src);
+        if (S * d->H <= 4096)
+            hipLaunchKernelGGL((attn_decode_kernel<true, 9>), dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc, vc, d->step,
+                               d->att, S, d->H, d->T, src);
+        else
+            hipLaunchKernelGGL((attn_decode_kernel<false, 5>), dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc, vc, d->step,
+                               d->att, S, d->H, d->T, src);
         RGRG_LAUNCH_CHECK();
         const bool defer_a = skinny && w.attn_proj.KS > 1, defer_m = skinny && w.mlp_proj.KS > 1;
         if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count, defer_a))) return rc;
