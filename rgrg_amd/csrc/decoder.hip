@@ -570,8 +570,148 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     }
 }
 
+// bf16 helpers for the opt-in bf16 K/V cache (torch.autocast(bf16) in the reference makes c_attn's output,
+// hence ``present``, bf16 as well)
+typedef unsigned short u16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned bf16_rne_bits(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf16_round(float f) { return __uint_as_float(bf16_rne_bits(f) << 16); }
+
+// Same attention with a bf16 K/V cache (half the bytes of the kernel's only real traffic).  An 8-lane group
+// owns one key (8 dims = one 16-byte load per lane), a wave covers 8 keys and the workgroup 32 keys per
+// pass; q, the scores, the softmax and the accumulation stay fp32.  The new token's k/v are rounded once and
+// the rounded values are used here too, so this step and later steps see the same numbers.
+template <int ATT_NI>  // a chunk = 32 * ATT_NI keys
+__global__ __launch_bounds__(256) void attn_decode_kv16_kernel(const float* __restrict__ qkv, int ld_qkv,
+                                                               u16* __restrict__ kc, u16* __restrict__ vc,
+                                                               const int* __restrict__ step, float* __restrict__ out,
+                                                               int S, int H, int T, const int* __restrict__ src) {
+    __shared__ float sc[ATT_MAXKEYS];
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = blockIdx.x / H, hd = blockIdx.x - s * H;
+    const int t = *step, nkeys = t + 2, slot = t + 1;
+    const int g = lane >> 3, d8 = lane & 7;
+    const float* row = qkv + (size_t)s * ld_qkv;
+    const int D = H * 64;
+    float q[8], kn[8], vn[8];
+    {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(row + hd * 64 + d8 * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(row + hd * 64 + d8 * 8 + 4);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(row + D + hd * 64 + d8 * 8);
+        const f32x4 e = *reinterpret_cast<const f32x4*>(row + D + hd * 64 + d8 * 8 + 4);
+        const f32x4 f = *reinterpret_cast<const f32x4*>(row + 2 * D + hd * 64 + d8 * 8);
+        const f32x4 h = *reinterpret_cast<const f32x4*>(row + 2 * D + hd * 64 + d8 * 8 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            q[i] = a[i]; q[4 + i] = b[i];
+            kn[i] = bf16_round(c[i]); kn[4 + i] = bf16_round(e[i]);
+            vn[i] = bf16_round(f[i]); vn[4 + i] = bf16_round(h[i]);
+        }
+    }
+    const int* srow = src ? src + (size_t)s * T : nullptr;
+    auto kv_off = [&](int j) -> size_t {
+        const size_t r = srow ? (size_t)srow[j] : (size_t)s;
+        return ((r * H + hd) * T + j) * 64 + d8 * 8;
+    };
+    auto pack8 = [](const float* v) -> u32x4 {
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (__float_as_uint(v[2 * i]) >> 16) | (__float_as_uint(v[2 * i + 1]) & 0xffff0000u);
+        return o;
+    };
+    if (wave == 0 && g == 0) {
+        const size_t o = (((size_t)s * H + hd) * T + slot) * 64 + d8 * 8;
+        *reinterpret_cast<u32x4*>(kc + o) = pack8(kn);
+        *reinterpret_cast<u32x4*>(vc + o) = pack8(vn);
+    }
+    constexpr int ATT_CHUNK = 32 * ATT_NI;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    for (int base = 0; base < nkeys; base += ATT_CHUNK) {
+        u32x4 kk[ATT_NI];
+#pragma unroll
+        for (int i = 0; i < ATT_NI; ++i) {
+            const int j = base + (i * 4 + wave) * 8 + g;
+            kk[i] = zero;
+            if (j < nkeys && j != slot) kk[i] = *reinterpret_cast<const u32x4*>(kc + kv_off(j));
+        }
+#pragma unroll
+        for (int i = 0; i < ATT_NI; ++i) {
+            const int j = base + (i * 4 + wave) * 8 + g;
+            float dot = 0.f;
+            if (j == slot) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dot += q[e] * kn[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    dot += q[2 * e] * __uint_as_float(kk[i][e] << 16) + q[2 * e + 1] * __uint_as_float(kk[i][e] & 0xffff0000u);
+            }
+            dot += __shfl_xor(dot, 1, 64);
+            dot += __shfl_xor(dot, 2, 64);
+            dot += __shfl_xor(dot, 4, 64);
+            if (d8 == 0 && j < nkeys) sc[j] = dot / 8.0f;
+        }
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = lane; j < nkeys; j += 64) m = fmaxf(m, sc[j]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < nkeys; j += 64) sum += expf(sc[j] - m);
+    sum = wave_sum(sum);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int base = 0; base < nkeys; base += ATT_CHUNK) {
+        u32x4 vv[ATT_NI];
+#pragma unroll
+        for (int i = 0; i < ATT_NI; ++i) {
+            const int j = base + (i * 4 + wave) * 8 + g;
+            vv[i] = zero;
+            if (j < nkeys && j != slot) vv[i] = *reinterpret_cast<const u32x4*>(vc + kv_off(j));
+        }
+#pragma unroll
+        for (int i = 0; i < ATT_NI; ++i) {
+            const int j = base + (i * 4 + wave) * 8 + g;
+            if (j < nkeys) {
+                const float pj = expf(sc[j] - m) / sum;
+                if (j == slot) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += pj * vn[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[2 * e] += pj * __uint_as_float(vv[i][e] << 16);
+                        acc[2 * e + 1] += pj * __uint_as_float(vv[i][e] & 0xffff0000u);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        acc[e] += __shfl_xor(acc[e], 8, 64);
+        acc[e] += __shfl_xor(acc[e], 16, 64);
+        acc[e] += __shfl_xor(acc[e], 32, 64);
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[wave][d8 * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64)
+        out[(size_t)s * D + hd * 64 + threadIdx.x] =
+            (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
 // image key/value (uk/uv outputs) -> cache slot 0 of every layer
-__global__ __launch_bounds__(256) void kv_slot0_kernel(const float* __restrict__ ukv, int ld, float* __restrict__ kv_all,
+template <typename KV>  // float, or u16 (bf16 cache)
+__global__ __launch_bounds__(256) void kv_slot0_kernel(const float* __restrict__ ukv, int ld, KV* __restrict__ kv_all,
                                                        size_t layer_stride, size_t kv_stride, int S, int H, int T,
                                                        int L, int row_mul) {
     const int D = H * 64;
@@ -583,8 +723,10 @@ __global__ __launch_bounds__(256) void kv_slot0_kernel(const float* __restrict__
         r /= S;
         const int kv = (int)(r & 1), l = (int)(r >> 1);
         const int hd = d >> 6, e = d & 63;
-        kv_all[(size_t)l * layer_stride + (size_t)kv * kv_stride + (((size_t)s * row_mul * H + hd) * T) * 64 + e] =
-            ukv[(size_t)s * ld + ((size_t)l * 2 + kv) * D + d];
+        const float val = ukv[(size_t)s * ld + ((size_t)l * 2 + kv) * D + d];
+        const size_t o = (size_t)l * layer_stride + (size_t)kv * kv_stride + (((size_t)s * row_mul * H + hd) * T) * 64 + e;
+        if constexpr (sizeof(KV) == 2) kv_all[o] = (KV)bf16_rne_bits(val);
+        else kv_all[o] = val;
     }
 }
 
@@ -929,6 +1071,10 @@ static int init_skinny_attrs() {
     return skinny_attr<16, 8>();
 }
 
+// bf16 K/V cache: with the bf16 GEMMs, i.e. on the many-sequence path of the opt-in bf16 mode.  `rows` is the
+// number of token rows of the decode steps (sequences x beams), the same for every launch of one generate call.
+static bool kv_is_bf16(const rgrg_decoder* d, int rows) { return d->bf16_gemms && rows > skinny_max_rows(); }
+
 // Y[:M] = act(X W^T + b + R).  <= 32 rows: weight-streaming skinny GEMM; when the layer
 // splits K over workgroups (KS > 1) and `defer` is set, only the partial sums are produced
 // (d->part) and the caller's next kernel (resid_ln_kernel) combines them with bias and
@@ -976,7 +1122,11 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
         const float* ng = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_g : d->lnf_g;
         const float* nb = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_b : d->lnf_b;
         if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, count))) return rc;
-        if (S * d->H <= 4096)
+        if (kv_is_bf16(d, S)) {
+            u16* kc16 = reinterpret_cast<u16*>(d->kv) + (size_t)l * d->kv_layer_stride;
+            hipLaunchKernelGGL((attn_decode_kv16_kernel<5>), dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc16,
+                               kc16 + d->kv_kv_stride, d->step, d->att, S, d->H, d->T, src);
+        } else if (S * d->H <= 4096)
             hipLaunchKernelGGL((attn_decode_kernel<true, 9>), dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc, vc, d->step,
                                d->att, S, d->H, d->T, src);
         else
@@ -1020,8 +1170,13 @@ static int enqueue_prefill(rgrg_decoder* d, const float* feats, int S, int row_m
     if ((rc = linear(d, d->fst2, d->h1, nullptr, d->img, S, D, RGRG_ACT_NONE, false))) return rc;
     // uk / uv of all layers in one GEMM, then scatter to cache slot 0
     if ((rc = linear(d, d->ukv, d->img, nullptr, d->ukv_out, S, d->ld_ukv, RGRG_ACT_NONE, false))) return rc;
-    hipLaunchKernelGGL(kv_slot0_kernel, dim3(1024), dim3(256), 0, st, d->ukv_out, d->ld_ukv, d->kv, d->kv_layer_stride,
-                       d->kv_kv_stride, S, d->H, d->T, d->n_layer, row_mul);
+    // the bf16 cache lives in the same allocation with the same ELEMENT strides (half the bytes used)
+    if (kv_is_bf16(d, S * row_mul))
+        hipLaunchKernelGGL(kv_slot0_kernel<u16>, dim3(1024), dim3(256), 0, st, d->ukv_out, d->ld_ukv,
+                           reinterpret_cast<u16*>(d->kv), d->kv_layer_stride, d->kv_kv_stride, S, d->H, d->T, d->n_layer, row_mul);
+    else
+        hipLaunchKernelGGL(kv_slot0_kernel<float>, dim3(1024), dim3(256), 0, st, d->ukv_out, d->ld_ukv, d->kv,
+                           d->kv_layer_stride, d->kv_kv_stride, S, d->H, d->T, d->n_layer, row_mul);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }

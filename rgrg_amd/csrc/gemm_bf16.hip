@@ -5,7 +5,7 @@
 //   Y[m,n] = act( sum_k bf16(A[m,k]) * Wb[n,k] + shift[n] + R[m,n] )        (fp32 in, fp32 out)
 //
 // A stays fp32 in HBM (LayerNorm / residual stream are fp32) and is rounded to bf16 (RNE) while it is
-// staged to LDS; Wb is the bf16 copy of the [N,K] weight made once at load time.  Both LDS tiles are
+// staged from registers to LDS; Wb is the bf16 copy of the [N,K] weight made once at load time.  Both LDS tiles are
 // [rows][64 bf16] with rows padded to 144 B, so the ds_read_b128 of an MFMA fragment (lane = row, 8
 // consecutive k) is conflict free.  A and B fragments use the same (lane half, element) -> k mapping, so
 // the K order inside a tile is irrelevant.  Not bit-exact with the fp32 reference by construction: this
@@ -35,57 +35,73 @@ __device__ __forceinline__ u16 f32_to_bf16_rne(float f) {
     return (u16)(u >> 16);
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_bf16w_kernel(const GemmBf16Params p) {
-    constexpr int MI = BM / 64, NI = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
-    constexpr int AL = BM / 32, BL = BN / 32;  // 8-element chunks per thread per tile
+// Workgroup = BM x BN output tile, THREADS/64 waves in a 2 x (WAVES/2) grid, each wave a (BM/2) x (BN/(WAVES/2))
+// sub-tile of 32x32 MFMA blocks.  M ~ 1000 rows gives only ~1 workgroup per CU, so memory latency cannot be
+// hidden by occupancy: every thread keeps NS K-tiles of global loads in flight in registers (the loads of
+// tile kt+NS are issued before tile kt is computed) and the LDS tiles are double buffered, one barrier per
+// K tile.  Workgroup ids are remapped so that the 1/8 of the grid an XCD receives (ids i mod 8) covers a
+// compact band of column tiles: its L2 then holds that band of W plus A.
+template <int BM, int BN, int THREADS>
+__global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Params p, const int mtiles, const int ntiles) {
+    constexpr int WAVES = THREADS / 64, WN = WAVES / 2;
+    constexpr int TM = BM / 2, TN = BN / WN;    // wave sub-tile
+    constexpr int MI = TM / 32, NI = TN / 32;   // 32x32 MFMA blocks per wave
+    constexpr int AL = BM * 8 / THREADS, BL = BN * 8 / THREADS;  // 8-element chunks per thread per K tile
+    constexpr int RSTEP = THREADS / 8;          // rows covered by one pass of the workgroup
+    constexpr int NS = 4;                       // K tiles in flight per thread
     extern __shared__ __attribute__((aligned(16))) u16 smem16[];
     u16* As = smem16;                  // [2][BM][LDB]
     u16* Bs = smem16 + 2 * BM * LDB;   // [2][BN][LDB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kchunk = tid & 7, lrow = tid >> 3;  // 8 chunks of 8 k per row, 32 rows per pass
+    const int wm = wave / WN, wn = wave % WN;
+    const int total = mtiles * ntiles;
+    int t = blockIdx.x;
+    if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);
+    const int tn = t / mtiles, tm = t - tn * mtiles;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kchunk = tid & 7, lrow = tid >> 3;
     const int nk = p.K / BK16;
 
-    f32x4 ra[AL][2];
-    bf16x8 rb[BL];
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK16 + kchunk * 8;
+    const float* aptr[AL];
+    const u16* bptr[BL];
 #pragma unroll
-        for (int i = 0; i < AL; ++i) {
-            const int m = m0 + lrow + 32 * i;
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            ra[i][0] = z; ra[i][1] = z;
-            if (m < p.M) {
-                const float* src = p.A + (size_t)m * p.K + k0;
-                ra[i][0] = *reinterpret_cast<const f32x4*>(src);
-                ra[i][1] = *reinterpret_cast<const f32x4*>(src + 4);
-            }
-        }
+    for (int i = 0; i < AL; ++i) {
+        // rows/columns past the edge read the last valid one: their products are never stored, and the loop
+        // stays branch free (the compiler can then count outstanding loads exactly)
+        const int m = min(m0 + lrow + RSTEP * i, p.M - 1);
+        aptr[i] = p.A + (size_t)m * p.K + kchunk * 8;
+    }
 #pragma unroll
-        for (int i = 0; i < BL; ++i) {
-            const int n = n0 + lrow + 32 * i;
-            bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            rb[i] = z;
-            if (n < p.N) rb[i] = *reinterpret_cast<const bf16x8*>(p.Wb + (size_t)n * p.K + k0);
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AL; ++i) {
-            bf16x8 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = (short)f32_to_bf16_rne(ra[i][0][e]);
-                v[4 + e] = (short)f32_to_bf16_rne(ra[i][1][e]);
-            }
-            *reinterpret_cast<bf16x8*>(&As[(buf * BM + lrow + 32 * i) * LDB + kchunk * 8]) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < BL; ++i)
-            *reinterpret_cast<bf16x8*>(&Bs[(buf * BN + lrow + 32 * i) * LDB + kchunk * 8]) = rb[i];
-    };
+    for (int i = 0; i < BL; ++i) {
+        const int n = min(n0 + lrow + RSTEP * i, p.N - 1);
+        bptr[i] = p.Wb + (size_t)n * p.K + kchunk * 8;
+    }
+
+    f32x4 ra[NS][AL][2];
+    bf16x8 rb[NS][BL];
+#define RGRG_LOAD_TILE(S, KT)                                                                    \
+    {                                                                                            \
+        const int koff = (KT) * BK16;                                                            \
+        _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                         \
+            ra[S][i][0] = *reinterpret_cast<const f32x4*>(aptr[i] + koff);                       \
+            ra[S][i][1] = *reinterpret_cast<const f32x4*>(aptr[i] + koff + 4);                   \
+        }                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < BL; ++i)                                           \
+            rb[S][i] = *reinterpret_cast<const bf16x8*>(bptr[i] + koff);                         \
+    }
+#define RGRG_STORE_TILE(S, BUF)                                                                  \
+    {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                         \
+            bf16x8 v;                                                                            \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                      \
+                v[e] = (short)f32_to_bf16_rne(ra[S][i][0][e]);                                   \
+                v[4 + e] = (short)f32_to_bf16_rne(ra[S][i][1][e]);                               \
+            }                                                                                    \
+            *reinterpret_cast<bf16x8*>(&As[((BUF) * BM + lrow + RSTEP * i) * LDB + kchunk * 8]) = v; \
+        }                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < BL; ++i)                                           \
+            *reinterpret_cast<bf16x8*>(&Bs[((BUF) * BN + lrow + RSTEP * i) * LDB + kchunk * 8]) = rb[S][i]; \
+    }
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -95,47 +111,76 @@ __global__ __launch_bounds__(256) void gemm_bf16w_kernel(const GemmBf16Params p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
+    // prologue: tiles 0..NS-1 in flight, tile 0 staged
+#pragma unroll
+    for (int s = 0; s < NS; ++s) RGRG_LOAD_TILE(s, s)  // nk is a multiple of NS (checked by the launcher)
+    __builtin_amdgcn_sched_barrier(0);
+    RGRG_STORE_TILE(0, 0)
     __syncthreads();
+
     const int frow = lane & 31, fk = (lane >> 5) * 8;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const u16* Ab = &As[(buf * BM + wm * (BM / 2) + frow) * LDB + fk];
-        const u16* Bb = &Bs[(buf * BN + wn * (BN / 2) + frow) * LDB + fk];
+    for (int kt0 = 0; kt0 < nk; kt0 += NS) {
 #pragma unroll
-        for (int ks = 0; ks < BK16 / 16; ++ks) {
-            bf16x8 a[MI], b[NI];
+        for (int s = 0; s < NS; ++s) {
+            const int kt = kt0 + s;
+            {
+                const int buf = kt & 1;
+                // registers of stage s were staged to LDS one iteration ago: refill them with tile kt+NS (past
+                // the end: the last tile again, never consumed)
+                RGRG_LOAD_TILE(s, min(kt + NS, nk - 1))
+                __builtin_amdgcn_sched_barrier(0);
+                const u16* Ab = &As[(buf * BM + wm * TM + frow) * LDB + fk];
+                const u16* Bb = &Bs[(buf * BN + wn * TN + frow) * LDB + fk];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * LDB + ks * 16);
+                for (int ks = 0; ks < BK16 / 16; ++ks) {
+                    bf16x8 a[MI], b[NI];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * LDB + ks * 16);
+                    for (int mi = 0; mi < MI; ++mi)
+                        a[mi] = *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * LDB + ks * 16);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+                    for (int ni = 0; ni < NI; ++ni)
+                        b[ni] = *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * LDB + ks * 16);
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                }
+                // stage tile kt+1 (the oldest loads in flight) into the other LDS buffer; its last readers
+                // passed the barrier that ended iteration kt-1
+                RGRG_STORE_TILE((s + 1) % NS, buf ^ 1)
+                __syncthreads();
+            }
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
     }
-    // epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+#undef RGRG_LOAD_TILE
+#undef RGRG_STORE_TILE
+    // epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  Residual
+    // reads use clamped addresses and are issued together; only the stores are predicated.
     const int ccol = lane & 31, crow4 = 4 * (lane >> 5);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const int col = n0 + wn * (BN / 2) + ni * 32 + ccol;
-            if (col >= p.N) continue;
-            const float sh = p.shift ? p.shift[col] : 0.f;
+            const int col = n0 + wn * TN + ni * 32 + ccol;
+            const int colc = min(col, p.N - 1);
+            const int rbase = m0 + wm * TM + mi * 32 + crow4;
+            const float sh = p.shift ? p.shift[colc] : 0.f;
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            if (p.R) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+                    rv[r] = p.R[(size_t)row * p.ldy + colc];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + crow4;
-                if (row >= p.M) continue;
-                float v = acc[mi][ni][r] + sh;
-                if (p.R) v += p.R[(size_t)row * p.ldy + col];
-                p.Y[(size_t)row * p.ldy + col] = apply_act(v, p.act);
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                const float v = apply_act(acc[mi][ni][r] + sh + rv[r], p.act);
+                if (row < p.M && col < p.N) p.Y[(size_t)row * p.ldy + col] = v;
             }
         }
 }
@@ -145,30 +190,30 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
         dst[i] = f32_to_bf16_rne(src[i]);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int THREADS>
 static int launch_bf16_cfg(const GemmBf16Params& p, hipStream_t st) {
     constexpr size_t lds = (size_t)(2 * BM + 2 * BN) * LDB * sizeof(u16);
-    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm_bf16w_kernel<BM, BN>), grid, dim3(256), lds, st, p);
+    const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_bf16w_kernel<BM, BN, THREADS>), dim3(mtiles * ntiles), dim3(THREADS), lds, st, p, mtiles, ntiles);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
 
 int init_gemm_bf16_attrs() {
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<128, 128>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)512 * LDB * sizeof(u16))));
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<64, 64>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<128, 128, 512>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<64, 64, 256>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
     return RGRG_OK;
 }
 
 int launch_gemm_bf16w(const float* A, const void* Wb, const float* shift, const float* R, float* Y, int M, int N, int K,
                       int ldy, int act, hipStream_t st) {
-    RGRG_CHECK_ARG(A && Wb && Y && M > 0 && N > 0 && K > 0 && K % BK16 == 0 && ldy >= N);
+    RGRG_CHECK_ARG(A && Wb && Y && M > 0 && N > 0 && K > 0 && K % (4 * BK16) == 0 && ldy >= N);  // 4 = pipeline depth NS
     GemmBf16Params p{A, reinterpret_cast<const u16*>(Wb), shift, R, Y, M, N, K, ldy, act};
     const long tiles_big = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (tiles_big >= 192) return launch_bf16_cfg<128, 128>(p, st);
-    return launch_bf16_cfg<64, 64>(p, st);
+    if (tiles_big >= 192) return launch_bf16_cfg<128, 128, 512>(p, st);
+    return launch_bf16_cfg<64, 64, 256>(p, st);
 }
 
 int convert_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st) {
