@@ -4,8 +4,8 @@
 //
 //   Y[m,n] = act( sum_k bf16(A[m,k]) * Wb[n,k] + shift[n] + R[m,n] )        (fp32 in, fp32 out)
 //
-// A stays fp32 in HBM (LayerNorm / residual stream are fp32) and is rounded to bf16 (RNE) while it is
-// staged from registers to LDS; Wb is the bf16 copy of the [N,K] weight made once at load time.  Both LDS tiles are
+// A stays fp32 in HBM (LayerNorm / residual stream are fp32; adjacent lanes read adjacent 16-byte pieces, so a
+// wave's load touches whole cache lines) and is rounded to bf16 (RNE) while it is staged from registers to LDS; Wb is the bf16 copy of the [N,K] weight made once at load time.  Both LDS tiles are
 // [rows][64 bf16] with rows padded to 144 B, so the ds_read_b128 of an MFMA fragment (lane = row, 8
 // consecutive k) is conflict free.  A and B fragments use the same (lane half, element) -> k mapping, so
 // the K order inside a tile is irrelevant.  Not bit-exact with the fp32 reference by construction: this
@@ -15,6 +15,7 @@
 namespace rgrg {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
 struct GemmBf16Params {
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Param
         // rows/columns past the edge read the last valid one: their products are never stored, and the loop
         // stays branch free (the compiler can then count outstanding loads exactly)
         const int m = min(m0 + lrow + RSTEP * i, p.M - 1);
-        aptr[i] = p.A + (size_t)m * p.K + kchunk * 8;
+        aptr[i] = p.A + (size_t)m * p.K + kchunk * 4;  // this lane: k = 4c..4c+3 and 32+4c..32+4c+3 of each K tile
     }
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
@@ -84,24 +85,33 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Param
         const int koff = (KT) * BK16;                                                            \
         _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                         \
             ra[S][i][0] = *reinterpret_cast<const f32x4*>(aptr[i] + koff);                       \
-            ra[S][i][1] = *reinterpret_cast<const f32x4*>(aptr[i] + koff + 4);                   \
+            ra[S][i][1] = *reinterpret_cast<const f32x4*>(aptr[i] + koff + 32);                  \
         }                                                                                        \
         _Pragma("unroll") for (int i = 0; i < BL; ++i)                                           \
             rb[S][i] = *reinterpret_cast<const bf16x8*>(bptr[i] + koff);                         \
     }
-#define RGRG_STORE_TILE(S, BUF)                                                                  \
+    // staging item I of register stage S -> LDS buffer BUF: items 0..AL-1 are A chunks (fp32 -> bf16, RNE),
+    // items AL..AL+BL-1 are W chunks
+#define RGRG_STORE_ITEM(S, BUF, I)                                                               \
     {                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                         \
-            bf16x8 v;                                                                            \
+        if ((I) < AL) {                                                                          \
+            constexpr int i = (I) < AL ? (I) : 0;                                                \
+            bf16x4 lo, hi;                                                                       \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                      \
-                v[e] = (short)f32_to_bf16_rne(ra[S][i][0][e]);                                   \
-                v[4 + e] = (short)f32_to_bf16_rne(ra[S][i][1][e]);                               \
+                lo[e] = (short)f32_to_bf16_rne(ra[S][i][0][e]);                                  \
+                hi[e] = (short)f32_to_bf16_rne(ra[S][i][1][e]);                                  \
             }                                                                                    \
-            *reinterpret_cast<bf16x8*>(&As[((BUF) * BM + lrow + RSTEP * i) * LDB + kchunk * 8]) = v; \
-        }                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < BL; ++i)                                           \
+            u16* dst = &As[((BUF) * BM + lrow + RSTEP * i) * LDB + kchunk * 4];                  \
+            *reinterpret_cast<bf16x4*>(dst) = lo;                                                \
+            *reinterpret_cast<bf16x4*>(dst + 32) = hi;                                           \
+        } else {                                                                                 \
+            constexpr int i = (I) >= AL ? (I) - AL : 0;                                          \
             *reinterpret_cast<bf16x8*>(&Bs[((BUF) * BN + lrow + RSTEP * i) * LDB + kchunk * 8]) = rb[S][i]; \
+        }                                                                                        \
     }
+#define RGRG_STORE_TILE(S, BUF) \
+    { RGRG_STORE_ITEM(S, BUF, 0) RGRG_STORE_ITEM(S, BUF, 1) RGRG_STORE_ITEM(S, BUF, 2) RGRG_STORE_ITEM(S, BUF, 3) }
+    static_assert(AL + BL == BK16 / 16, "one staging item per 16-wide K step");
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -131,30 +141,35 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Param
                 __builtin_amdgcn_sched_barrier(0);
                 const u16* Ab = &As[(buf * BM + wm * TM + frow) * LDB + fk];
                 const u16* Bb = &Bs[(buf * BN + wn * TN + frow) * LDB + fk];
+                // the 4 K steps of the tile; the fragments of step ks+1 are read before the MFMAs of step ks, and
+                // one quarter of tile kt+1 (the oldest loads in flight) is converted and written to the other LDS
+                // buffer in the shadow of each step's MFMAs (its last readers passed the barrier of iteration kt-1)
+                bf16x8 a[2][MI], b[2][NI];
 #pragma unroll
-                for (int ks = 0; ks < BK16 / 16; ++ks) {
-                    bf16x8 a[MI], b[NI];
+                for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * LDB);
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-                        a[mi] = *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * LDB + ks * 16);
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        b[ni] = *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * LDB + ks * 16);
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-                }
-                // stage tile kt+1 (the oldest loads in flight) into the other LDS buffer; its last readers
-                // passed the barrier that ended iteration kt-1
-                RGRG_STORE_TILE((s + 1) % NS, buf ^ 1)
+                for (int ni = 0; ni < NI; ++ni) b[0][ni] = *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * LDB);
+#define RGRG_KSTEP(KS)                                                                                       \
+    {                                                                                                        \
+        if ((KS) + 1 < BK16 / 16) {                                                                          \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) a[((KS) + 1) & 1][mi] =                        \
+                *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * LDB + ((KS) + 1) * 16);                      \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) b[((KS) + 1) & 1][ni] =                        \
+                *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * LDB + ((KS) + 1) * 16);                      \
+        }                                                                                                    \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)  \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(KS) & 1][mi], b[(KS) & 1][ni], acc[mi][ni], 0, 0, 0); \
+        RGRG_STORE_ITEM((s + 1) % NS, buf ^ 1, KS)                                                           \
+    }
+                RGRG_KSTEP(0) RGRG_KSTEP(1) RGRG_KSTEP(2) RGRG_KSTEP(3)
+#undef RGRG_KSTEP
                 __syncthreads();
             }
         }
     }
 #undef RGRG_LOAD_TILE
 #undef RGRG_STORE_TILE
+#undef RGRG_STORE_ITEM
     // epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  Residual
     // reads use clamped addresses and are issued together; only the stores are predicated.
     const int ccol = lane & 31, crow4 = 4 * (lane >> 5);
@@ -199,21 +214,41 @@ static int launch_bf16_cfg(const GemmBf16Params& p, hipStream_t st) {
     return RGRG_OK;
 }
 
-int init_gemm_bf16_attrs() {
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<128, 128, 512>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<64, 64, 256>),
+template <int BM, int BN, int THREADS>
+static int bf16_attr() {
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<BM, BN, THREADS>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
     return RGRG_OK;
+}
+
+int init_gemm_bf16_attrs() {
+    int rc;
+    if ((rc = bf16_attr<128, 128, 512>())) return rc;
+    return bf16_attr<64, 64, 256>();
+}
+
+// RGRG_BF16_TILE=1 (128x128, 8 waves) / 5 (64x64, 4 waves) forces one tile configuration (tools/gemm_bf16_bench.py); unset/0 = the heuristic
+static int forced_bf16_cfg() {
+    static const int v = [] {
+        const char* e = getenv("RGRG_BF16_TILE");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
 }
 
 int launch_gemm_bf16w(const float* A, const void* Wb, const float* shift, const float* R, float* Y, int M, int N, int K,
                       int ldy, int act, hipStream_t st) {
     RGRG_CHECK_ARG(A && Wb && Y && M > 0 && N > 0 && K > 0 && K % (4 * BK16) == 0 && ldy >= N);  // 4 = pipeline depth NS
     GemmBf16Params p{A, reinterpret_cast<const u16*>(Wb), shift, R, Y, M, N, K, ldy, act};
-    const long tiles_big = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (tiles_big >= 192) return launch_bf16_cfg<128, 128, 512>(p, st);
-    return launch_bf16_cfg<64, 64, 256>(p, st);
+    int cfg = forced_bf16_cfg();
+    if (cfg == 0) {
+        const long tiles_big = (long)((M + 127) / 128) * ((N + 127) / 128);
+        cfg = tiles_big >= 192 ? 1 : 5;
+    }
+    switch (cfg) {
+        case 1: return launch_bf16_cfg<128, 128, 512>(p, st);
+        default: return launch_bf16_cfg<64, 64, 256>(p, st);
+    }
 }
 
 int convert_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st) {
