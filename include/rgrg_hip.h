@@ -103,6 +103,12 @@ int rgrg_top1_per_class_f32(const float* pred, int ldp, const float* proposals, 
                             const float* pooled, uint8_t* class_detected, float* top_scores, float* top_boxes,
                             float* top_feats, int B, int C, int max_props, float img_w, float img_h, void* stream);
 
+/* Replaces nn.BCEWithLogitsLoss(pos_weight) on `logits[class_detected]` of the two region classifiers in
+ * forward() (src/binary_classifier/binary_classifier_region_selection.py:22,40-44 with pos_weight 2.2;
+ * binary_classifier_region_abnormal.py:29,43-47 with 6.0): mean over the rows with mask != 0 of
+ * (1-y) x - (1 + (w-1) y) log_sigmoid(x).  logits f32 [n], mask/target u8 [n], loss: one f32 (nan when no row). */
+int rgrg_bce_with_logits_masked_f32(const float* logits, const uint8_t* mask, const uint8_t* target, float pos_weight,
+                                    int n, float* loss, void* stream);
 /* BinaryClassifierRegionSelection threshold + mask + row-major compaction
  * (binary_classifier_region_selection.py:53-61): selected = (logit > thr) & detected;
  * sel_rows int32 [n] lists the selected flat (image*29+region) indices in order,
@@ -161,10 +167,25 @@ int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int S, int num
                              int early_stopping, float length_penalty, int64_t* out_ids, int out_ld, int* out_len,
                              void* stream);
 /* Opt-in reduced precision for MANY sequences (BASELINE configs[2], batch 32): bf16_gemms = 1 makes the
- * decode projections of the > 128-sequence path run on the bf16 MFMA (bf16 weights, activations rounded to
- * bf16 in LDS, fp32 accumulate / LayerNorm / attention / residual).  NOT bit-exact with the fp32 reference;
- * the <= 128-sequence path (launch-latency bound) always stays fp32.  May allocate and synchronise. */
+ * > 128-row paths run their projections on the bf16 MFMA (bf16 weights, activations rounded to bf16 in LDS,
+ * fp32 accumulate / LayerNorm / softmax / residual) and keep the decode K/V cache in bf16 (what the reference's
+ * torch.autocast does to `present`).  NOT bit-exact with the fp32 reference; the <= 128-sequence decode path
+ * (launch-latency bound) always stays fp32.  May allocate and synchronise. */
 int rgrg_decoder_set_precision(rgrg_decoder* d, int bf16_gemms);
+/* Replaces LanguageModel.forward(input_ids, attention_mask, image_hidden_states, return_loss, use_cache=False)
+ * in eval mode (src/language_model/language_model.py:258-399): one teacher-forced pass over
+ * T tokens per sequence - feature_space_transformation_nn, wte[ids] + wte[arange(T)] (:298-307), 24 blocks of
+ * pseudo self-attention without cache (image key/value first, future columns -1e4, additive padding mask
+ * (1 - [1|attention_mask]) * -10000, :84-160,:325-334), final LayerNorm, lm_head.
+ *   feats [S,1024] f32, input_ids [S,T] int64 (every id in [0, vocab)), attention_mask [S,T] f32 or NULL (= ones),
+ *   S <= max_seqs of the decoder, T <= 255.
+ *   logits_out: NULL or f32 [S,T,vocab] (return_loss=False);
+ *   loss_out:   NULL or one f32 = CrossEntropyLoss(ignore_index=-100) of logits[:, :-1] against input_ids[:, 1:]
+ *               with the labels of attention_mask == 0 positions ignored (:368-396); nan when no label is scored.
+ * Runs on the decoder's stream between two event edges with `stream`; does not synchronise the host.  Work space
+ * for S*T token rows is grown on demand (first call of a larger size allocates). */
+int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, const int64_t* input_ids, const float* attention_mask,
+                            int S, int T, float* logits_out, float* loss_out, void* stream);
 /* fp32 -> bf16 (round to nearest even), and Y = act(bf16(A) Wb^T + shift + R) on v_mfma_f32_32x32x16_bf16
  * (A fp32 [M,K], Wb bf16 [N,K], K % 64 == 0). */
 int rgrg_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);

@@ -1,8 +1,9 @@
 """CPU restatement of ``ReportGenerationModel.generate`` and the region
 selection head.  TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
 
-Follows ``src/full_model/report_generation_model.py:212-276`` and
-``src/binary_classifier/binary_classifier_region_selection.py:24-68``.
+Follows ``src/full_model/report_generation_model.py:212-276`` (generate) and ``:35-168`` (forward, eval
+branch), ``src/binary_classifier/binary_classifier_region_selection.py:24-68`` and
+``src/binary_classifier/binary_classifier_region_abnormal.py:32-60``.
 """
 from __future__ import annotations
 
@@ -30,6 +31,36 @@ def region_selection(sd: SD, top_region_features: Tensor, class_detected: Tensor
     selected = logits > -1
     selected = selected & class_detected
     return selected, top_region_features[selected], logits
+
+
+def _classifier_logits(sd: SD, c: str, x: Tensor) -> Tensor:
+    h = F.relu(F.linear(x, sd[c + "0.weight"], sd[c + "0.bias"]))
+    h = F.relu(F.linear(h, sd[c + "2.weight"], sd[c + "2.bias"]))
+    return F.linear(h, sd[c + "4.weight"], sd[c + "4.bias"]).squeeze(-1)
+
+
+@torch.no_grad()
+def forward_eval(sd: SD, images: Tensor, input_ids: Tensor, attention_mask: Tensor, region_has_sentence: Tensor,
+                 region_is_abnormal: Tensor):
+    """ReportGenerationModel.forward in eval mode with ``image_targets=None`` (report_generation_model.py:87-168):
+    detector (losses {}), selection classifier loss (BCEWithLogits pos_weight 2.2 on detected regions) and
+    ``selected_regions``, abnormal classifier loss (pos_weight 6.0) and ``logits > -1`` predictions, decoder inputs of
+    the selected regions (:196-210), teacher-forced LM loss.  Returns the reference's 8-tuple, or -1 (:136)."""
+    from .language_model import lm_teacher_forced
+    _, detections, top_region_features, class_detected = object_detector_forward(sd, images)
+    selected_regions, selected_feats, sel_logits = region_selection(sd, top_region_features, class_detected)
+    loss_sel = F.binary_cross_entropy_with_logits(sel_logits[class_detected], region_has_sentence[class_detected].float(),
+                                                  pos_weight=torch.tensor([2.2]))
+    abn_logits = _classifier_logits(sd, "binary_classifier_region_abnormal.classifier.", top_region_features)
+    loss_abn = F.binary_cross_entropy_with_logits(abn_logits[class_detected], region_is_abnormal[class_detected].float(),
+                                                  pos_weight=torch.tensor([6.0]))
+    predicted_abnormal = abn_logits > -1
+    flat = selected_regions.reshape(-1)
+    ids, mask = input_ids[flat], attention_mask[flat]
+    if ids.shape[0] == 0:
+        return -1
+    lm_loss = lm_teacher_forced(sd, ids, mask, selected_feats, return_loss=True)
+    return {}, loss_sel, loss_abn, lm_loss, detections, class_detected, selected_regions, predicted_abnormal
 
 
 @torch.no_grad()

@@ -91,6 +91,24 @@ def lm_forward(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_s
 
 
 @torch.no_grad()
+def lm_teacher_forced(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_states: Tensor,
+                      return_loss: bool = True, p: str = "language_model."):
+    """LanguageModel.forward(..., past_key_values=None, position_ids=None, use_cache=False) in eval mode
+    (:258-399): positions default to arange(T) (:298-300); with ``return_loss`` the labels are ``input_ids``
+    with attention_mask == 0 positions set to -100, shifted one to the left, CrossEntropyLoss(ignore_index=-100)
+    (:368-396).  Returns the scalar loss, or the logits [S,T,50257]."""
+    S, T = input_ids.shape
+    pos = torch.arange(T, dtype=torch.long)[None, :]
+    logits, _ = lm_forward(sd, input_ids, attention_mask.to(torch.int64) if attention_mask.dtype == torch.bool else attention_mask,
+                           image_hidden_states, None, pos, p)
+    if not return_loss:
+        return logits
+    labels = input_ids.clone()
+    labels[~attention_mask.to(torch.bool)] = -100
+    return F.cross_entropy(logits[:, :-1, :].reshape(-1, VOCAB), labels[:, 1:].reshape(-1), ignore_index=-100)
+
+
+@torch.no_grad()
 def greedy_generate(sd: SD, image_hidden_states: Tensor, max_length: Optional[int], p: str = "language_model.",
                     return_logits: bool = False):
     """LanguageModel.generate(num_beams=1) -> greedy_search (:401-447, :609-652).

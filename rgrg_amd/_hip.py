@@ -46,12 +46,14 @@ SIGNATURES = {
     "rgrg_roi_align_avgpool_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "rgrg_top1_per_class_f32": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p]),
     "rgrg_select_regions_f32": (_i, [_p, _p, _f, _p, _p, _p, _i, _p]),
+    "rgrg_bce_with_logits_masked_f32": (_i, [_p, _p, _p, C.c_float, _i, _p, _p]),
     "rgrg_gather_rows_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "rgrg_decoder_create": (_i, [C.POINTER(DecoderWeights), _i, _i, C.POINTER(_p)]),
     "rgrg_decoder_destroy": (None, [_p]),
     "rgrg_decoder_generate": (_i, [_p, _p, _i, _i, _p, _i, C.POINTER(_i), _i, _p]),
     "rgrg_decoder_beam_search": (_i, [_p, _p, _i, _i, _i, _i, _f, _p, _i, C.POINTER(_i), _p]),
     "rgrg_decoder_set_precision": (_i, [_p, _i]),
+    "rgrg_decoder_lm_forward": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "rgrg_f32_to_bf16": (_i, [_p, _p, C.c_int64, _p]),
     "rgrg_linear_bf16w_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rgrg_decoder_copy_last_logits": (_i, [_p, _p, _i, _p]),

@@ -942,6 +942,145 @@ __global__ __launch_bounds__(256) void beam_init_kernel(int* __restrict__ src, i
     if (r == 0) *step = 0;
 }
 
+// ------------------------------------------------------------------ teacher-forced pass (LanguageModel.forward, no cache)
+// x[s,t] = wte[ids[s,t]] + wte[t] (position_ids default to arange(T) and are embedded with wte, language_model.py:298-307),
+// xn = ln_1 of layer 0.  One workgroup per token row.
+__global__ __launch_bounds__(256) void embed_seq_ln_kernel(const float* __restrict__ wte, const long long* __restrict__ ids,
+                                                           int T, const float* __restrict__ g, const float* __restrict__ b,
+                                                           float* __restrict__ x, float* __restrict__ xn, int D) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const long long tok = ids[row];
+    const int pos = row % T;
+    const f32x4 v = reinterpret_cast<const f32x4*>(wte + (size_t)tok * D)[tid] + reinterpret_cast<const f32x4*>(wte + (size_t)pos * D)[tid];
+    reinterpret_cast<f32x4*>(x + (size_t)row * D)[tid] = v;
+    reinterpret_cast<f32x4*>(xn + (size_t)row * D)[tid] = ln_row(v, g, b, sh, D);
+}
+
+// GPT2PseudoAttention.forward without layer_past (:124-160) and _attn (:84-122) over T tokens: keys/values are
+// [uk(img) ; k_0..k_{T-1}], scores / 8, future token columns replaced by -1e4 (the image column is never masked),
+// plus the additive padding mask (1 - [1|attention_mask]) * -10000 (:325-334), softmax, . V.
+// One workgroup per (sequence, head): K (rows padded to 65 floats) and V live in LDS; a wave owns query rows
+// wave, wave+4, ...; a lane owns keys lane, lane+64, ... for the scores and one of the 64 dims for P.V.
+constexpr int TF_MAX_T = 255;
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
+                                                           int kcol, const float* __restrict__ am, float* __restrict__ out,
+                                                           int H, int T) {
+    extern __shared__ __attribute__((aligned(16))) float tf_sm[];
+    const int NK = T + 1, D = H * 64;
+    float* Ks = tf_sm;              // [NK][65]
+    float* Vs = Ks + NK * 65;       // [NK][64]
+    float* Qs = Vs + NK * 64;       // [4][64]
+    float* Ps = Qs + 4 * 64;        // [4][NK]
+    float* addm = Ps + 4 * NK;      // [NK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x / H, hd = blockIdx.x - s * H;
+    for (int idx = tid; idx < NK * 64; idx += 256) {
+        const int c = idx >> 6, e = idx & 63;
+        float k, v;
+        if (c == 0) {
+            k = ukv[(size_t)s * ld_ukv + kcol + hd * 64 + e];
+            v = ukv[(size_t)s * ld_ukv + kcol + D + hd * 64 + e];
+        } else {
+            const float* r = qkv + ((size_t)s * T + c - 1) * 3 * D + hd * 64 + e;
+            k = r[D];
+            v = r[2 * D];
+        }
+        Ks[c * 65 + e] = k;
+        Vs[c * 64 + e] = v;
+    }
+    for (int c = tid; c < NK; c += 256) addm[c] = (c == 0 || !am) ? 0.f : (1.0f - am[(size_t)s * T + c - 1]) * -10000.0f;
+    __syncthreads();
+    for (int i = wave; i < T; i += 4) {
+        Qs[wave * 64 + lane] = qkv[((size_t)s * T + i) * 3 * D + hd * 64 + lane];
+        __builtin_amdgcn_wave_barrier();
+        float w[4];
+        float m = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = lane + 64 * u;
+            w[u] = -INFINITY;
+            if (c < NK) {
+                float dot = 0.f;
+#pragma unroll 16
+                for (int e = 0; e < 64; ++e) dot += Qs[wave * 64 + e] * Ks[c * 65 + e];
+                const bool allowed = (c == 0) || (c - 1 <= i);
+                w[u] = (allowed ? dot / 8.0f : -1e4f) + addm[c];
+                m = fmaxf(m, w[u]);
+            }
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = lane + 64 * u;
+            if (c < NK) { w[u] = expf(w[u] - m); sum += w[u]; }
+        }
+        sum = wave_sum(sum);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = lane + 64 * u;
+            if (c < NK) Ps[wave * NK + c] = w[u] / sum;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float acc = 0.f;
+        for (int c = 0; c < NK; ++c) acc += Ps[wave * NK + c] * Vs[c * 64 + lane];
+        out[((size_t)s * T + i) * D + hd * 64 + lane] = acc;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// CrossEntropyLoss(ignore_index=-100) on the shifted logits/labels (:368-396): the row of token (s,t), t < T-1, is
+// scored against ids[s][t+1] unless attention_mask[s][t+1] == 0.  One workgroup per logits row of the chunk.
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, size_t ld, int V, int row0,
+                                                      const long long* __restrict__ ids, const float* __restrict__ am, int T,
+                                                      float* __restrict__ row_loss, int* __restrict__ row_valid) {
+    __shared__ float shv[4];
+    const int r = row0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = r % T;
+    const bool ignore = (t == T - 1) || (am && am[r + 1] == 0.f);
+    if (ignore) {
+        if (tid == 0) { row_loss[r] = 0.f; row_valid[r] = 0; }
+        return;
+    }
+    const float* x = logits + (size_t)blockIdx.x * ld;
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i]);
+    m = wave_max(m);
+    if (lane == 0) shv[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(shv[0], shv[1]), fmaxf(shv[2], shv[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < V; i += 256) sum += expf(x[i] - m);
+    sum = wave_sum(sum);
+    if (lane == 0) shv[wave] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        const float tot = (shv[0] + shv[1]) + (shv[2] + shv[3]);
+        row_loss[r] = (m + logf(tot)) - x[ids[r + 1]];
+        row_valid[r] = 1;
+    }
+}
+
+// mean over the scored rows in a fixed order (double accumulation); no scored row -> nan, like torch
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restrict__ row_loss, const int* __restrict__ row_valid,
+                                                          int n, float* __restrict__ loss) {
+    __shared__ double ssum[256];
+    __shared__ int scnt[256];
+    double a = 0.0;
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += 256) { a += (double)row_loss[i]; c += row_valid[i]; }
+    ssum[threadIdx.x] = a;
+    scnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { ssum[threadIdx.x] += ssum[threadIdx.x + o]; scnt[threadIdx.x] += scnt[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(ssum[0] / (double)scnt[0]);
+}
+
 // ------------------------------------------------------------------ decoder object
 struct Lin {
     const float* w = nullptr;  // [N,K]
@@ -989,6 +1128,11 @@ struct rgrg_decoder {
     std::vector<GraphEntry> graphs;
     std::vector<void*> allocs;
     size_t gemm_bytes_per_step = 0;
+    // teacher-forced pass workspace (grown on demand, rgrg_decoder_lm_forward)
+    float *tf_x = nullptr, *tf_xn = nullptr, *tf_qkv = nullptr, *tf_att = nullptr, *tf_ff = nullptr, *tf_logits = nullptr,
+          *tf_ws = nullptr, *tf_row_loss = nullptr;
+    int* tf_row_valid = nullptr;
+    size_t tf_rows = 0, tf_ws_floats = 0;
     int bf16_gemms = 0;  // 1: bf16-weight MFMA GEMMs on the many-sequence path (not bit-exact; opt-in)
     int gemm_launches_per_step = 0;
 };
@@ -1271,10 +1415,15 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     return RGRG_OK;
 }
 
+namespace rgrg {
+static void tf_free(rgrg_decoder* d);
+}
+
 extern "C" void rgrg_decoder_destroy(rgrg_decoder* d) {
     if (!d) return;
     for (auto& g : d->graphs) (void)hipGraphExecDestroy(g.exec);
     for (void* p : d->allocs) (void)hipFree(p);
+    tf_free(d);
     if (d->h_done) (void)hipHostFree(d->h_done);
     if (d->ev_in) (void)hipEventDestroy(d->ev_in);
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -1492,6 +1641,110 @@ extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int
                               (size_t)L * sizeof(long long), S, hipMemcpyHostToDevice, st));
     RGRG_HIP(hipStreamSynchronize(st));
     *out_len = L;
+    return RGRG_OK;
+}
+
+// ------------------------------------------------------------------ teacher-forced pass (host side)
+namespace rgrg {
+constexpr int TF_LOGIT_ROWS = 2048;  // lm_head + cross entropy run over chunks of this many token rows (412 MB of logits)
+
+static void tf_free(rgrg_decoder* d) {
+    float** fs[] = {&d->tf_x, &d->tf_xn, &d->tf_qkv, &d->tf_att, &d->tf_ff, &d->tf_logits, &d->tf_ws, &d->tf_row_loss};
+    for (float** f : fs) { if (*f) (void)hipFree(*f); *f = nullptr; }
+    if (d->tf_row_valid) (void)hipFree(d->tf_row_valid);
+    d->tf_row_valid = nullptr;
+    d->tf_rows = 0;
+    d->tf_ws_floats = 0;
+}
+
+static int tf_reserve(rgrg_decoder* d, size_t rows) {
+    if (rows <= d->tf_rows) return RGRG_OK;
+    tf_free(d);
+    const size_t D = (size_t)d->D;
+    const size_t chunk = rows < (size_t)TF_LOGIT_ROWS ? rows : (size_t)TF_LOGIT_ROWS;
+    d->tf_ws_floats = 4 * rows * D;  // split-K partials of the narrow (N = 1024) GEMMs when there are few row tiles
+    RGRG_HIP(hipMalloc((void**)&d->tf_x, rows * D * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tf_xn, rows * D * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tf_qkv, rows * 3 * D * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tf_att, rows * D * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tf_ff, rows * 4 * D * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tf_logits, chunk * (size_t)d->V * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tf_ws, d->tf_ws_floats * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tf_row_loss, rows * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tf_row_valid, rows * 4));
+    d->tf_rows = rows;
+    return RGRG_OK;
+}
+
+// tiled GEMM for the M = S*T token rows (never the skinny path: its buffers are sized for decode rows)
+static int tf_linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R, float* Y, int M, int ldy, int act) {
+    if (d->bf16_gemms && l.wb && l.K % 256 == 0 && M > skinny_max_rows())
+        return launch_gemm_bf16w(X, l.wb, l.b, R, Y, M, l.N, l.K, ldy, act, d->stream);
+    return launch_gemm_dense(X, l.w, l.b, R, Y, M, l.N, l.K, ldy, act, d->tf_ws, d->tf_ws_floats, d->stream);
+}
+}  // namespace rgrg
+
+extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, const int64_t* input_ids,
+                                       const float* attention_mask, int S, int T, float* logits_out, float* loss_out,
+                                       void* stream) {
+    RGRG_CHECK_ARG(d && feats && input_ids && S > 0 && S <= d->max_seqs && T >= 1 && T <= TF_MAX_T && (logits_out || loss_out));
+    RGRG_CHECK_ARG(!loss_out || T >= 2);
+    const int D = d->D, M = S * T;
+    int rc = tf_reserve(d, (size_t)M);
+    if (rc) return rc;
+    const size_t lds = ((size_t)(T + 1) * (65 + 64 + 4 + 1) + 4 * 64) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_done = true;
+    }
+    hipStream_t caller = as_stream(stream), st = d->stream;
+    RGRG_HIP(hipEventRecord(d->ev_in, caller));
+    RGRG_HIP(hipStreamWaitEvent(st, d->ev_in, 0));
+    // feature_space_transformation_nn (:284), then uk / uv of every layer in one GEMM (:145-150)
+    RGRG_HIP(hipMemcpyAsync(d->feats, feats, (size_t)S * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if ((rc = linear(d, d->fst0, d->feats, nullptr, d->h1, S, D, RGRG_ACT_RELU, false))) return rc;
+    if ((rc = linear(d, d->fst2, d->h1, nullptr, d->img, S, D, RGRG_ACT_NONE, false))) return rc;
+    if ((rc = linear(d, d->ukv, d->img, nullptr, d->ukv_out, S, d->ld_ukv, RGRG_ACT_NONE, false))) return rc;
+    const long long* ids = reinterpret_cast<const long long*>(input_ids);
+    hipLaunchKernelGGL(embed_seq_ln_kernel, dim3(M), dim3(256), 0, st, d->wte, ids, T, d->layers[0].ln1_g, d->layers[0].ln1_b,
+                       d->tf_x, d->tf_xn, D);
+    RGRG_LAUNCH_CHECK();
+    for (int l = 0; l < d->n_layer; ++l) {
+        const LayerW& w = d->layers[l];
+        const float* ng = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_g : d->lnf_g;
+        const float* nb = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_b : d->lnf_b;
+        if ((rc = tf_linear(d, w.c_attn, d->tf_xn, nullptr, d->tf_qkv, M, 3 * D, RGRG_ACT_NONE))) return rc;
+        hipLaunchKernelGGL(attn_prefill_kernel, dim3(S * d->H), dim3(256), lds, st, d->tf_qkv, d->ukv_out, d->ld_ukv, l * 2 * D,
+                           attention_mask, d->tf_att, d->H, T);
+        RGRG_LAUNCH_CHECK();
+        if ((rc = tf_linear(d, w.attn_proj, d->tf_att, d->tf_x, d->tf_x, M, D, RGRG_ACT_NONE))) return rc;
+        hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, d->tf_x, nullptr, nullptr, 1, 0, w.ln2_g, w.ln2_b, d->tf_xn, D);
+        RGRG_LAUNCH_CHECK();
+        if ((rc = tf_linear(d, w.c_fc, d->tf_xn, nullptr, d->tf_ff, M, 4 * D, RGRG_ACT_GELU_NEW))) return rc;
+        if ((rc = tf_linear(d, w.mlp_proj, d->tf_ff, d->tf_x, d->tf_x, M, D, RGRG_ACT_NONE))) return rc;
+        hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, d->tf_x, nullptr, nullptr, 1, 0, ng, nb, d->tf_xn, D);
+        RGRG_LAUNCH_CHECK();
+    }
+    // lm_head (tied to wte, no bias) and the loss, over chunks of token rows
+    for (int r0 = 0; r0 < M; r0 += TF_LOGIT_ROWS) {
+        const int rows = (M - r0 < TF_LOGIT_ROWS) ? M - r0 : TF_LOGIT_ROWS;
+        float* lg = logits_out ? logits_out + (size_t)r0 * d->V : d->tf_logits;
+        if ((rc = tf_linear(d, d->lm_head, d->tf_xn + (size_t)r0 * D, nullptr, lg, rows, d->V, RGRG_ACT_NONE))) return rc;
+        if (loss_out) {
+            hipLaunchKernelGGL(ce_rows_kernel, dim3(rows), dim3(256), 0, st, lg, (size_t)d->V, d->V, r0, ids, attention_mask, T,
+                               d->tf_row_loss, d->tf_row_valid);
+            RGRG_LAUNCH_CHECK();
+        }
+    }
+    if (loss_out) {
+        hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, d->tf_row_loss, d->tf_row_valid, M, loss_out);
+        RGRG_LAUNCH_CHECK();
+    }
+    // the caller's stream continues after this pass (no host synchronisation)
+    RGRG_HIP(hipEventRecord(d->ev_in, st));
+    RGRG_HIP(hipStreamWaitEvent(caller, d->ev_in, 0));
     return RGRG_OK;
 }
 

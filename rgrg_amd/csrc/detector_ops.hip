@@ -517,6 +517,36 @@ __global__ __launch_bounds__(1024) void select_regions_kernel(const float* __res
     if (tid == 0) *n_selected = base;
 }
 
+// nn.BCEWithLogitsLoss(pos_weight=w) over the rows with mask != 0, mean reduction
+// (binary_classifier_region_selection.py:22,40-44, binary_classifier_region_abnormal.py:29,43-47):
+//   l_i = (1 - y_i) x_i - (1 + (w - 1) y_i) log_sigmoid(x_i),  log_sigmoid(x) = min(x, 0) - log1p(exp(-|x|))
+// One workgroup, fixed summation order (double); no row -> nan, like torch's mean of an empty tensor.
+__global__ __launch_bounds__(256) void bce_logits_masked_kernel(const float* __restrict__ logits,
+                                                                const unsigned char* __restrict__ mask,
+                                                                const unsigned char* __restrict__ target, float pos_weight,
+                                                                int n, float* __restrict__ loss) {
+    __shared__ double ssum[256];
+    __shared__ int scnt[256];
+    double a = 0.0;
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        if (!mask[i]) continue;
+        const float x = logits[i], y = target[i] ? 1.f : 0.f;
+        const float ls = fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+        const float lw = (pos_weight - 1.f) * y + 1.f;
+        a += (double)((1.f - y) * x - lw * ls);
+        ++c;
+    }
+    ssum[threadIdx.x] = a;
+    scnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { ssum[threadIdx.x] += ssum[threadIdx.x + o]; scnt[threadIdx.x] += scnt[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(ssum[0] / (double)scnt[0]);
+}
+
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows,
                                                           float* __restrict__ dst, int D4) {
     const int r = blockIdx.x;
@@ -608,6 +638,14 @@ extern "C" int rgrg_select_regions_f32(const float* logits, const uint8_t* class
     RGRG_CHECK_ARG(logits && class_detected && selected && sel_rows && n_selected && n > 0);
     hipLaunchKernelGGL(select_regions_kernel, dim3(1), dim3(1024), 0, as_stream(stream), logits, class_detected, thr,
                        selected, sel_rows, n_selected, n);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+extern "C" int rgrg_bce_with_logits_masked_f32(const float* logits, const uint8_t* mask, const uint8_t* target,
+                                               float pos_weight, int n, float* loss, void* stream) {
+    RGRG_CHECK_ARG(logits && mask && target && loss && n > 0);
+    hipLaunchKernelGGL(bce_logits_masked_kernel, dim3(1), dim3(256), 0, as_stream(stream), logits, mask, target, pos_weight, n, loss);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }

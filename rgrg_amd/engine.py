@@ -101,8 +101,12 @@ class HipEngine:
         self.has_decoder = "language_model.gpt_with_lm_head.transformer.wte.weight" in sd
         if self.has_detector:
             self._pack_detector(sd)
+        self.sel = self.abn = None
         if self.has_selection:
             self._pack_selection(sd)
+        a = "binary_classifier_region_abnormal.classifier."  # forward() only
+        if a + "0.weight" in sd:
+            self.abn = [(sd[a + f"{i}.weight"].contiguous(), sd[a + f"{i}.bias"].contiguous()) for i in (0, 2, 4)]
         if self.has_decoder:
             self._pack_decoder(sd)
 
@@ -326,12 +330,43 @@ class HipEngine:
         return {"top_region_boxes": boxes, "top_scores": scores}, top, cd
 
     # ------------------------------------------------------------------ selection
+    def classifier_logits(self, mlp, x: Tensor) -> Tensor:
+        """The 1024-512-128-1 ReLU MLP shared by both region classifiers: x [n,1024] -> logits [n]."""
+        h = self.linear(x, *mlp[0], act=_hip.ACT_RELU)
+        h = self.linear(h, *mlp[1], act=_hip.ACT_RELU)
+        return self.linear(h, *mlp[2]).view(-1)
+
+    def bce_masked(self, logits: Tensor, mask: Tensor, target: Tensor, pos_weight: float) -> Tensor:
+        """BCEWithLogitsLoss(pos_weight)(logits[mask], target[mask]) -> float32 scalar tensor."""
+        n = logits.numel()
+        m = mask.reshape(-1).to(torch.uint8).contiguous()
+        t = target.reshape(-1).to(torch.uint8).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        _hip.check(self.lib.rgrg_bce_with_logits_masked_f32(_hip.ptr(logits), _hip.ptr(m), _hip.ptr(t), float(pos_weight), n,
+                                                            _hip.ptr(loss), _stream()), "rgrg_bce_with_logits_masked_f32")
+        return loss
+
+    def abnormal(self, top_region_features: Tensor, class_detected: Tensor, region_is_abnormal: Tensor, pos_weight: float):
+        """BinaryClassifierRegionAbnormal.forward, eval: -> (loss, predicted_abnormal_regions bool [B,29])."""
+        if self.abn is None:
+            raise RuntimeError("the loaded state dict has no binary_classifier_region_abnormal.* weights")
+        B, Rg, D = top_region_features.shape
+        x = top_region_features.reshape(B * Rg, D).contiguous().to(torch.float32)
+        logits = self.classifier_logits(self.abn, x)
+        loss = self.bce_masked(logits, class_detected, region_is_abnormal, pos_weight)
+        n = B * Rg
+        ones = torch.ones((n,), dtype=torch.uint8, device=x.device)
+        pred = torch.empty((n,), dtype=torch.uint8, device=x.device)
+        rows = torch.empty((n,), dtype=torch.int32, device=x.device)
+        cnt = torch.empty((1,), dtype=torch.int32, device=x.device)
+        _hip.check(self.lib.rgrg_select_regions_f32(_hip.ptr(logits), _hip.ptr(ones), SELECTION_LOGIT_THRESHOLD, _hip.ptr(pred),
+                                                    _hip.ptr(rows), _hip.ptr(cnt), n, _stream()), "rgrg_select_regions_f32")
+        return loss, pred.view(B, Rg).bool()
+
     def select(self, top_region_features: Tensor, class_detected: Tensor, taps: Optional[dict] = None):
         B, Rg, D = top_region_features.shape
         x = top_region_features.reshape(B * Rg, D).contiguous().to(torch.float32)
-        h = self.linear(x, *self.sel[0], act=_hip.ACT_RELU)
-        h = self.linear(h, *self.sel[1], act=_hip.ACT_RELU)
-        logits = self.linear(h, *self.sel[2]).view(-1)
+        logits = self.classifier_logits(self.sel, x)
         n = B * Rg
         det = class_detected.reshape(-1).to(torch.uint8).contiguous()
         sel = torch.empty((n,), dtype=torch.uint8, device=x.device)
@@ -379,12 +414,13 @@ class HipEngine:
         return out[:, :out_len.value].contiguous()
 
     def beam_search(self, feats: Tensor, max_length: int, num_beams: int, early_stopping: bool = False,
-                    length_penalty: float = 1.0) -> Tensor:
+                    length_penalty: float = 1.0, bf16: bool = False) -> Tensor:
         """LanguageModel.generate(num_beams>1, num_return_sequences=1): feats [S,1024] -> int64 [S, L]."""
         _require_gpu(feats.device)
         S = feats.shape[0]
         limit = int(max_length)
         dec = self._get_decoder(S * num_beams, limit)
+        _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")
         feats = feats.to(torch.float32).contiguous()
         out = torch.empty((S, limit), dtype=torch.int64, device=feats.device)
         out_len = C.c_int(0)
@@ -392,6 +428,32 @@ class HipEngine:
                                                      float(length_penalty), _hip.ptr(out), limit, C.byref(out_len), _stream()),
                    "rgrg_decoder_beam_search")
         return out[:, :out_len.value].contiguous()
+
+    def lm_forward(self, feats: Tensor, input_ids: Tensor, attention_mask: Optional[Tensor], want_logits: bool = False,
+                   want_loss: bool = True, bf16: bool = False) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+        """LanguageModel.forward without cache (teacher forcing): feats [S,1024], input_ids int64 [S,T],
+        attention_mask [S,T] -> (logits f32 [S,T,V] or None, loss f32 scalar tensor or None)."""
+        _require_gpu(feats.device)
+        S, T = input_ids.shape
+        if feats.shape[0] != S:
+            raise ValueError(f"image_hidden_states has {feats.shape[0]} rows, input_ids {S}")
+        if T > 255:
+            raise NotImplementedError("the HIP teacher-forced pass supports sequences of up to 255 tokens")
+        lo, hi = int(input_ids.min().item()), int(input_ids.max().item())
+        if lo < 0 or hi >= self.vocab:
+            raise IndexError("index out of range in self")  # torch.nn.Embedding's error
+        dec = self._get_decoder(S, 2)
+        _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")
+        feats = feats.to(torch.float32).contiguous()
+        ids = input_ids.to(torch.int64).contiguous()
+        am = None if attention_mask is None else attention_mask.to(torch.float32).contiguous()
+        logits = torch.empty((S, T, self.vocab), dtype=torch.float32, device=feats.device) if want_logits else None
+        loss = torch.empty((), dtype=torch.float32, device=feats.device) if want_loss else None
+        _hip.check(self.lib.rgrg_decoder_lm_forward(dec, _hip.ptr(feats), _hip.ptr(ids), None if am is None else _hip.ptr(am),
+                                                    S, T, None if logits is None else _hip.ptr(logits),
+                                                    None if loss is None else _hip.ptr(loss), _stream()),
+                   "rgrg_decoder_lm_forward")
+        return logits, loss
 
     def last_logits(self, S: int) -> Tensor:
         dst = torch.empty((S, self.vocab), dtype=torch.float32, device=self.device)

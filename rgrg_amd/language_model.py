@@ -94,9 +94,38 @@ class LanguageModel(EngineOwner):
         self.gpt2_blocks = nn.ModuleList(nn.ModuleList([b.ln_1, b.attn, b.ln_2, b.mlp]) for b in self.gpt.h)
         self.feature_space_transformation_nn = nn.Sequential(nn.Linear(1024, 1024), nn.ReLU(), nn.Linear(1024, 1024))
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("teacher-forced LanguageModel.forward (training/eval loss) is SURVEY.md 8(f); "
-                                  "the HIP path implements generate()")
+    def forward(self, input_ids: torch.LongTensor, attention_mask: torch.FloatTensor, image_hidden_states: torch.FloatTensor,
+                return_loss: bool = False, past_key_values=None, position_ids: Optional[torch.LongTensor] = None,
+                use_cache: Optional[bool] = False):
+        """Teacher-forced pass of language_model.py:258-399 in eval mode (LM part):
+        ``return_loss=True`` -> the scalar language-modelling loss (float32 tensor).  Like the reference, the
+        positions of ``input_ids`` whose ``attention_mask`` is 0 are overwritten with -100 IN PLACE (:371-374),
+        and ``return_loss=False, use_cache=False`` returns None (:396-399).  The incremental
+        ``use_cache=True`` form belongs to the reference's own generate loop; here ``generate()`` owns the cache."""
+        if self.training:
+            raise NotImplementedError("rgrg_amd implements eval-mode forward (no dropout, no backward); training is SURVEY.md 8(f)")
+        if past_key_values is not None or use_cache:
+            raise NotImplementedError("incremental forward(use_cache=True / past_key_values) is internal to generate() "
+                                      "in the HIP path; call generate()")
+        if position_ids is not None:
+            T = input_ids.shape[-1]
+            if not torch.equal(position_ids.view(-1, T).cpu(), torch.arange(T).view(1, T).expand(position_ids.view(-1, T).shape[0], T)):
+                raise NotImplementedError("only the default position_ids = arange(seq_len) are supported")
+        if not return_loss:
+            return None
+        ids2 = input_ids.view(-1, input_ids.shape[-1])
+        am2 = attention_mask.view(ids2.shape[0], -1)
+        low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
+        _, loss = self.engine().lm_forward(image_hidden_states, ids2, am2, want_logits=False, want_loss=True, bf16=bool(low))
+        ids2[~am2.to(torch.bool)] = -100  # the reference's in-place label write (labels IS input_ids)
+        return loss
+
+    @torch.no_grad()
+    def teacher_forced_logits(self, input_ids: torch.LongTensor, attention_mask: torch.FloatTensor,
+                              image_hidden_states: torch.FloatTensor) -> torch.FloatTensor:
+        """lm_logits [S,T,50257] of the same pass (what the reference returns next to ``presents``, :398-399)."""
+        logits, _ = self.engine().lm_forward(image_hidden_states, input_ids, attention_mask, want_logits=True, want_loss=False)
+        return logits
 
     @torch.no_grad()
     def generate(self, image_hidden_states: torch.FloatTensor, max_length: Optional[int] = None, num_beams: int = 1,
@@ -131,5 +160,6 @@ class LanguageModel(EngineOwner):
             if 2 * num_beams > 16:
                 raise NotImplementedError("the HIP beam search supports num_beams <= 8")
             # length_penalty = 1.0 as in the reference (language_model.py:461)
-            return self.engine().beam_search(image_hidden_states, max_length, num_beams, early_stopping, 1.0)
+            low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
+            return self.engine().beam_search(image_hidden_states, max_length, num_beams, early_stopping, 1.0, bf16=bool(low))
         raise NotImplementedError("Diverse beam-search decoding is not implemented.")

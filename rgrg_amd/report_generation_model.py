@@ -6,7 +6,7 @@ tuple / ``-1`` sentinel (report_generation_model.py:12-33, :212-276).
 """
 from __future__ import annotations
 
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 from torch import Tensor
@@ -73,7 +73,8 @@ class ReportGenerationModel(EngineOwner):
         self.binary_classifier_region_selection = BinaryClassifierRegionSelection()
         self.binary_classifier_region_abnormal = BinaryClassifierRegionAbnormal()
         self.language_model = LanguageModel()
-        for child in (self.object_detector, self.binary_classifier_region_selection, self.language_model):
+        for child in (self.object_detector, self.binary_classifier_region_selection, self.binary_classifier_region_abnormal,
+                      self.language_model):
             self._adopt(child)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
@@ -89,9 +90,47 @@ class ReportGenerationModel(EngineOwner):
                 sd[k] = v
         return super().load_state_dict(sd, strict=strict, **kw)
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("ReportGenerationModel.forward (training / eval losses, report_generation_model.py:35-168) "
-                                  "is SURVEY.md 8(f) 'next'; the HIP path implements generate()")
+    def forward(self, images: torch.FloatTensor, image_targets, input_ids: torch.LongTensor,
+                attention_mask: torch.FloatTensor, region_has_sentence: torch.BoolTensor,
+                region_is_abnormal: torch.BoolTensor, return_loss: bool = True, past_key_values=None,
+                position_ids: Optional[torch.LongTensor] = None, use_cache: Optional[bool] = False):
+        """Eval-mode branch of report_generation_model.py:35-168:
+        detector -> both region classifiers with their losses -> decoder inputs of the SELECTED regions
+        (get_valid_decoder_input_for_evaluation, :196-210) -> teacher-forced language-model loss.  Returns
+        ``(obj_detector_loss_dict, classifier_loss_region_selection, classifier_loss_region_abnormal,
+        language_model_loss, detections, class_detected, selected_regions, predicted_abnormal_regions)``, the
+        7-tuple without the LM loss when ``pretrain_without_lm_model``, or ``-1`` when no region is selected (:136).
+
+        Not implemented: training mode (needs backward), and ``image_targets`` (the detector's validation
+        losses draw random anchor/proposal samples, torchvision ``BalancedPositiveNegativeSampler``): pass
+        ``image_targets=None`` and ``obj_detector_loss_dict`` is ``{}`` as in the reference's ``targets is None`` path
+        (object_detector.py:195-197)."""
+        if self.training:
+            raise NotImplementedError("rgrg_amd implements eval-mode forward(); the training step is SURVEY.md 8(f)")
+        if image_targets is not None:
+            raise NotImplementedError("detector validation losses (image_targets) are not implemented: pass image_targets=None")
+        obj_detector_loss_dict, detections, top_region_features, class_detected = self.object_detector(images, None)
+        del images
+        classifier_loss_region_selection, selected_regions, selected_region_features = self.binary_classifier_region_selection(
+            top_region_features, class_detected, return_loss=True, region_has_sentence=region_has_sentence)
+        classifier_loss_region_abnormal, predicted_abnormal_regions = self.binary_classifier_region_abnormal(
+            top_region_features, class_detected, region_is_abnormal)
+        if self.pretrain_without_lm_model:
+            return (obj_detector_loss_dict, classifier_loss_region_selection, classifier_loss_region_abnormal, detections,
+                    class_detected, selected_regions, predicted_abnormal_regions)
+        valid_input_ids, valid_attention_mask = self.get_valid_decoder_input_for_evaluation(selected_regions, input_ids,
+                                                                                            attention_mask)
+        if valid_input_ids.shape[0] == 0:
+            return -1
+        language_model_loss = self.language_model(valid_input_ids, valid_attention_mask, selected_region_features, return_loss,
+                                                  past_key_values, position_ids, use_cache)
+        return (obj_detector_loss_dict, classifier_loss_region_selection, classifier_loss_region_abnormal, language_model_loss,
+                detections, class_detected, selected_regions, predicted_abnormal_regions)
+
+    def get_valid_decoder_input_for_evaluation(self, selected_regions, input_ids, attention_mask):
+        """report_generation_model.py:196-210: rows of the (batch*29) sentences whose region was selected."""
+        selected_regions = selected_regions.reshape(-1)
+        return input_ids[selected_regions], attention_mask[selected_regions]
 
     @torch.no_grad()
     def generate(self, images: torch.FloatTensor, max_length: int = None, num_beams: int = 1, num_beam_groups: int = 1,

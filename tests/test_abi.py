@@ -117,6 +117,13 @@ def test_no_cpu_fallback(model):
         model.generate(torch.zeros(1, 1, 512, 512), max_length=4)
     with pytest.raises(_hip.RgrgHipError):
         model.language_model.generate(torch.zeros(2, 1024), 4)
+    ids, am = torch.zeros((2, 5), dtype=torch.int64), torch.ones((2, 5), dtype=torch.int64)
+    with pytest.raises(_hip.RgrgHipError):
+        model.language_model(ids, am, torch.zeros(2, 1024), return_loss=True)   # eval forward: HIP only as well
+    model.language_model.train()
+    with pytest.raises(NotImplementedError, match="eval-mode"):
+        model.language_model(ids, am, torch.zeros(2, 1024), return_loss=True)
+    model.language_model.eval()
 
 
 def test_product_never_imports_the_oracle():

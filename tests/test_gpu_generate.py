@@ -259,3 +259,92 @@ def test_decoder_bf16_opt_in_for_many_sequences():
     assert rel > 0.0  # the reduced-precision path really ran
     again = m.language_model.generate(feats, max_length=7)
     assert torch.equal(again, exact)
+
+
+# ------------------------------------------------------------------------- forward(), eval mode
+def test_teacher_forced_lm_loss_matches_reference_fixture():
+    """LanguageModel.forward(return_loss=True) through the HIP teacher-forced pass vs the REAL reference's loss
+    (fixture): 2e-4 absolute on a loss of ~11 (fp32, different summation order over 24 layers and 50257 logits);
+    probe logits within 1e-3 of the reference (logits of O(4)); the padded ids are overwritten with -100 in place."""
+    m = gpu_model("ragged")
+    fx = load_golden("lm_teacher_forced.pt")
+    for name, c in fx["cases"].items():
+        ids = c["input_ids"].clone().to(DEV)
+        am = c["attention_mask"].to(DEV)
+        loss = m.language_model(ids, am, c["feats"].to(DEV), return_loss=True)
+        assert loss.dtype == torch.float32 and loss.dim() == 0
+        assert abs(loss.item() - c["loss"].item()) <= 2e-4, (name, loss.item(), c["loss"].item())
+        assert torch.equal(ids.cpu(), c["input_ids_after"])
+        logits = m.language_model.teacher_forced_logits(c["input_ids"].to(DEV), am, c["feats"].to(DEV))
+        got = torch.stack([logits[s, t] for s, t in c["probes"]]).cpu()
+        assert (got - c["probe_logits"]).abs().max().item() <= 1e-3, name
+    assert m.language_model(ids, am, c["feats"].to(DEV), return_loss=False) is None  # language_model.py:396-399
+
+
+def test_teacher_forced_logits_equal_incremental_decode_and_oracle():
+    """Consistency of the two HIP decoders: feeding a greedy sequence back through the teacher-forced pass
+    reproduces the tokens the incremental (KV-cache) path chose, and its logits match the CPU oracle."""
+    m = gpu_model("ragged")
+    feats = _lm_feats().to(DEV)
+    ids = m.language_model.generate(feats, max_length=12)
+    L = ids.shape[1]
+    am = torch.ones_like(ids)
+    logits = m.language_model.teacher_forced_logits(ids, am, feats)
+    nxt = logits.argmax(-1)[:, :-1].cpu()
+    finished = (ids[:, 1:] == 50256).cumsum(1).cpu() > 0   # after EOS greedy_search writes PAD regardless of the logits
+    tgt = ids[:, 1:].cpu()
+    prev_fin = torch.cat([torch.zeros((ids.shape[0], 1), dtype=torch.bool), finished[:, :-1]], 1)
+    assert torch.equal(nxt[~prev_fin], tgt[~prev_fin])
+    o_logits = o_lm.lm_teacher_forced(synth_sd("ragged"), ids.cpu(), am.cpu(), _lm_feats(), return_loss=False)
+    assert (logits.cpu() - o_logits).abs().max().item() <= 2e-3
+    assert L >= 4
+
+
+def test_teacher_forced_many_rows_and_padding_properties():
+    """> 128 token rows (tiled split-K GEMM path) against the oracle, plus two size-independent properties: the loss
+    does not depend on what sits at padded positions, and an all-ones mask equals mask=None."""
+    m = gpu_model("ragged")
+    g = torch.Generator().manual_seed(11)
+    S, T = 12, 33                                   # 396 token rows, T + 1 = 34 keys
+    ids = torch.randint(0, 50257, (S, T), generator=g)
+    ids[:, 0] = 50256
+    lens = torch.randint(2, T + 1, (S,), generator=g)
+    am = (torch.arange(T)[None, :] < lens[:, None]).to(torch.int64)
+    feats = torch.randn((S, 1024), generator=g)
+    ref = o_lm.lm_teacher_forced(synth_sd("ragged"), ids, am, feats, return_loss=True)
+    loss = m.language_model(ids.clone().to(DEV), am.to(DEV), feats.to(DEV), return_loss=True)
+    assert abs(loss.item() - ref.item()) <= 2e-4, (loss.item(), ref.item())
+    junk = ids.clone()
+    junk[am == 0] = 123                              # different pad content, same mask
+    loss2 = m.language_model(junk.to(DEV), am.to(DEV), feats.to(DEV), return_loss=True)
+    assert abs(loss2.item() - loss.item()) <= 1e-5   # padded keys get weight exp(-1e4) = 0 and padded labels are ignored
+    eng = m.engine()
+    _, l_ones = eng.lm_forward(feats.to(DEV), ids.to(DEV), torch.ones((S, T), device=DEV))
+    _, l_none = eng.lm_forward(feats.to(DEV), ids.to(DEV), None)
+    assert l_ones.item() == l_none.item()
+
+
+def test_eval_forward_matches_reference_fixture():
+    """ReportGenerationModel.forward in eval mode (image_targets=None) vs the REAL reference: masks bit-exact,
+    classifier losses to 1e-5, LM loss to 2e-4, boxes to 1e-2 px."""
+    import rgrg_amd
+    fx = load_golden("forward_eval_b2.pt")
+    m = rgrg_amd.ReportGenerationModel(pretrain_without_lm_model=False)
+    m.load_state_dict(synth_sd("ragged"))
+    m.to(torch.device("cuda", 0)).eval()
+    images = torch.cat([synth.make_images(1, s) for s in fx["meta"]["image_seeds"]], 0).to(DEV)
+    i, e = fx["inputs"], fx["expected"]
+    out = m(images, None, i["input_ids"].clone().to(DEV), i["attention_mask"].to(DEV), i["region_has_sentence"].to(DEV),
+            i["region_is_abnormal"].to(DEV), return_loss=True)
+    assert len(out) == 8 and out[0] == {}
+    assert abs(out[1].item() - e["classifier_loss_region_selection"].item()) <= 1e-5
+    assert abs(out[2].item() - e["classifier_loss_region_abnormal"].item()) <= 1e-5
+    assert abs(out[3].item() - e["language_model_loss"].item()) <= 2e-4
+    assert torch.equal(out[5].cpu(), e["class_detected"]) and torch.equal(out[6].cpu(), e["selected_regions"])
+    assert torch.equal(out[7].cpu(), e["predicted_abnormal_regions"])
+    assert (out[4]["top_region_boxes"].cpu() - e["top_region_boxes"]).abs().max().item() <= 1e-2
+    with pytest.raises(NotImplementedError):
+        m(images, [{"boxes": None, "labels": None}], None, None, None, None)
+    m.pretrain_without_lm_model = True
+    assert len(m(images, None, None, None, i["region_has_sentence"].to(DEV), i["region_is_abnormal"].to(DEV))) == 7
+    m.invalidate_engine()

@@ -87,3 +87,45 @@ def test_beam_scorer_hand_case():
     h.add(torch.tensor([1]), -5.0)            # worse than worst: ignored
     assert len(h) == 2
     assert h.is_done(-8.0, 4) and not h.is_done(-2.0, 4)   # -8/4 = -2 <= -1.0 done ; -2/4 = -0.5 > -1.0 not done
+
+
+# ------------------------------------------------------------------------- forward(), eval mode
+def test_teacher_forced_lm_oracle_matches_reference_forward(sd_ragged):
+    """LanguageModel.forward(return_loss=True) of the REAL reference (fixture) vs the restatement: loss to 1e-5
+    absolute (loss ~ 11), probe logits to 2e-4; padded label positions are ignored."""
+    fx = load_golden("lm_teacher_forced.pt")
+    assert fx["meta"]["oracle_matches_reference"] is True
+    for name in ("ragged_s6_t11", "full_s3_t7"):
+        c = fx["cases"][name]
+        loss = o_lm.lm_teacher_forced(sd_ragged, c["input_ids"], c["attention_mask"], c["feats"], return_loss=True)
+        assert abs(loss.item() - c["loss"].item()) <= 1e-5, name
+        logits = o_lm.lm_teacher_forced(sd_ragged, c["input_ids"], c["attention_mask"], c["feats"], return_loss=False)
+        got = torch.stack([logits[s, t] for s, t in c["probes"]])
+        assert (got - c["probe_logits"]).abs().max().item() <= 2e-4, name
+        # the reference overwrote the padded ids with -100 in place (labels IS input_ids, language_model.py:371-374)
+        am = c["attention_mask"].bool()
+        assert (c["input_ids_after"][~am] == -100).all() and torch.equal(c["input_ids_after"][am], c["input_ids"][am])
+    # a fully padded label row set contributes nothing: masking every label but one leaves that row's NLL
+    c = fx["cases"]["full_s3_t7"]
+    m1 = torch.zeros_like(c["attention_mask"])
+    m1[:, 0] = 1
+    m1[1, 1] = 1
+    one = o_lm.lm_teacher_forced(sd_ragged, c["input_ids"], m1, c["feats"], return_loss=True)
+    assert torch.isfinite(one) and one.item() > 0
+
+
+def test_eval_forward_oracle_matches_reference(sd_ragged):
+    """ReportGenerationModel.forward (eval, image_targets=None) of the REAL reference vs the restatement."""
+    fx = load_golden("forward_eval_b2.pt")
+    assert fx["meta"]["oracle_matches_reference"] is True
+    images = torch.cat([synth.make_images(1, s) for s in fx["meta"]["image_seeds"]], 0)
+    i, e = fx["inputs"], fx["expected"]
+    out = o_full.forward_eval(sd_ragged, images, i["input_ids"].clone(), i["attention_mask"], i["region_has_sentence"],
+                              i["region_is_abnormal"])
+    assert out[0] == {}
+    for got, key in ((out[1], "classifier_loss_region_selection"), (out[2], "classifier_loss_region_abnormal"),
+                     (out[3], "language_model_loss")):
+        assert abs(got.item() - e[key].item()) <= 1e-5, key
+    assert torch.equal(out[5], e["class_detected"]) and torch.equal(out[6], e["selected_regions"])
+    assert torch.equal(out[7], e["predicted_abnormal_regions"])
+    assert torch.equal(out[4]["top_region_boxes"], e["top_region_boxes"])
