@@ -960,73 +960,123 @@ __global__ __launch_bounds__(256) void embed_seq_ln_kernel(const float* __restri
 // GPT2PseudoAttention.forward without layer_past (:124-160) and _attn (:84-122) over T tokens: keys/values are
 // [uk(img) ; k_0..k_{T-1}], scores / 8, future token columns replaced by -1e4 (the image column is never masked),
 // plus the additive padding mask (1 - [1|attention_mask]) * -10000 (:325-334), softmax, . V.
-// One workgroup per (sequence, head): K (rows padded to 65 floats) and V live in LDS; a wave owns query rows
-// wave, wave+4, ...; a lane owns keys lane, lane+64, ... for the scores and one of the 64 dims for P.V.
+//
+// One WAVE per (sequence, head, 32-query tile), everything in registers on the exact-fp32 matrix core
+// (v_mfma_f32_32x32x2_f32), no LDS:
+//   * scores are computed TRANSPOSED, S^T = K Q^T (A = 32 keys x dims, B = dims x 32 queries; a lane half owns
+//     dims [32h, 32h+32), so a lane reads 128 contiguous bytes of its key / query row).  In the accumulator layout a
+//     lane then holds ONE query (column lane&31) and 16 keys per tile, half of that query's keys - the softmax row
+//     reduction is a register loop plus one exchange with lane^32;
+//   * that same layout is exactly the B operand (keys x queries) of O^T = V^T P^T: register j of a tile is fed to
+//     the MFMA as is, next to A = V[key(j, lane half)][dim], a coalesced 128-byte row read.  No transpose.
+// Key tiles entirely in the future of the query tile are skipped: their weights are exp(-1e4 - max) = 0 in fp32
+// because the never-masked image column keeps max = O(1).  Keys beyond T (tile padding) get -inf.
 constexpr int TF_MAX_T = 255;
+template <int NT>  // key tiles held in registers: T + 1 <= 32 * NT
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
                                                            int kcol, const float* __restrict__ am, float* __restrict__ out,
-                                                           int H, int T) {
-    extern __shared__ __attribute__((aligned(16))) float tf_sm[];
+                                                           int S, int H, int T) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int QT = (T + 31) / 32;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= S * H * QT) return;
+    const int qt = item % QT, sh = item / QT, hd = sh % H, s = sh / H;
     const int NK = T + 1, D = H * 64;
-    float* Ks = tf_sm;              // [NK][65]
-    float* Vs = Ks + NK * 65;       // [NK][64]
-    float* Qs = Vs + NK * 64;       // [4][64]
-    float* Ps = Qs + 4 * 64;        // [4][NK]
-    float* addm = Ps + 4 * NK;      // [NK]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = blockIdx.x / H, hd = blockIdx.x - s * H;
-    for (int idx = tid; idx < NK * 64; idx += 256) {
-        const int c = idx >> 6, e = idx & 63;
-        float k, v;
-        if (c == 0) {
-            k = ukv[(size_t)s * ld_ukv + kcol + hd * 64 + e];
-            v = ukv[(size_t)s * ld_ukv + kcol + D + hd * 64 + e];
-        } else {
-            const float* r = qkv + ((size_t)s * T + c - 1) * 3 * D + hd * 64 + e;
-            k = r[D];
-            v = r[2 * D];
-        }
-        Ks[c * 65 + e] = k;
-        Vs[c * 64 + e] = v;
-    }
-    for (int c = tid; c < NK; c += 256) addm[c] = (c == 0 || !am) ? 0.f : (1.0f - am[(size_t)s * T + c - 1]) * -10000.0f;
-    __syncthreads();
-    for (int i = wave; i < T; i += 4) {
-        Qs[wave * 64 + lane] = qkv[((size_t)s * T + i) * 3 * D + hd * 64 + lane];
-        __builtin_amdgcn_wave_barrier();
-        float w[4];
-        float m = -INFINITY;
+    const int col = lane & 31, half = lane >> 5;
+    const int iq = qt * 32 + col;                    // this lane's query (column of S^T)
+    const int need = min(NK - 1, qt * 32 + 32) / 32 + 1;  // key tiles with a key <= last query of the tile + 1
+    auto krow = [&](int c) -> const float* {         // K row of key c (c = 0: image key); V row = K row + D
+        c = min(c, NK - 1);
+        return c == 0 ? ukv + (size_t)s * ld_ukv + kcol + hd * 64 : qkv + ((size_t)s * T + c - 1) * 3 * D + D + hd * 64;
+    };
+    // B operand of S^T: this lane's query row, dims [32*half, 32*half + 32)
+    f32x4 qf[8];
+    {
+        const float* qp = qkv + ((size_t)s * T + min(iq, T - 1)) * 3 * D + hd * 64 + half * 32;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = lane + 64 * u;
-            w[u] = -INFINITY;
-            if (c < NK) {
-                float dot = 0.f;
-#pragma unroll 16
-                for (int e = 0; e < 64; ++e) dot += Qs[wave * 64 + e] * Ks[c * 65 + e];
-                const bool allowed = (c == 0) || (c - 1 <= i);
-                w[u] = (allowed ? dot / 8.0f : -1e4f) + addm[c];
-                m = fmaxf(m, w[u]);
+        for (int u = 0; u < 8; ++u) qf[u] = *reinterpret_cast<const f32x4*>(qp + 4 * u);
+    }
+    f32x16 sc[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        if (kt < need) {
+            f32x4 kf[8];
+            const float* kp = krow(kt * 32 + col) + half * 32;   // A operand: key row kt*32 + (lane&31), same dims
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kf[u] = *reinterpret_cast<const f32x4*>(kp + 4 * u);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u][e], qf[u][e], acc, 0, 0, 0);
+            sc[kt] = acc;
+        }
+    }
+    // masks, scale, softmax over the keys of query iq (this lane: 16 keys per tile, lane^32 the other 16)
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        if (kt < need) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float w = -INFINITY;
+                if (c < NK) {
+                    const bool allowed = (c == 0) || (c - 1 <= iq);
+                    const float addm = (c == 0 || !am) ? 0.f : (1.0f - am[(size_t)s * T + c - 1]) * -10000.0f;
+                    w = (allowed ? sc[kt][r] / 8.0f : -1e4f) + addm;
+                }
+                sc[kt][r] = w;
+                m = fmaxf(m, w);
             }
         }
-        m = wave_max(m);
-        float sum = 0.f;
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = lane + 64 * u;
-            if (c < NK) { w[u] = expf(w[u] - m); sum += w[u]; }
-        }
-        sum = wave_sum(sum);
+    for (int kt = 0; kt < NT; ++kt) {
+        if (kt < need) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = lane + 64 * u;
-            if (c < NK) Ps[wave * NK + c] = w[u] / sum;
+            for (int r = 0; r < 16; ++r) {
+                const float pexp = expf(sc[kt][r] - m);
+                sc[kt][r] = pexp;
+                sum += pexp;
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        float acc = 0.f;
-        for (int c = 0; c < NK; ++c) acc += Ps[wave * NK + c] * Vs[c * 64 + lane];
-        out[((size_t)s * T + i) * D + hd * 64 + lane] = acc;
-        __builtin_amdgcn_wave_barrier();
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    // O^T = V^T P^T : A = V[key(j, half)][dim = lane&31 (+32)], B = register j of the tile
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        if (kt < need) {
+            float v0[16], v1[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float* vp = krow(kt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half) + D;
+                v0[j] = vp[col];
+                v1[j] = vp[32 + col];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float pj = sc[kt][j] / sum;
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[j], pj, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[j], pj, o1, 0, 0, 0);
+            }
+        }
+    }
+    if (iq < T) {
+        float* op = out + ((size_t)s * T + iq) * D + hd * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dim = (r & 3) + 8 * (r >> 2) + 4 * half;
+            op[dim] = o0[r];
+            op[32 + dim] = o1[r];
+        }
     }
 }
 
@@ -1692,13 +1742,6 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
     const int D = d->D, M = S * T;
     int rc = tf_reserve(d, (size_t)M);
     if (rc) return rc;
-    const size_t lds = ((size_t)(T + 1) * (65 + 64 + 4 + 1) + 4 * 64) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_done = true;
-    }
     hipStream_t caller = as_stream(stream), st = d->stream;
     RGRG_HIP(hipEventRecord(d->ev_in, caller));
     RGRG_HIP(hipStreamWaitEvent(st, d->ev_in, 0));
@@ -1716,9 +1759,16 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
         const float* ng = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_g : d->lnf_g;
         const float* nb = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_b : d->lnf_b;
         if ((rc = tf_linear(d, w.c_attn, d->tf_xn, nullptr, d->tf_qkv, M, 3 * D, RGRG_ACT_NONE))) return rc;
-        hipLaunchKernelGGL(attn_prefill_kernel, dim3(S * d->H), dim3(256), lds, st, d->tf_qkv, d->ukv_out, d->ld_ukv, l * 2 * D,
-                           attention_mask, d->tf_att, d->H, T);
-        RGRG_LAUNCH_CHECK();
+        {
+            const int items = S * d->H * ((T + 31) / 32);
+            if (T + 1 <= 96)
+                hipLaunchKernelGGL(attn_prefill_kernel<3>, dim3((items + 3) / 4), dim3(256), 0, st, d->tf_qkv, d->ukv_out, d->ld_ukv,
+                                   l * 2 * D, attention_mask, d->tf_att, S, d->H, T);
+            else
+                hipLaunchKernelGGL(attn_prefill_kernel<8>, dim3((items + 3) / 4), dim3(256), 0, st, d->tf_qkv, d->ukv_out, d->ld_ukv,
+                                   l * 2 * D, attention_mask, d->tf_att, S, d->H, T);
+            RGRG_LAUNCH_CHECK();
+        }
         if ((rc = tf_linear(d, w.attn_proj, d->tf_att, d->tf_x, d->tf_x, M, D, RGRG_ACT_NONE))) return rc;
         hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, d->tf_x, nullptr, nullptr, 1, 0, w.ln2_g, w.ln2_b, d->tf_xn, D);
         RGRG_LAUNCH_CHECK();
