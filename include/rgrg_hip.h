@@ -186,6 +186,28 @@ int rgrg_decoder_set_precision(rgrg_decoder* d, int bf16_gemms);
  * for S*T token rows is grown on demand (first call of a larger size allocates). */
 int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, const int64_t* input_ids, const float* attention_mask,
                             int S, int T, float* logits_out, float* loss_out, void* stream);
+/* Replaces `language_model_loss.backward()` of the training loop (src/full_model/train_full_model.py:172-208) for the
+ * decoder: the same teacher-forced pass as rgrg_decoder_lm_forward, keeping the activations, followed by the backward
+ * pass.  Only what the reference trains in the language model receives a gradient: uk / uv of every
+ * GPT2PseudoAttention (src/language_model/language_model.py:50-57) and feature_space_transformation_nn (:230-236);
+ * every other GPT-2 tensor is frozen there (:207-213), so the 24 blocks only propagate activation gradients
+ * (dX = dY W on transposed weight copies made at the first call).  Dropout is not applied (deterministic pass).
+ *   loss_scale    d(total_loss)/d(language_model_loss), e.g. the loss weight (and an AMP scale)
+ *   loss_out      one f32, the unscaled loss
+ *   grad_ukv_w    f32 [n_layer*2*1024, 1024]  rows = [uk_0; uv_0; uk_1; uv_1; ...]      grad_ukv_b  f32 [n_layer*2*1024]
+ *   grad_fst0_w/b, grad_fst2_w/b   f32 [1024,1024] / [1024]  (Linear 0 and 2 of feature_space_transformation_nn)
+ * Gradients are WRITTEN (not accumulated).  T <= 160.  Allocates work space on demand (~0.9 MB per token row). */
+int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, const int64_t* input_ids, const float* attention_mask,
+                              int S, int T, float loss_scale, float* loss_out, float* grad_ukv_w, float* grad_ukv_b,
+                              float* grad_fst0_w, float* grad_fst0_b, float* grad_fst2_w, float* grad_fst2_b, void* stream);
+/* After an optimizer step changed the trainable decoder weights IN PLACE (the fst0/fst2/ukv pointers given to
+ * rgrg_decoder_create): rebuild the kernel-side copies derived from them (packed skinny layouts, transposes). */
+int rgrg_decoder_refresh_trainable(rgrg_decoder* d, void* stream);
+/* Replaces torch.optim.AdamW.step() for one parameter tensor (train_full_model.py:409, decoupled weight decay):
+ *   p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * with g = grad * grad_scale (1/AMP-scale, 1/accumulation steps).  All arrays f32 [n]; step t >= 1. */
+int rgrg_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 /* fp32 -> bf16 (round to nearest even), and Y = act(bf16(A) Wb^T + shift + R) on v_mfma_f32_32x32x16_bf16
  * (A fp32 [M,K], Wb bf16 [N,K], K % 64 == 0). */
 int rgrg_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);

@@ -108,6 +108,34 @@ def lm_teacher_forced(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_h
     return F.cross_entropy(logits[:, :-1, :].reshape(-1, VOCAB), labels[:, 1:].reshape(-1), ignore_index=-100)
 
 
+def trainable_keys(p: str = "language_model.") -> List[str]:
+    """The decoder tensors the reference trains (language_model.py:207-213 freezes GPT-2 before uk/uv and
+    feature_space_transformation_nn are created, :50-57,:230-236)."""
+    g = p + "gpt_with_lm_head.transformer."
+    keys = []
+    for l in range(N_LAYER):
+        keys += [f"{g}h.{l}.attn.{n}.{wb}" for n in ("uk", "uv") for wb in ("weight", "bias")]
+    return keys + [p + f"feature_space_transformation_nn.{i}.{wb}" for i in (0, 2) for wb in ("weight", "bias")]
+
+
+def lm_loss_and_grads(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_states: Tensor, p: str = "language_model."):
+    """``loss = LanguageModel.forward(return_loss=True); loss.backward()`` with dropout off (modules in eval mode,
+    gradients enabled): torch autograd through the restated forward.  Returns (loss, {key: grad})."""
+    sd2 = dict(sd)
+    keys = trainable_keys(p)
+    for k in keys:
+        sd2[k] = sd[k].detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        S, T = input_ids.shape
+        pos = torch.arange(T, dtype=torch.long)[None, :]
+        logits, _ = lm_forward(sd2, input_ids, attention_mask, image_hidden_states, None, pos, p)
+        labels = input_ids.clone()
+        labels[~attention_mask.to(torch.bool)] = -100
+        loss = F.cross_entropy(logits[:, :-1, :].reshape(-1, VOCAB), labels[:, 1:].reshape(-1), ignore_index=-100)
+        loss.backward()
+    return loss.detach(), {k: sd2[k].grad for k in keys}
+
+
 @torch.no_grad()
 def greedy_generate(sd: SD, image_hidden_states: Tensor, max_length: Optional[int], p: str = "language_model.",
                     return_logits: bool = False):

@@ -54,6 +54,9 @@ SIGNATURES = {
     "rgrg_decoder_beam_search": (_i, [_p, _p, _i, _i, _i, _i, _f, _p, _i, C.POINTER(_i), _p]),
     "rgrg_decoder_set_precision": (_i, [_p, _i]),
     "rgrg_decoder_lm_forward": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p]),
+    "rgrg_decoder_lm_loss_grad": (_i, [_p, _p, _p, _p, _i, _i, C.c_float, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "rgrg_decoder_refresh_trainable": (_i, [_p, _p]),
+    "rgrg_adamw_step_f32": (_i, [_p, _p, _p, _p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _p]),
     "rgrg_f32_to_bf16": (_i, [_p, _p, C.c_int64, _p]),
     "rgrg_linear_bf16w_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rgrg_decoder_copy_last_logits": (_i, [_p, _p, _i, _p]),

@@ -1084,7 +1084,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
 // scored against ids[s][t+1] unless attention_mask[s][t+1] == 0.  One workgroup per logits row of the chunk.
 __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, size_t ld, int V, int row0,
                                                       const long long* __restrict__ ids, const float* __restrict__ am, int T,
-                                                      float* __restrict__ row_loss, int* __restrict__ row_valid) {
+                                                      float* __restrict__ row_loss, int* __restrict__ row_valid,
+                                                      float* __restrict__ row_lse) {
     __shared__ float shv[4];
     const int r = row0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = r % T;
@@ -1108,14 +1109,16 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
     __syncthreads();
     if (tid == 0) {
         const float tot = (shv[0] + shv[1]) + (shv[2] + shv[3]);
-        row_loss[r] = (m + logf(tot)) - x[ids[r + 1]];
+        const float lse = m + logf(tot);
+        row_loss[r] = lse - x[ids[r + 1]];
         row_valid[r] = 1;
+        if (row_lse) row_lse[r] = lse;
     }
 }
 
 // mean over the scored rows in a fixed order (double accumulation); no scored row -> nan, like torch
 __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restrict__ row_loss, const int* __restrict__ row_valid,
-                                                          int n, float* __restrict__ loss) {
+                                                          int n, float* __restrict__ loss, int* __restrict__ n_scored = nullptr) {
     __shared__ double ssum[256];
     __shared__ int scnt[256];
     double a = 0.0;
@@ -1128,7 +1131,20 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restric
         if (threadIdx.x < o) { ssum[threadIdx.x] += ssum[threadIdx.x + o]; scnt[threadIdx.x] += scnt[threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *loss = (float)(ssum[0] / (double)scnt[0]);
+    if (threadIdx.x == 0) {
+        if (loss) *loss = (float)(ssum[0] / (double)scnt[0]);
+        if (n_scored) *n_scored = scnt[0];
+    }
+}
+
+// row_valid of every token row from the ids/mask alone (the scored-row count is needed before the first chunk's backward)
+__global__ __launch_bounds__(256) void ce_valid_kernel(const float* __restrict__ am, int T, int n, float* __restrict__ row_loss,
+                                                       int* __restrict__ row_valid) {
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+        const int t = r % T;
+        row_valid[r] = !((t == T - 1) || (am && am[r + 1] == 0.f));
+        row_loss[r] = 0.f;
+    }
 }
 
 // ------------------------------------------------------------------ decoder object
@@ -1137,6 +1153,7 @@ struct Lin {
     const float* b = nullptr;  // [N]
     float* packed = nullptr;   // skinny layout
     void* wb = nullptr;        // bf16 copy of w (opt-in many-sequence path)
+    float* wT = nullptr;       // [K][Np] transposed copy, Np = N rounded up to 32 (backward pass: dX = dY W)
     int N = 0, K = 0, NT = 0, KS = 1, ntile = 32;
 };
 
@@ -1183,6 +1200,13 @@ struct rgrg_decoder {
           *tf_ws = nullptr, *tf_row_loss = nullptr;
     int* tf_row_valid = nullptr;
     size_t tf_rows = 0, tf_ws_floats = 0;
+    // training pass (rgrg_decoder_lm_loss_grad): saved activations and gradient work space, grown on demand
+    float *tr_xs = nullptr, *tr_qkv = nullptr, *tr_ffpre = nullptr, *tr_ff = nullptr, *tr_dx = nullptr, *tr_dbig = nullptr,
+          *tr_dxn = nullptr, *tr_logits = nullptr, *tr_dukv = nullptr, *tr_t1 = nullptr, *tr_t2 = nullptr, *tr_dimg = nullptr,
+          *tr_dh1 = nullptr, *tr_row_lse = nullptr;
+    int* tr_count = nullptr;
+    size_t tr_rows = 0, tr_seqs = 0;
+    bool have_wT = false;
     int bf16_gemms = 0;  // 1: bf16-weight MFMA GEMMs on the many-sequence path (not bit-exact; opt-in)
     int gemm_launches_per_step = 0;
 };
@@ -1467,6 +1491,7 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
 
 namespace rgrg {
 static void tf_free(rgrg_decoder* d);
+static void tr_free(rgrg_decoder* d);
 }
 
 extern "C" void rgrg_decoder_destroy(rgrg_decoder* d) {
@@ -1474,6 +1499,7 @@ extern "C" void rgrg_decoder_destroy(rgrg_decoder* d) {
     for (auto& g : d->graphs) (void)hipGraphExecDestroy(g.exec);
     for (void* p : d->allocs) (void)hipFree(p);
     tf_free(d);
+    tr_free(d);
     if (d->h_done) (void)hipHostFree(d->h_done);
     if (d->ev_in) (void)hipEventDestroy(d->ev_in);
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -1784,7 +1810,7 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
         if ((rc = tf_linear(d, d->lm_head, d->tf_xn + (size_t)r0 * D, nullptr, lg, rows, d->V, RGRG_ACT_NONE))) return rc;
         if (loss_out) {
             hipLaunchKernelGGL(ce_rows_kernel, dim3(rows), dim3(256), 0, st, lg, (size_t)d->V, d->V, r0, ids, attention_mask, T,
-                               d->tf_row_loss, d->tf_row_valid);
+                               d->tf_row_loss, d->tf_row_valid, (float*)nullptr);
             RGRG_LAUNCH_CHECK();
         }
     }
@@ -1793,6 +1819,217 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
         RGRG_LAUNCH_CHECK();
     }
     // the caller's stream continues after this pass (no host synchronisation)
+    RGRG_HIP(hipEventRecord(d->ev_in, st));
+    RGRG_HIP(hipStreamWaitEvent(caller, d->ev_in, 0));
+    return RGRG_OK;
+}
+
+// ------------------------------------------------------------------ training pass: loss + gradients (host side)
+namespace rgrg {
+// train_ops.hip
+int launch_gelu_apply(const float* pre, float* out, size_t n, hipStream_t st);
+int launch_gelu_backward(float* d, const float* pre, size_t n, hipStream_t st);
+int launch_relu_backward(float* d, const float* h, size_t n, hipStream_t st);
+int launch_ln_backward(const float* dy, const float* x, const float* g, float* out, int rows, int D, int accumulate, hipStream_t st);
+int launch_ce_backward(float* logits, size_t ld, int V, int row0, int rows, const long long* ids, const int* row_valid,
+                       const float* row_lse, const int* n_scored, float scale, hipStream_t st);
+int launch_transpose_pad(const float* src, float* dst, int R, int Cc, int Rp, hipStream_t st);
+int launch_colsum(const float* src, float* out, int R, int Cc, hipStream_t st);
+int attn_backward_max_t();
+int launch_attn_backward(const float* qkv, const float* ukv, int ld_ukv, int kcol, const float* am, const float* d_att, float* d_qkv,
+                         float* d_ukv, int S, int H, int T, hipStream_t st);
+
+static int pad32(int n) { return (n + 31) / 32 * 32; }
+
+// transposed copies of the frozen weights the activation gradients flow through (made once)
+static int make_wT(rgrg_decoder* d, Lin& l) {
+    if (l.wT) return RGRG_OK;
+    const int Np = pad32(l.N);
+    int rc = dmalloc(d, (void**)&l.wT, (size_t)l.K * Np * sizeof(float), false);
+    if (rc) return rc;
+    return launch_transpose_pad(l.w, l.wT, l.N, l.K, Np, d->stream);
+}
+
+static int ensure_wT(rgrg_decoder* d) {
+    if (d->have_wT) return RGRG_OK;
+    int rc;
+    if ((rc = make_wT(d, d->lm_head)) || (rc = make_wT(d, d->ukv)) || (rc = make_wT(d, d->fst2))) return rc;
+    for (auto& w : d->layers)
+        if ((rc = make_wT(d, w.c_attn)) || (rc = make_wT(d, w.attn_proj)) || (rc = make_wT(d, w.c_fc)) || (rc = make_wT(d, w.mlp_proj)))
+            return rc;
+    d->have_wT = true;
+    return RGRG_OK;
+}
+
+static void tr_free(rgrg_decoder* d) {
+    float** fs[] = {&d->tr_xs, &d->tr_qkv, &d->tr_ffpre, &d->tr_ff, &d->tr_dx, &d->tr_dbig, &d->tr_dxn, &d->tr_logits,
+                    &d->tr_dukv, &d->tr_t1, &d->tr_t2, &d->tr_dimg, &d->tr_dh1, &d->tr_row_lse};
+    for (float** f : fs) { if (*f) (void)hipFree(*f); *f = nullptr; }
+    if (d->tr_count) (void)hipFree(d->tr_count);
+    d->tr_count = nullptr;
+    d->tr_rows = d->tr_seqs = 0;
+}
+
+static int tr_reserve(rgrg_decoder* d, size_t rows, size_t seqs) {
+    if (rows <= d->tr_rows && seqs <= d->tr_seqs) return RGRG_OK;
+    tr_free(d);
+    rows = rows > d->tr_rows ? rows : d->tr_rows;
+    const size_t D = (size_t)d->D, L = (size_t)d->n_layer, Sp = (size_t)pad32((int)seqs), VP = (size_t)pad32(d->V);
+    const size_t chunk = rows < (size_t)TF_LOGIT_ROWS ? rows : (size_t)TF_LOGIT_ROWS;
+    RGRG_HIP(hipMalloc((void**)&d->tr_xs, (2 * L + 1) * rows * D * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_qkv, L * rows * 3 * D * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_ffpre, L * rows * 4 * D * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_ff, rows * 4 * D * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_dx, rows * D * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_dbig, rows * 4 * D * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_dxn, rows * D * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_logits, chunk * VP * 4));
+    RGRG_HIP(hipMemset(d->tr_logits, 0, chunk * VP * 4));  // the K-padding columns stay 0 for the backward GEMM
+    RGRG_HIP(hipMalloc((void**)&d->tr_dukv, seqs * (size_t)d->ld_ukv * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_t1, (size_t)d->ld_ukv * Sp * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_t2, D * Sp * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_dimg, seqs * D * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_dh1, seqs * D * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_row_lse, rows * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_count, 4));
+    d->tr_rows = rows;
+    d->tr_seqs = seqs;
+    return RGRG_OK;
+}
+
+// Y = X W^T (+R) on the fp32 tiled GEMM with the teacher-forced pass's split-K work space
+static int tr_gemm(rgrg_decoder* d, const float* X, const float* W, const float* b, const float* R, float* Y, int M, int N, int K,
+                   int ldy, int act = RGRG_ACT_NONE) {
+    return launch_gemm_dense(X, W, b, R, Y, M, N, K, ldy, act, d->tf_ws, d->tf_ws_floats, d->stream);
+}
+}  // namespace rgrg
+
+extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, const int64_t* input_ids,
+                                         const float* attention_mask, int S, int T, float loss_scale, float* loss_out,
+                                         float* grad_ukv_w, float* grad_ukv_b, float* grad_fst0_w, float* grad_fst0_b,
+                                         float* grad_fst2_w, float* grad_fst2_b, void* stream) {
+    RGRG_CHECK_ARG(d && feats && input_ids && loss_out && grad_ukv_w && grad_ukv_b && grad_fst0_w && grad_fst0_b && grad_fst2_w &&
+                   grad_fst2_b);
+    RGRG_CHECK_ARG(S > 0 && S <= d->max_seqs && T >= 2 && T <= attn_backward_max_t());
+    const int D = d->D, M = S * T, L = d->n_layer, V = d->V, VP = pad32(V), Sp = pad32(S), LD = d->ld_ukv;
+    int rc;
+    if ((rc = tf_reserve(d, (size_t)M)) || (rc = tr_reserve(d, (size_t)M, (size_t)S))) return rc;
+    hipStream_t caller = as_stream(stream), st = d->stream;
+    RGRG_HIP(hipEventRecord(d->ev_in, caller));
+    RGRG_HIP(hipStreamWaitEvent(st, d->ev_in, 0));
+    if ((rc = ensure_wT(d))) return rc;
+    const long long* ids = reinterpret_cast<const long long*>(input_ids);
+    const size_t MD = (size_t)M * D;
+    auto xs = [&](int i) { return d->tr_xs + (size_t)i * MD; };
+
+    // ---------------- forward, keeping what the backward needs (layer inputs, qkv, c_fc pre-activations)
+    RGRG_HIP(hipMemcpyAsync(d->feats, feats, (size_t)S * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if ((rc = linear(d, d->fst0, d->feats, nullptr, d->h1, S, D, RGRG_ACT_RELU, false))) return rc;
+    if ((rc = linear(d, d->fst2, d->h1, nullptr, d->img, S, D, RGRG_ACT_NONE, false))) return rc;
+    if ((rc = linear(d, d->ukv, d->img, nullptr, d->ukv_out, S, LD, RGRG_ACT_NONE, false))) return rc;
+    hipLaunchKernelGGL(embed_seq_ln_kernel, dim3(M), dim3(256), 0, st, d->wte, ids, T, d->layers[0].ln1_g, d->layers[0].ln1_b,
+                       xs(0), d->tf_xn, D);
+    RGRG_LAUNCH_CHECK();
+    const int items = S * d->H * ((T + 31) / 32);
+    for (int l = 0; l < L; ++l) {
+        const LayerW& w = d->layers[l];
+        const float* ng = (l + 1 < L) ? d->layers[l + 1].ln1_g : d->lnf_g;
+        const float* nb = (l + 1 < L) ? d->layers[l + 1].ln1_b : d->lnf_b;
+        float* qkv = d->tr_qkv + (size_t)l * M * 3 * D;
+        float* ffpre = d->tr_ffpre + (size_t)l * M * 4 * D;
+        if ((rc = tr_gemm(d, d->tf_xn, w.c_attn.w, w.c_attn.b, nullptr, qkv, M, 3 * D, D, 3 * D))) return rc;
+        if (T + 1 <= 96)
+            hipLaunchKernelGGL(attn_prefill_kernel<3>, dim3((items + 3) / 4), dim3(256), 0, st, qkv, d->ukv_out, LD, l * 2 * D,
+                               attention_mask, d->tf_att, S, d->H, T);
+        else
+            hipLaunchKernelGGL(attn_prefill_kernel<8>, dim3((items + 3) / 4), dim3(256), 0, st, qkv, d->ukv_out, LD, l * 2 * D,
+                               attention_mask, d->tf_att, S, d->H, T);
+        RGRG_LAUNCH_CHECK();
+        if ((rc = tr_gemm(d, d->tf_att, w.attn_proj.w, w.attn_proj.b, xs(2 * l), xs(2 * l + 1), M, D, D, D))) return rc;
+        hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, xs(2 * l + 1), nullptr, nullptr, 1, 0, w.ln2_g, w.ln2_b, d->tf_xn, D);
+        RGRG_LAUNCH_CHECK();
+        if ((rc = tr_gemm(d, d->tf_xn, w.c_fc.w, w.c_fc.b, nullptr, ffpre, M, 4 * D, D, 4 * D))) return rc;
+        if ((rc = launch_gelu_apply(ffpre, d->tr_ff, (size_t)M * 4 * D, st))) return rc;
+        if ((rc = tr_gemm(d, d->tr_ff, w.mlp_proj.w, w.mlp_proj.b, xs(2 * l + 1), xs(2 * l + 2), M, D, 4 * D, D))) return rc;
+        hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, xs(2 * l + 2), nullptr, nullptr, 1, 0, ng, nb, d->tf_xn, D);
+        RGRG_LAUNCH_CHECK();
+    }
+    // ---------------- lm_head + loss + d(logits) + d(ln_f output), chunk by chunk (the logits never exist as a whole)
+    hipLaunchKernelGGL(ce_valid_kernel, dim3((M + 255) / 256), dim3(256), 0, st, attention_mask, T, M, d->tf_row_loss, d->tf_row_valid);
+    RGRG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, d->tf_row_loss, d->tf_row_valid, M, (float*)nullptr, d->tr_count);
+    RGRG_LAUNCH_CHECK();
+    for (int r0 = 0; r0 < M; r0 += TF_LOGIT_ROWS) {
+        const int rows = (M - r0 < TF_LOGIT_ROWS) ? M - r0 : TF_LOGIT_ROWS;
+        if ((rc = tr_gemm(d, d->tf_xn + (size_t)r0 * D, d->lm_head.w, nullptr, nullptr, d->tr_logits, rows, V, D, VP))) return rc;
+        hipLaunchKernelGGL(ce_rows_kernel, dim3(rows), dim3(256), 0, st, d->tr_logits, (size_t)VP, V, r0, ids, attention_mask, T,
+                           d->tf_row_loss, d->tf_row_valid, d->tr_row_lse);
+        RGRG_LAUNCH_CHECK();
+        if ((rc = launch_ce_backward(d->tr_logits, (size_t)VP, V, r0, rows, ids, d->tf_row_valid, d->tr_row_lse, d->tr_count,
+                                     loss_scale, st)))
+            return rc;
+        if ((rc = tr_gemm(d, d->tr_logits, d->lm_head.wT, nullptr, nullptr, d->tr_dxn + (size_t)r0 * D, rows, D, VP, D))) return rc;
+    }
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, d->tf_row_loss, d->tf_row_valid, M, loss_out, (int*)nullptr);
+    RGRG_LAUNCH_CHECK();
+    // ---------------- backward through ln_f and the 24 frozen blocks (activation gradients only)
+    if ((rc = launch_ln_backward(d->tr_dxn, xs(2 * L), d->lnf_g, d->tr_dx, M, D, 0, st))) return rc;
+    for (int l = L - 1; l >= 0; --l) {
+        const LayerW& w = d->layers[l];
+        float* qkv = d->tr_qkv + (size_t)l * M * 3 * D;
+        float* ffpre = d->tr_ffpre + (size_t)l * M * 4 * D;
+        // x_out = x_mid + mlp_proj(gelu(c_fc(ln_2(x_mid))))
+        if ((rc = tr_gemm(d, d->tr_dx, w.mlp_proj.wT, nullptr, nullptr, d->tr_dbig, M, 4 * D, D, 4 * D))) return rc;
+        if ((rc = launch_gelu_backward(d->tr_dbig, ffpre, (size_t)M * 4 * D, st))) return rc;
+        if ((rc = tr_gemm(d, d->tr_dbig, w.c_fc.wT, nullptr, nullptr, d->tr_dxn, M, D, 4 * D, D))) return rc;
+        if ((rc = launch_ln_backward(d->tr_dxn, xs(2 * l + 1), w.ln2_g, d->tr_dx, M, D, 1, st))) return rc;
+        // x_mid = x_in + attn_proj(attention(c_attn(ln_1(x_in)), uk(img), uv(img)))
+        if ((rc = tr_gemm(d, d->tr_dx, w.attn_proj.wT, nullptr, nullptr, d->tf_att, M, D, D, D))) return rc;
+        if ((rc = launch_attn_backward(qkv, d->ukv_out, LD, l * 2 * D, attention_mask, d->tf_att, d->tr_dbig, d->tr_dukv, S, d->H, T, st)))
+            return rc;
+        if ((rc = tr_gemm(d, d->tr_dbig, w.c_attn.wT, nullptr, nullptr, d->tr_dxn, M, D, 3 * D, D))) return rc;
+        if ((rc = launch_ln_backward(d->tr_dxn, xs(2 * l), w.ln1_g, d->tr_dx, M, D, 1, st))) return rc;
+    }
+    // ---------------- uk / uv of every layer (one stacked Linear) and feature_space_transformation_nn
+    if ((rc = launch_colsum(d->tr_dukv, grad_ukv_b, S, LD, st))) return rc;
+    if ((rc = tr_gemm(d, d->tr_dukv, d->ukv.wT, nullptr, nullptr, d->tr_dimg, S, D, LD, D))) return rc;
+    if ((rc = launch_transpose_pad(d->tr_dukv, d->tr_t1, S, LD, Sp, st))) return rc;
+    if ((rc = launch_transpose_pad(d->img, d->tr_t2, S, D, Sp, st))) return rc;
+    if ((rc = tr_gemm(d, d->tr_t1, d->tr_t2, nullptr, nullptr, grad_ukv_w, LD, D, Sp, D))) return rc;
+    if ((rc = launch_colsum(d->tr_dimg, grad_fst2_b, S, D, st))) return rc;
+    if ((rc = launch_transpose_pad(d->tr_dimg, d->tr_t1, S, D, Sp, st))) return rc;
+    if ((rc = launch_transpose_pad(d->h1, d->tr_t2, S, D, Sp, st))) return rc;
+    if ((rc = tr_gemm(d, d->tr_t1, d->tr_t2, nullptr, nullptr, grad_fst2_w, D, D, Sp, D))) return rc;
+    if ((rc = tr_gemm(d, d->tr_dimg, d->fst2.wT, nullptr, nullptr, d->tr_dh1, S, D, D, D))) return rc;
+    if ((rc = launch_relu_backward(d->tr_dh1, d->h1, (size_t)S * D, st))) return rc;
+    if ((rc = launch_colsum(d->tr_dh1, grad_fst0_b, S, D, st))) return rc;
+    if ((rc = launch_transpose_pad(d->tr_dh1, d->tr_t1, S, D, Sp, st))) return rc;
+    if ((rc = launch_transpose_pad(d->feats, d->tr_t2, S, D, Sp, st))) return rc;
+    if ((rc = tr_gemm(d, d->tr_t1, d->tr_t2, nullptr, nullptr, grad_fst0_w, D, D, Sp, D))) return rc;
+    RGRG_HIP(hipEventRecord(d->ev_in, st));
+    RGRG_HIP(hipStreamWaitEvent(caller, d->ev_in, 0));
+    return RGRG_OK;
+}
+
+extern "C" int rgrg_decoder_refresh_trainable(rgrg_decoder* d, void* stream) {
+    RGRG_CHECK_ARG(d);
+    hipStream_t caller = as_stream(stream), st = d->stream;
+    RGRG_HIP(hipEventRecord(d->ev_in, caller));
+    RGRG_HIP(hipStreamWaitEvent(st, d->ev_in, 0));
+    Lin* ls[] = {&d->fst0, &d->fst2, &d->ukv};
+    for (Lin* l : ls) {
+        if (l->packed) {
+            if (l->ntile == 32)
+                hipLaunchKernelGGL(pack_weights_kernel, dim3(2048), dim3(256), 0, st, l->w, l->packed, l->N, l->K, l->NT);
+            else
+                hipLaunchKernelGGL(pack_weights16_kernel, dim3(2048), dim3(256), 0, st, l->w, l->packed, l->N, l->K, l->NT);
+            RGRG_LAUNCH_CHECK();
+        }
+        if (l->wT) {
+            int rc = launch_transpose_pad(l->w, l->wT, l->N, l->K, pad32(l->N), st);
+            if (rc) return rc;
+        }
+    }
     RGRG_HIP(hipEventRecord(d->ev_in, st));
     RGRG_HIP(hipStreamWaitEvent(caller, d->ev_in, 0));
     return RGRG_OK;

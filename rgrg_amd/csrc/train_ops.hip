@@ -1,0 +1,356 @@
+// Backward kernels of the teacher-forced language-model pass (the gradients of
+// LanguageModel.forward(return_loss=True), src/language_model/language_model.py:258-399, w.r.t. what the reference
+// trains in the decoder: uk / uv of every GPT2PseudoAttention (:50-57,:145-150) and feature_space_transformation_nn
+// (:230-236); every other GPT-2 tensor is frozen (:207-213, Conv1DWithTrainedWeights :11-29), so only activation
+// gradients flow through it).  The GEMMs of the backward pass reuse gemm_f32.hip on transposed weight copies; this
+// file holds the element-wise / row-wise / attention parts.  Launchers are called from decoder.hip.
+#include "common.h"
+
+namespace rgrg {
+
+constexpr float LN_EPS_T = 1e-5f;
+
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// ff = gelu_new(pre)   (NewGELUActivation; the training pass keeps the pre-activation for the backward)
+__global__ __launch_bounds__(256) void gelu_apply_kernel(const float* __restrict__ pre, float* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(pre)[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = gelu_new(v[e]);
+        reinterpret_cast<f32x4*>(out)[i] = o;
+    }
+}
+
+// d *= gelu_new'(pre):  0.5 (1 + tanh u) + 0.5 x (1 - tanh^2 u) sqrt(2/pi) (1 + 3 * 0.044715 x^2)
+__global__ __launch_bounds__(256) void gelu_backward_kernel(float* __restrict__ d, const float* __restrict__ pre, size_t n4) {
+    const float k = 0.7978845608028654f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 x = reinterpret_cast<const f32x4*>(pre)[i];
+        f32x4 g = reinterpret_cast<f32x4*>(d)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float th = tanhf(k * (x[e] + 0.044715f * x[e] * x[e] * x[e]));
+            g[e] *= 0.5f * (1.0f + th) + 0.5f * x[e] * (1.0f - th * th) * k * (1.0f + 3.0f * 0.044715f * x[e] * x[e]);
+        }
+        reinterpret_cast<f32x4*>(d)[i] = g;
+    }
+}
+
+// d *= (h > 0)   (ReLU of feature_space_transformation_nn; h is the post-ReLU activation)
+__global__ __launch_bounds__(256) void relu_backward_kernel(float* __restrict__ d, const float* __restrict__ h, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        if (!(h[i] > 0.f)) d[i] = 0.f;
+}
+
+// LayerNorm backward w.r.t. its input (weight / bias are frozen): one workgroup per row, D == 1024.
+//   xhat = (x - mean) rstd ; t = dy * g ; dx = rstd (t - mean(t) - xhat mean(t xhat)) ; out = (acc ? out : 0) + dx
+__global__ __launch_bounds__(256) void ln_backward_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ g, float* __restrict__ out, int D,
+                                                          int accumulate) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const f32x4 v = reinterpret_cast<const f32x4*>(x + (size_t)row * D)[tid];
+    const float mean = block_sum256((v[0] + v[1]) + (v[2] + v[3]), sh) / (float)D;
+    f32x4 c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c[e] = v[e] - mean;
+    const float var = block_sum256((c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]), sh) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + LN_EPS_T);
+    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[tid];
+    const f32x4 dd = reinterpret_cast<const f32x4*>(dy + (size_t)row * D)[tid];
+    f32x4 t, xh;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { t[e] = dd[e] * gg[e]; xh[e] = c[e] * rstd; }
+    const float m1 = block_sum256((t[0] + t[1]) + (t[2] + t[3]), sh) / (float)D;
+    const float m2 = block_sum256((t[0] * xh[0] + t[1] * xh[1]) + (t[2] * xh[2] + t[3] * xh[3]), sh) / (float)D;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (accumulate) o = reinterpret_cast<const f32x4*>(out + (size_t)row * D)[tid];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] += rstd * (t[e] - m1 - xh[e] * m2);
+    reinterpret_cast<f32x4*>(out + (size_t)row * D)[tid] = o;
+}
+
+// d logits of CrossEntropyLoss(ignore_index=-100, mean) in place on a chunk of logits rows:
+//   scored row: (softmax - onehot(label)) * scale / n_scored ; other rows (and the padding columns) : 0
+__global__ __launch_bounds__(256) void ce_backward_kernel(float* __restrict__ logits, size_t ld, int V, int row0,
+                                                          const long long* __restrict__ ids, const int* __restrict__ row_valid,
+                                                          const float* __restrict__ row_lse, const int* __restrict__ n_scored,
+                                                          float scale) {
+    const int r = row0 + blockIdx.x;
+    float* x = logits + (size_t)blockIdx.x * ld;
+    if (!row_valid[r]) {
+        for (int i = threadIdx.x; i < V; i += 256) x[i] = 0.f;
+        return;
+    }
+    const float lse = row_lse[r], f = scale / (float)(*n_scored);
+    const int label = (int)ids[r + 1];
+    for (int i = threadIdx.x; i < V; i += 256) x[i] = (expf(x[i] - lse) - (i == label ? 1.f : 0.f)) * f;
+}
+
+// dst[c][r] = src[r][c] for r < R, 0 for R <= r < Rp   (K-padding of a transposed GEMM operand)
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc,
+                                                            int Rp) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx: column block of src, by: row block of src
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int r = by + j, c = bx + tx;
+        tile[j][tx] = (r < R && c < Cc) ? src[(size_t)r * Cc + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = bx + j, r = by + tx;
+        if (c < Cc && r < Rp) dst[(size_t)c * Rp + r] = tile[tx][j];
+    }
+}
+
+// out[c] = sum_r src[r][c]  (bias gradients), rows added in index order
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ src, float* __restrict__ out, int R, int Cc) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Cc) return;
+    float a = 0.f;
+    for (int r = 0; r < R; ++r) a += src[(size_t)r * Cc + c];
+    out[c] = a;
+}
+
+// Backward of the pseudo self-attention of one layer (GPT2PseudoAttention._attn, :84-122, without cache).
+// One workgroup per (sequence, head).  K and V (image slot first) live in LDS; queries are processed in blocks of 32:
+//   phase 1 (a wave per query, a lane per key): recompute P, dP = dO . V, dS = P (dP - sum P dP), dS = 0 on the future
+//            (constant -1e4) branch, scaled by 1/8; P and dS of the block go to LDS;
+//   phase 2 (a lane per dim): dQ = dS K for the block's queries; every wave owns the keys c = wave (mod 4) and adds
+//            dK_c += dS[:,c] Q, dV_c += P[:,c] dO into registers.
+// The image key/value gradients (c == 0) are written to d_ukv, the token ones to d_qkv.
+constexpr int AB_QB = 32;    // queries per block
+constexpr int AB_KMAX = 48;  // keys per wave: T + 1 <= 4 * AB_KMAX
+__global__ __launch_bounds__(256) void attn_backward_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
+                                                            int kcol, const float* __restrict__ am, const float* __restrict__ d_att,
+                                                            float* __restrict__ d_qkv, float* __restrict__ d_ukv, int H, int T) {
+    extern __shared__ __attribute__((aligned(16))) float ab_sm[];
+    const int NK = T + 1, D = H * 64;
+    float* Ks = ab_sm;                  // [NK][65]
+    float* Vs = Ks + NK * 65;           // [NK][65]
+    float* Qb = Vs + NK * 65;           // [32][64]
+    float* dOb = Qb + AB_QB * 64;       // [32][64]
+    float* Pm = dOb + AB_QB * 64;       // [32][NK]
+    float* dSm = Pm + AB_QB * NK;       // [32][NK]
+    float* addm = dSm + AB_QB * NK;     // [NK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x / H, hd = blockIdx.x - s * H;
+    for (int idx = tid; idx < NK * 64; idx += 256) {
+        const int c = idx >> 6, e = idx & 63;
+        float k, v;
+        if (c == 0) {
+            k = ukv[(size_t)s * ld_ukv + kcol + hd * 64 + e];
+            v = ukv[(size_t)s * ld_ukv + kcol + D + hd * 64 + e];
+        } else {
+            const float* r = qkv + ((size_t)s * T + c - 1) * 3 * D + hd * 64 + e;
+            k = r[D];
+            v = r[2 * D];
+        }
+        Ks[c * 65 + e] = k;
+        Vs[c * 65 + e] = v;
+    }
+    for (int c = tid; c < NK; c += 256) addm[c] = (c == 0 || !am) ? 0.f : (1.0f - am[(size_t)s * T + c - 1]) * -10000.0f;
+    float dKa[AB_KMAX], dVa[AB_KMAX];
+#pragma unroll
+    for (int k = 0; k < AB_KMAX; ++k) { dKa[k] = 0.f; dVa[k] = 0.f; }
+    for (int i0 = 0; i0 < T; i0 += AB_QB) {
+        __syncthreads();  // previous block fully consumed (also orders the K/V fill before the first block)
+        for (int idx = tid; idx < AB_QB * 64; idx += 256) {
+            const int j = idx >> 6, e = idx & 63, i = i0 + j;
+            float q = 0.f, g = 0.f;
+            if (i < T) {
+                q = qkv[((size_t)s * T + i) * 3 * D + hd * 64 + e];
+                g = d_att[((size_t)s * T + i) * D + hd * 64 + e];
+            }
+            Qb[idx] = q;
+            dOb[idx] = g;
+        }
+        __syncthreads();
+        // phase 1
+        for (int j = wave; j < AB_QB; j += 4) {
+            const int i = i0 + j;
+            if (i >= T) break;
+            float w[3], dp[3];
+            bool allowed[3];
+            float m = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int c = lane + 64 * u;
+                w[u] = -INFINITY;
+                dp[u] = 0.f;
+                allowed[u] = false;
+                if (c < NK) {
+                    float dot = 0.f, dv = 0.f;
+#pragma unroll 16
+                    for (int e = 0; e < 64; ++e) {
+                        dot += Qb[j * 64 + e] * Ks[c * 65 + e];
+                        dv += dOb[j * 64 + e] * Vs[c * 65 + e];
+                    }
+                    allowed[u] = (c == 0) || (c - 1 <= i);
+                    w[u] = (allowed[u] ? dot / 8.0f : -1e4f) + addm[c];
+                    dp[u] = dv;
+                    m = fmaxf(m, w[u]);
+                }
+            }
+            m = wave_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (lane + 64 * u < NK) { w[u] = expf(w[u] - m); sum += w[u]; }
+            sum = wave_sum(sum);
+            float delta = 0.f;
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (lane + 64 * u < NK) { w[u] = w[u] / sum; delta += w[u] * dp[u]; }
+            delta = wave_sum(delta);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int c = lane + 64 * u;
+                if (c < NK) {
+                    Pm[j * NK + c] = w[u];
+                    dSm[j * NK + c] = allowed[u] ? w[u] * (dp[u] - delta) / 8.0f : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        // phase 2a: dQ of the block's queries (lane = dim)
+        for (int j = wave; j < AB_QB; j += 4) {
+            const int i = i0 + j;
+            if (i >= T) break;
+            float acc = 0.f;
+            for (int c = 0; c < NK; ++c) acc += dSm[j * NK + c] * Ks[c * 65 + lane];
+            d_qkv[((size_t)s * T + i) * 3 * D + hd * 64 + lane] = acc;
+        }
+        // phase 2b: dK / dV of this wave's keys
+        const int jn = min(AB_QB, T - i0);
+#pragma unroll 1
+        for (int j = 0; j < jn; ++j) {
+            const float q = Qb[j * 64 + lane], g = dOb[j * 64 + lane];
+            const float* dsr = dSm + j * NK + wave;
+            const float* pr = Pm + j * NK + wave;
+#pragma unroll
+            for (int k = 0; k < AB_KMAX; ++k) {
+                if (wave + 4 * k < NK) {  // wave-uniform
+                    dKa[k] += dsr[4 * k] * q;
+                    dVa[k] += pr[4 * k] * g;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < AB_KMAX; ++k) {
+        const int c = wave + 4 * k;
+        if (c < NK) {
+            if (c == 0) {
+                d_ukv[(size_t)s * ld_ukv + kcol + hd * 64 + lane] = dKa[k];
+                d_ukv[(size_t)s * ld_ukv + kcol + D + hd * 64 + lane] = dVa[k];
+            } else {
+                float* r = d_qkv + ((size_t)s * T + c - 1) * 3 * D + hd * 64 + lane;
+                r[D] = dKa[k];
+                r[2 * D] = dVa[k];
+            }
+        }
+    }
+}
+
+// AdamW (torch.optim.AdamW semantics, decoupled weight decay): one element per thread
+//   p *= 1 - lr wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr / (1-b1^t) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2_sqrt, float grad_scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i] * grad_scale;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        pi -= (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        p[i] = pi;
+    }
+}
+
+// ------------------------------------------------------------------ launchers (decoder.hip)
+static int blocks_for(size_t n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
+
+int launch_gelu_apply(const float* pre, float* out, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(gelu_apply_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, st, pre, out, n / 4);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+int launch_gelu_backward(float* d, const float* pre, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(gelu_backward_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, st, d, pre, n / 4);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+int launch_relu_backward(float* d, const float* h, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(relu_backward_kernel, dim3(blocks_for(n)), dim3(256), 0, st, d, h, n);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+int launch_ln_backward(const float* dy, const float* x, const float* g, float* out, int rows, int D, int accumulate, hipStream_t st) {
+    RGRG_CHECK_ARG(D == 1024 && rows > 0);
+    hipLaunchKernelGGL(ln_backward_kernel, dim3(rows), dim3(256), 0, st, dy, x, g, out, D, accumulate);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+int launch_ce_backward(float* logits, size_t ld, int V, int row0, int rows, const long long* ids, const int* row_valid,
+                       const float* row_lse, const int* n_scored, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(ce_backward_kernel, dim3(rows), dim3(256), 0, st, logits, ld, V, row0, ids, row_valid, row_lse, n_scored, scale);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+int launch_transpose_pad(const float* src, float* dst, int R, int Cc, int Rp, hipStream_t st) {
+    RGRG_CHECK_ARG(R > 0 && Cc > 0 && Rp >= R);
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((Cc + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, src, dst, R, Cc, Rp);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+int launch_colsum(const float* src, float* out, int R, int Cc, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((Cc + 255) / 256), dim3(256), 0, st, src, out, R, Cc);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+int attn_backward_max_t() { return 4 * AB_KMAX - 1 < 160 ? 4 * AB_KMAX - 1 : 160; }
+int launch_attn_backward(const float* qkv, const float* ukv, int ld_ukv, int kcol, const float* am, const float* d_att, float* d_qkv,
+                         float* d_ukv, int S, int H, int T, hipStream_t st) {
+    RGRG_CHECK_ARG(T >= 1 && T <= attn_backward_max_t());
+    const int NK = T + 1;
+    const size_t lds = ((size_t)NK * 65 * 2 + 2 * AB_QB * 64 + 2 * (size_t)AB_QB * NK + NK) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_backward_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    RGRG_CHECK_ARG(lds <= 160 * 1024);
+    hipLaunchKernelGGL(attn_backward_kernel, dim3(S * H), dim3(256), lds, st, qkv, ukv, ld_ukv, kcol, am, d_att, d_qkv, d_ukv, H, T);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+}  // namespace rgrg
+
+using namespace rgrg;
+
+extern "C" int rgrg_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                   void* stream) {
+    RGRG_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1 && lr >= 0.f);
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks_for((size_t)n)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq,
+                       (size_t)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}

@@ -190,9 +190,10 @@ class HipEngine:
         dw.vocab = wte.shape[0]
         dw.wte = wte.data_ptr()
         dw.lnf_g, dw.lnf_b = K(sd[g + "ln_f.weight"]).data_ptr(), K(sd[g + "ln_f.bias"]).data_ptr()
-        dw.fst0_w, dw.fst0_b = K(sd[f + "0.weight"]).data_ptr(), K(sd[f + "0.bias"]).data_ptr()
-        dw.fst2_w, dw.fst2_b = K(sd[f + "2.weight"]).data_ptr(), K(sd[f + "2.bias"]).data_ptr()
-        dw.ukv_w, dw.ukv_b = K(torch.cat(uk, 0)).data_ptr(), K(torch.cat(ub, 0)).data_ptr()
+        self._ukv_w, self._ukv_b = K(torch.cat(uk, 0)), K(torch.cat(ub, 0))  # [uk_0; uv_0; uk_1; ...] stacked Linear
+        self._fst = [K(sd[f + "0.weight"]), K(sd[f + "0.bias"]), K(sd[f + "2.weight"]), K(sd[f + "2.bias"])]
+        dw.fst0_w, dw.fst0_b, dw.fst2_w, dw.fst2_b = (t.data_ptr() for t in self._fst)
+        dw.ukv_w, dw.ukv_b = self._ukv_w.data_ptr(), self._ukv_b.data_ptr()
         dw.layers = layers
         self._dec_weights, self._dec_layers, self._dec_keep = dw, layers, keep
         self.vocab = dw.vocab
@@ -454,6 +455,53 @@ class HipEngine:
                                                     None if loss is None else _hip.ptr(loss), _stream()),
                    "rgrg_decoder_lm_forward")
         return logits, loss
+
+    def lm_loss_grad(self, feats: Tensor, input_ids: Tensor, attention_mask: Optional[Tensor], loss_scale: float = 1.0):
+        """Teacher-forced loss and its gradients w.r.t. the trainable decoder weights (rgrg_decoder_lm_loss_grad):
+        -> (loss, {"ukv_w" [L*2*1024,1024], "ukv_b", "fst0_w", "fst0_b", "fst2_w", "fst2_b"})."""
+        _require_gpu(feats.device)
+        S, T = input_ids.shape
+        if feats.shape[0] != S:
+            raise ValueError(f"image_hidden_states has {feats.shape[0]} rows, input_ids {S}")
+        if T > 160:
+            raise NotImplementedError("the HIP training pass supports sequences of up to 160 tokens")
+        lo, hi = int(input_ids.min().item()), int(input_ids.max().item())
+        if lo < 0 or hi >= self.vocab:
+            raise IndexError("index out of range in self")
+        dec = self._get_decoder(S, 2)
+        _hip.check(self.lib.rgrg_decoder_set_precision(dec, 0), "rgrg_decoder_set_precision")
+        feats = feats.detach().to(torch.float32).contiguous()
+        ids = input_ids.to(torch.int64).contiguous()
+        am = None if attention_mask is None else attention_mask.to(torch.float32).contiguous()
+        dev, LD = feats.device, self.n_layer * 2 * 1024
+        g = {"ukv_w": torch.empty((LD, 1024), dtype=torch.float32, device=dev), "ukv_b": torch.empty((LD,), dtype=torch.float32, device=dev),
+             "fst0_w": torch.empty((1024, 1024), dtype=torch.float32, device=dev), "fst0_b": torch.empty((1024,), dtype=torch.float32, device=dev),
+             "fst2_w": torch.empty((1024, 1024), dtype=torch.float32, device=dev), "fst2_b": torch.empty((1024,), dtype=torch.float32, device=dev)}
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _hip.check(self.lib.rgrg_decoder_lm_loss_grad(dec, _hip.ptr(feats), _hip.ptr(ids), None if am is None else _hip.ptr(am), S, T,
+                                                      float(loss_scale), _hip.ptr(loss), _hip.ptr(g["ukv_w"]), _hip.ptr(g["ukv_b"]),
+                                                      _hip.ptr(g["fst0_w"]), _hip.ptr(g["fst0_b"]), _hip.ptr(g["fst2_w"]),
+                                                      _hip.ptr(g["fst2_b"]), _stream()), "rgrg_decoder_lm_loss_grad")
+        return loss, g
+
+    def sync_trainable(self, state_dict: Dict[str, Tensor]) -> None:
+        """Copy the (optimizer-updated) trainable decoder parameters into the engine's buffers and rebuild the
+        kernel-side layouts derived from them."""
+        g = "language_model.gpt_with_lm_head.transformer."
+        f = "language_model.feature_space_transformation_nn."
+        D = 1024
+        with torch.no_grad():
+            for l in range(self.n_layer):
+                b = f"{g}h.{l}.attn."
+                self._ukv_w[(2 * l) * D:(2 * l + 1) * D].copy_(state_dict[b + "uk.weight"])
+                self._ukv_w[(2 * l + 1) * D:(2 * l + 2) * D].copy_(state_dict[b + "uv.weight"])
+                self._ukv_b[(2 * l) * D:(2 * l + 1) * D].copy_(state_dict[b + "uk.bias"])
+                self._ukv_b[(2 * l + 1) * D:(2 * l + 2) * D].copy_(state_dict[b + "uv.bias"])
+            for t, k in zip(self._fst, ("0.weight", "0.bias", "2.weight", "2.bias")):
+                if t.data_ptr() != state_dict[f + k].data_ptr():
+                    t.copy_(state_dict[f + k])
+        if self._decoder is not None:
+            _hip.check(self.lib.rgrg_decoder_refresh_trainable(self._decoder, _stream()), "rgrg_decoder_refresh_trainable")
 
     def last_logits(self, S: int) -> Tensor:
         dst = torch.empty((S, self.vocab), dtype=torch.float32, device=self.device)

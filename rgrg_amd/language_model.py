@@ -76,6 +76,27 @@ class GPT2LMHeadSkeleton(nn.Module):
         self.lm_head.weight = self.transformer.wte.weight  # tied
 
 
+class _TeacherForcedLoss(torch.autograd.Function):
+    """Bridges the HIP training pass into autograd: forward runs loss + gradients in one call
+    (rgrg_decoder_lm_loss_grad); backward hands the gradients of the 100 trainable tensors (uk/uv of every layer,
+    feature_space_transformation_nn) to autograd, scaled by the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, lm, input_ids, attention_mask, feats, *params):
+        loss, g = lm.engine().lm_loss_grad(feats, input_ids, attention_mask)
+        D, grads = 1024, []
+        for l in range(len(lm.gpt.h)):  # same order as LanguageModel.trainable_parameters()
+            grads += [g["ukv_w"][(2 * l) * D:(2 * l + 1) * D], g["ukv_b"][(2 * l) * D:(2 * l + 1) * D],
+                      g["ukv_w"][(2 * l + 1) * D:(2 * l + 2) * D], g["ukv_b"][(2 * l + 1) * D:(2 * l + 2) * D]]
+        grads += [g["fst0_w"], g["fst0_b"], g["fst2_w"], g["fst2_b"]]
+        ctx.grads = grads
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return (None, None, None, None) + tuple(g * grad_out for g in ctx.grads)
+
+
 class LanguageModel(EngineOwner):
     _engine_prefix = "language_model."
 
@@ -86,6 +107,11 @@ class LanguageModel(EngineOwner):
         self.gpt_with_lm_head = GPT2LMHeadSkeleton()
         for p in self.gpt_with_lm_head.parameters():
             p.requires_grad = False
+        # the reference freezes GPT-2 BEFORE it swaps in GPT2PseudoAttention (language_model.py:207-213, :50-57), so
+        # uk / uv (and feature_space_transformation_nn below) are the trainable decoder tensors
+        for b in self.gpt_with_lm_head.transformer.h:
+            for p in (b.attn.uk.weight, b.attn.uk.bias, b.attn.uv.weight, b.attn.uv.bias):
+                p.requires_grad = True
         # the same aliases the reference creates (language_model.py:215-227)
         self.gpt = self.gpt_with_lm_head.transformer
         self.lm_head = self.gpt_with_lm_head.lm_head
@@ -101,9 +127,8 @@ class LanguageModel(EngineOwner):
         ``return_loss=True`` -> the scalar language-modelling loss (float32 tensor).  Like the reference, the
         positions of ``input_ids`` whose ``attention_mask`` is 0 are overwritten with -100 IN PLACE (:371-374),
         and ``return_loss=False, use_cache=False`` returns None (:396-399).  The incremental
-        ``use_cache=True`` form belongs to the reference's own generate loop; here ``generate()`` owns the cache."""
-        if self.training:
-            raise NotImplementedError("rgrg_amd implements eval-mode forward (no dropout, no backward); training is SURVEY.md 8(f)")
+        ``use_cache=True`` form belongs to the reference's own generate loop; here ``generate()`` owns the cache.
+        In ``train()`` mode with gradients enabled the returned loss carries a ``grad_fn`` (HIP backward pass)."""
         if past_key_values is not None or use_cache:
             raise NotImplementedError("incremental forward(use_cache=True / past_key_values) is internal to generate() "
                                       "in the HIP path; call generate()")
@@ -115,10 +140,36 @@ class LanguageModel(EngineOwner):
             return None
         ids2 = input_ids.view(-1, input_ids.shape[-1])
         am2 = attention_mask.view(ids2.shape[0], -1)
-        low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
-        _, loss = self.engine().lm_forward(image_hidden_states, ids2, am2, want_logits=False, want_loss=True, bf16=bool(low))
+        if self.training and torch.is_grad_enabled():
+            # training pass: loss with a grad_fn; loss.backward() fills .grad of uk/uv/feature_space_transformation_nn
+            # (what the reference trains in the decoder).  fp32, no dropout.
+            self.sync_trainable_if_stale()
+            loss = _TeacherForcedLoss.apply(self, ids2, am2, image_hidden_states, *self.trainable_parameters())
+        else:
+            low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
+            _, loss = self.engine().lm_forward(image_hidden_states, ids2, am2, want_logits=False, want_loss=True, bf16=bool(low))
         ids2[~am2.to(torch.bool)] = -100  # the reference's in-place label write (labels IS input_ids)
         return loss
+
+    def trainable_parameters(self):
+        """uk/uv of every layer, then feature_space_transformation_nn: the language-model tensors the reference
+        leaves trainable (language_model.py:207-213 freezes the rest)."""
+        ps = []
+        for b in self.gpt.h:
+            ps += [b.attn.uk.weight, b.attn.uk.bias, b.attn.uv.weight, b.attn.uv.bias]
+        f = self.feature_space_transformation_nn
+        return ps + [f[0].weight, f[0].bias, f[2].weight, f[2].bias]
+
+    def sync_trainable_if_stale(self) -> None:
+        """Push optimizer-updated parameters into the engine (cheap version check: torch bumps ``_version`` on every
+        in-place update)."""
+        ver = tuple(p._version for p in self.trainable_parameters())
+        root = self._root()
+        eng_existed = root.__dict__.get("_engine") is not None
+        eng = self.engine()
+        if eng_existed and root.__dict__.get("_trainable_version") != ver:
+            eng.sync_trainable(root._full_state_dict())
+        root.__dict__["_trainable_version"] = ver
 
     @torch.no_grad()
     def teacher_forced_logits(self, input_ids: torch.LongTensor, attention_mask: torch.FloatTensor,

@@ -1,0 +1,51 @@
+"""AdamW on the HIP kernel ``rgrg_adamw_step_f32`` (torch.optim.AdamW semantics: decoupled weight decay, bias
+correction), the optimizer of ``src/full_model/train_full_model.py:409``.  Same constructor / ``step`` /
+``zero_grad`` / ``param_groups`` / ``state`` surface as ``torch.optim.AdamW`` (it IS a ``torch.optim.Optimizer``),
+so the reference's loop, LR scheduler and checkpoint code keep working; only fp32 CUDA parameters are supported.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _hip
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._lib = None
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        """``grad_scale`` multiplies every gradient inside the kernel (1 / AMP scale, 1 / accumulation steps)."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._lib is None:
+            self._lib = _hip.load()
+        stream = torch.cuda.current_stream().cuda_stream
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise _hip.RgrgHipError("rgrg_amd.optim.AdamW needs contiguous fp32 parameters on the GPU (no CPU fallback)")
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                _hip.check(self._lib.rgrg_adamw_step_f32(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                                         st["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]), float(b1),
+                                                         float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                                         int(st["step"]), float(grad_scale), stream), "rgrg_adamw_step_f32")
+                # the kernel wrote p behind torch's back: bump the version counter so that engines caching derived
+                # layouts (LanguageModel.sync_trainable_if_stale) and autograd's checks notice
+                torch._C._increment_version(p)
+        return loss

@@ -121,8 +121,8 @@ def test_no_cpu_fallback(model):
     with pytest.raises(_hip.RgrgHipError):
         model.language_model(ids, am, torch.zeros(2, 1024), return_loss=True)   # eval forward: HIP only as well
     model.language_model.train()
-    with pytest.raises(NotImplementedError, match="eval-mode"):
-        model.language_model(ids, am, torch.zeros(2, 1024), return_loss=True)
+    with pytest.raises(_hip.RgrgHipError):
+        model.language_model(ids, am, torch.zeros(2, 1024), return_loss=True)   # training pass: HIP only too
     model.language_model.eval()
 
 
