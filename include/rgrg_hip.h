@@ -203,6 +203,19 @@ int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, const int64_t
 /* After an optimizer step changed the trainable decoder weights IN PLACE (the fst0/fst2/ukv pointers given to
  * rgrg_decoder_create): rebuild the kernel-side copies derived from them (packed skinny layouts, transposes). */
 int rgrg_decoder_refresh_trainable(rgrg_decoder* d, void* stream);
+/* Building blocks of the two region classifiers' backward pass (the autograd of
+ * src/binary_classifier/binary_classifier_region_selection.py:32-44 and binary_classifier_region_abnormal.py:32-47
+ * inside train_full_model.py:208 `backward()`); the GEMMs are rgrg_linear_f32 on transposed operands.
+ *   rgrg_transpose_pad_f32: dst[c][r] = src[r][c], r < rows; 0 for rows <= r < rows_padded  (dst [cols, rows_padded])
+ *   rgrg_colsum_f32:        out[c] = sum_r src[r][c]                                      (bias gradients)
+ *   rgrg_relu_backward_f32: d[i] = 0 where h[i] <= 0                                      (h = post-ReLU activation)
+ *   rgrg_bce_with_logits_masked_backward_f32: d(mean BCEWithLogits(pos_weight) over mask != 0)/d logits * scale,
+ *                           written to dlogits[i*ld] (0 on unmasked rows) */
+int rgrg_transpose_pad_f32(const float* src, float* dst, int rows, int cols, int rows_padded, void* stream);
+int rgrg_colsum_f32(const float* src, float* out, int rows, int cols, void* stream);
+int rgrg_relu_backward_f32(float* d, const float* h, int64_t n, void* stream);
+int rgrg_bce_with_logits_masked_backward_f32(const float* logits, const uint8_t* mask, const uint8_t* target, float pos_weight,
+                                             int n, float scale, float* dlogits, int ld, void* stream);
 /* Replaces torch.optim.AdamW.step() for one parameter tensor (train_full_model.py:409, decoupled weight decay):
  *   p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
  * with g = grad * grad_scale (1/AMP-scale, 1/accumulation steps).  All arrays f32 [n]; step t >= 1. */

@@ -63,6 +63,40 @@ def forward_eval(sd: SD, images: Tensor, input_ids: Tensor, attention_mask: Tens
     return {}, loss_sel, loss_abn, lm_loss, detections, class_detected, selected_regions, predicted_abnormal
 
 
+def train_losses_and_grads(sd: SD, images: Tensor, input_ids: Tensor, attention_mask: Tensor, region_has_sentence: Tensor,
+                           region_is_abnormal: Tensor):
+    """Training branch of ReportGenerationModel.forward (report_generation_model.py:52-84,136-157) with the object
+    detector frozen (its inference branch provides the features; BASELINE configs[4]) and dropout off: the two
+    classifier losses over the detected regions, the LM loss over the regions that are detected AND have a sentence
+    (:170-194), and the gradients torch autograd gives for the classifiers and the decoder's trainable tensors.
+    Returns ((loss_sel, loss_abn, loss_lm), {key: grad})."""
+    from .language_model import lm_loss_and_grads
+    with torch.no_grad():
+        _, _detections, top_region_features, class_detected = object_detector_forward(sd, images)
+    grads, losses = {}, []
+    for name, target, pw in (("binary_classifier_region_selection", region_has_sentence, 2.2),
+                             ("binary_classifier_region_abnormal", region_is_abnormal, 6.0)):
+        c = name + ".classifier."
+        sd2 = dict(sd)
+        keys = [c + f"{i}.{wb}" for i in (0, 2, 4) for wb in ("weight", "bias")]
+        for k in keys:
+            sd2[k] = sd[k].detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            logits = _classifier_logits(sd2, c, top_region_features)
+            loss = F.binary_cross_entropy_with_logits(logits[class_detected], target[class_detected].float(),
+                                                      pos_weight=torch.tensor([pw]))
+            loss.backward()
+        losses.append(loss.detach())
+        grads.update({k: sd2[k].grad for k in keys})
+    valid = torch.logical_and(class_detected, region_has_sentence)
+    flat = valid.reshape(-1)
+    if int(flat.sum()) == 0:
+        return -1
+    lm_loss, lm_grads = lm_loss_and_grads(sd, input_ids[flat], attention_mask[flat], top_region_features[valid])
+    grads.update(lm_grads)
+    return (losses[0], losses[1], lm_loss), grads
+
+
 @torch.no_grad()
 def generate(sd: SD, images: Tensor, max_length: Optional[int] = None, return_intermediates: bool = False,
              num_beams: int = 1, early_stopping: bool = False):

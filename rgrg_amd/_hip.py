@@ -56,6 +56,10 @@ SIGNATURES = {
     "rgrg_decoder_lm_forward": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "rgrg_decoder_lm_loss_grad": (_i, [_p, _p, _p, _p, _i, _i, C.c_float, _p, _p, _p, _p, _p, _p, _p, _p]),
     "rgrg_decoder_refresh_trainable": (_i, [_p, _p]),
+    "rgrg_transpose_pad_f32": (_i, [_p, _p, _i, _i, _i, _p]),
+    "rgrg_colsum_f32": (_i, [_p, _p, _i, _i, _p]),
+    "rgrg_relu_backward_f32": (_i, [_p, _p, C.c_int64, _p]),
+    "rgrg_bce_with_logits_masked_backward_f32": (_i, [_p, _p, _p, C.c_float, _i, C.c_float, _p, _i, _p]),
     "rgrg_adamw_step_f32": (_i, [_p, _p, _p, _p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _p]),
     "rgrg_f32_to_bf16": (_i, [_p, _p, C.c_int64, _p]),
     "rgrg_linear_bf16w_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

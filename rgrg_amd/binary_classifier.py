@@ -3,8 +3,8 @@
 ``BinaryClassifierRegionSelection`` runs inside ``generate()``
 (binary_classifier_region_selection.py:24-68) and, with its loss, inside the eval-mode
 ``forward()``; ``BinaryClassifierRegionAbnormal`` runs in ``forward()`` only
-(report_generation_model.py:67-69,104-106).  Eval mode only: training needs backward
-(SURVEY.md 8(f)).
+(report_generation_model.py:67-69,104-106).  In ``train()`` mode both return only their loss, with a ``grad_fn``
+whose backward runs on the HIP kernels.
 """
 from __future__ import annotations
 
@@ -20,6 +20,30 @@ class _BCEWithLogitsLossHolder(nn.Module):
     def __init__(self, pos_weight: float):
         super().__init__()
         self.register_buffer("pos_weight", torch.tensor([pos_weight]))
+
+
+class _ClassifierLoss(torch.autograd.Function):
+    """Autograd bridge of a region classifier's training loss: forward runs the HIP forward + backward
+    (engine.classifier_loss_grad), backward hands the six parameter gradients to autograd."""
+
+    @staticmethod
+    def forward(ctx, owner, which, feats, mask, target, pos_weight, *params):
+        eng = owner.engine()
+        mlp = eng.sel if which == "selection" else eng.abn
+        if mlp is None:
+            raise RuntimeError(f"the loaded state dict has no binary_classifier_region_{which}.* weights")
+        x = feats.detach().reshape(-1, feats.shape[-1]).contiguous().to(torch.float32)
+        loss, _, grads = eng.classifier_loss_grad(mlp, x, mask, target, pos_weight)
+        ctx.grads = grads
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return (None,) * 6 + tuple(g * grad_out for g in ctx.grads)
+
+
+def _classifier_params(seq: nn.Sequential):
+    return [seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias, seq[4].weight, seq[4].bias]
 
 
 def _classifier() -> nn.Sequential:
@@ -40,7 +64,9 @@ class BinaryClassifierRegionSelection(EngineOwner):
         return_loss=True  -> (loss, selected_regions, selected_region_features), loss = BCEWithLogits(pos_weight
         2.2) over the detected regions against ``region_has_sentence``."""
         if self.training:
-            raise NotImplementedError("rgrg_amd implements eval mode; the training step is SURVEY.md 8(f)")
+            # training: only the loss is returned (:46-47); it carries a grad_fn for the six classifier tensors
+            return _ClassifierLoss.apply(self, "selection", top_region_features, class_detected, region_has_sentence,
+                                         float(self.loss_fn.pos_weight.item()), *_classifier_params(self.classifier))
         taps = {} if return_loss else None
         selected_regions, feats = self.engine().select(top_region_features, class_detected, taps)
         if not return_loss:
@@ -61,6 +87,7 @@ class BinaryClassifierRegionAbnormal(EngineOwner):
     def forward(self, top_region_features, class_detected, region_is_abnormal):
         """Eval mode (binary_classifier_region_abnormal.py:32-60): -> (loss, predicted_abnormal_regions bool [B,29])."""
         if self.training:
-            raise NotImplementedError("rgrg_amd implements eval mode; the training step is SURVEY.md 8(f)")
+            return _ClassifierLoss.apply(self, "abnormal", top_region_features, class_detected, region_is_abnormal,
+                                         float(self.loss_fn.pos_weight.item()), *_classifier_params(self.classifier))
         return self.engine().abnormal(top_region_features, class_detected, region_is_abnormal,
                                       float(self.loss_fn.pos_weight.item()))

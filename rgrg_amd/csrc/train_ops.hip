@@ -263,6 +263,33 @@ __global__ __launch_bounds__(256) void attn_backward_kernel(const float* __restr
     }
 }
 
+// d logits of BCEWithLogitsLoss(pos_weight) over the rows with mask != 0 (mean): ((1-y) - lw + lw sigmoid(x)) * scale / n,
+// lw = 1 + (w-1) y; other rows 0.  dlogits has row stride ld (K-padding of the next GEMM; only column 0 is written).
+__global__ __launch_bounds__(256) void bce_backward_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ mask,
+                                                           const unsigned char* __restrict__ target, float pos_weight, int n,
+                                                           float scale, float* __restrict__ dlogits, int ld) {
+    __shared__ int scnt[256];
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += 256) c += mask[i] ? 1 : 0;
+    scnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) scnt[threadIdx.x] += scnt[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float f = scale / (float)scnt[0];
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float g = 0.f;
+        if (mask[i]) {
+            const float x = logits[i], y = target[i] ? 1.f : 0.f;
+            const float lw = (pos_weight - 1.f) * y + 1.f;
+            const float sg = 1.0f / (1.0f + expf(-x));
+            g = ((1.f - y) - lw + lw * sg) * f;
+        }
+        dlogits[(size_t)i * ld] = g;
+    }
+}
+
 // AdamW (torch.optim.AdamW semantics, decoupled weight decay): one element per thread
 //   p *= 1 - lr wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr / (1-b1^t) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -342,6 +369,31 @@ int launch_attn_backward(const float* qkv, const float* ukv, int ld_ukv, int kco
 }  // namespace rgrg
 
 using namespace rgrg;
+
+extern "C" int rgrg_transpose_pad_f32(const float* src, float* dst, int rows, int cols, int rows_padded, void* stream) {
+    RGRG_CHECK_ARG(src && dst);
+    return launch_transpose_pad(src, dst, rows, cols, rows_padded, as_stream(stream));
+}
+
+extern "C" int rgrg_colsum_f32(const float* src, float* out, int rows, int cols, void* stream) {
+    RGRG_CHECK_ARG(src && out && rows > 0 && cols > 0);
+    return launch_colsum(src, out, rows, cols, as_stream(stream));
+}
+
+extern "C" int rgrg_relu_backward_f32(float* d, const float* h, int64_t n, void* stream) {
+    RGRG_CHECK_ARG(d && h && n > 0);
+    return launch_relu_backward(d, h, (size_t)n, as_stream(stream));
+}
+
+extern "C" int rgrg_bce_with_logits_masked_backward_f32(const float* logits, const uint8_t* mask, const uint8_t* target,
+                                                        float pos_weight, int n, float scale, float* dlogits, int ld,
+                                                        void* stream) {
+    RGRG_CHECK_ARG(logits && mask && target && dlogits && n > 0 && ld >= 1);
+    hipLaunchKernelGGL(bce_backward_kernel, dim3(1), dim3(256), 0, as_stream(stream), logits, mask, target, pos_weight, n, scale,
+                       dlogits, ld);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
 
 extern "C" int rgrg_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,

@@ -347,6 +347,46 @@ class HipEngine:
                                                             _hip.ptr(loss), _stream()), "rgrg_bce_with_logits_masked_f32")
         return loss
 
+    def _transpose_pad(self, x: Tensor, rows_padded: int) -> Tensor:
+        R, Cc = x.shape
+        out = torch.empty((Cc, rows_padded), dtype=torch.float32, device=x.device)
+        _hip.check(self.lib.rgrg_transpose_pad_f32(_hip.ptr(x), _hip.ptr(out), R, Cc, rows_padded, _stream()), "rgrg_transpose_pad_f32")
+        return out
+
+    def _colsum(self, x: Tensor) -> Tensor:
+        out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
+        _hip.check(self.lib.rgrg_colsum_f32(_hip.ptr(x), _hip.ptr(out), x.shape[0], x.shape[1], _stream()), "rgrg_colsum_f32")
+        return out
+
+    def classifier_loss_grad(self, mlp, x: Tensor, mask: Tensor, target: Tensor, pos_weight: float):
+        """Loss of one region classifier (1024-512-128-1 ReLU MLP + BCEWithLogits(pos_weight) over ``mask``) and its
+        gradients w.r.t. the six parameter tensors, all on the HIP kernels: -> (loss, logits, [dW0, db0, dW2, db2, dW4, db4])."""
+        n = x.shape[0]
+        npad = (n + 31) // 32 * 32
+        (W0, b0), (W2, b2), (W4, b4) = mlp
+        h1 = self.linear(x, W0, b0, act=_hip.ACT_RELU)
+        h2 = self.linear(h1, W2, b2, act=_hip.ACT_RELU)
+        logits = self.linear(h2, W4, b4).view(-1)
+        loss = self.bce_masked(logits, mask, target, pos_weight)
+        m = mask.reshape(-1).to(torch.uint8).contiguous()
+        t = target.reshape(-1).to(torch.uint8).contiguous()
+        dlog = torch.zeros((n, 32), dtype=torch.float32, device=x.device)  # column 0 = d logits, 31 columns of K padding
+        _hip.check(self.lib.rgrg_bce_with_logits_masked_backward_f32(_hip.ptr(logits), _hip.ptr(m), _hip.ptr(t), float(pos_weight), n,
+                                                                     1.0, _hip.ptr(dlog), 32, _stream()),
+                   "rgrg_bce_with_logits_masked_backward_f32")
+        dlogT = self._transpose_pad(dlog, npad)                       # [32, npad], row 0 = d logits
+        dW4 = self.linear(dlogT[:1].contiguous(), self._transpose_pad(h2, npad), None)          # [1,128]
+        db4 = self._colsum(dlog)[:1].contiguous()
+        dh2 = self.linear(dlog, self._transpose_pad(W4, 32), None)   # [n,128] = dlog W4
+        _hip.check(self.lib.rgrg_relu_backward_f32(_hip.ptr(dh2), _hip.ptr(h2), dh2.numel(), _stream()), "rgrg_relu_backward_f32")
+        dW2 = self.linear(self._transpose_pad(dh2, npad), self._transpose_pad(h1, npad), None)   # [128,512]
+        db2 = self._colsum(dh2)
+        dh1 = self.linear(dh2, self._transpose_pad(W2, W2.shape[0]), None)                        # [n,512] = dh2 W2
+        _hip.check(self.lib.rgrg_relu_backward_f32(_hip.ptr(dh1), _hip.ptr(h1), dh1.numel(), _stream()), "rgrg_relu_backward_f32")
+        dW0 = self.linear(self._transpose_pad(dh1, npad), self._transpose_pad(x, npad), None)    # [512,1024]
+        db0 = self._colsum(dh1)
+        return loss, logits, [dW0, db0, dW2, db2, dW4, db4]
+
     def abnormal(self, top_region_features: Tensor, class_detected: Tensor, region_is_abnormal: Tensor, pos_weight: float):
         """BinaryClassifierRegionAbnormal.forward, eval: -> (loss, predicted_abnormal_regions bool [B,29])."""
         if self.abn is None:

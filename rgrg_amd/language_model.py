@@ -146,6 +146,7 @@ class LanguageModel(EngineOwner):
             self.sync_trainable_if_stale()
             loss = _TeacherForcedLoss.apply(self, ids2, am2, image_hidden_states, *self.trainable_parameters())
         else:
+            self.sync_trainable_if_stale()
             low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
             _, loss = self.engine().lm_forward(image_hidden_states, ids2, am2, want_logits=False, want_loss=True, bf16=bool(low))
         ids2[~am2.to(torch.bool)] = -100  # the reference's in-place label write (labels IS input_ids)
@@ -184,6 +185,8 @@ class LanguageModel(EngineOwner):
                  early_stopping: bool = False) -> torch.LongTensor:
         """Same contract as language_model.py:401-479: int64 [S, L'] incl. the leading BOS."""
         # same mode table, exceptions and messages as the reference's generate() (language_model.py:422-479)
+        if image_hidden_states.is_cuda:
+            self.sync_trainable_if_stale()  # weights changed by an optimizer step since the engine packed them
         single_group = num_beam_groups == 1
         if num_beam_groups > num_beams:
             raise ValueError("'num_beam_groups' has to be smaller or equal to 'num_beams'")

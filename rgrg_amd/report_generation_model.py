@@ -101,12 +101,13 @@ class ReportGenerationModel(EngineOwner):
         language_model_loss, detections, class_detected, selected_regions, predicted_abnormal_regions)``, the
         7-tuple without the LM loss when ``pretrain_without_lm_model``, or ``-1`` when no region is selected (:136).
 
-        Not implemented: training mode (needs backward), and ``image_targets`` (the detector's validation
-        losses draw random anchor/proposal samples, torchvision ``BalancedPositiveNegativeSampler``): pass
-        ``image_targets=None`` and ``obj_detector_loss_dict`` is ``{}`` as in the reference's ``targets is None`` path
-        (object_detector.py:195-197)."""
+        Not implemented: ``image_targets`` in eval mode (the detector's validation losses draw random anchor/proposal
+        samples, torchvision ``BalancedPositiveNegativeSampler``): pass ``image_targets=None`` and
+        ``obj_detector_loss_dict`` is ``{}`` as in the reference's ``targets is None`` path (object_detector.py:195-197).
+        In ``train()`` mode see ``_forward_train`` (frozen detector)."""
         if self.training:
-            raise NotImplementedError("rgrg_amd implements eval-mode forward(); the training step is SURVEY.md 8(f)")
+            return self._forward_train(images, input_ids, attention_mask, region_has_sentence, region_is_abnormal, return_loss,
+                                       past_key_values, position_ids, use_cache)
         if image_targets is not None:
             raise NotImplementedError("detector validation losses (image_targets) are not implemented: pass image_targets=None")
         obj_detector_loss_dict, detections, top_region_features, class_detected = self.object_detector(images, None)
@@ -126,6 +127,43 @@ class ReportGenerationModel(EngineOwner):
                                                   past_key_values, position_ids, use_cache)
         return (obj_detector_loss_dict, classifier_loss_region_selection, classifier_loss_region_abnormal, language_model_loss,
                 detections, class_detected, selected_regions, predicted_abnormal_regions)
+
+    def _forward_train(self, images, input_ids, attention_mask, region_has_sentence, region_is_abnormal, return_loss,
+                       past_key_values, position_ids, use_cache):
+        """Training branch (report_generation_model.py:52-84,136-157) with the object detector FROZEN (BASELINE
+        configs[4]; the reference also fine-tunes it): the detector runs its inference branch, ``image_targets`` are
+        not used and ``obj_detector_loss_dict`` is ``{}``.  Returns ``(obj_detector_loss_dict,
+        classifier_loss_region_selection, classifier_loss_region_abnormal[, language_model_loss])`` - losses with a
+        ``grad_fn`` for the classifiers and for uk/uv/feature_space_transformation_nn - or ``-1`` (:136)."""
+        with torch.no_grad():
+            _detections, top_region_features, class_detected = self.engine().detect(images)
+        del images
+        classifier_loss_region_selection = self.binary_classifier_region_selection(
+            top_region_features, class_detected, return_loss=True, region_has_sentence=region_has_sentence)
+        classifier_loss_region_abnormal = self.binary_classifier_region_abnormal(top_region_features, class_detected,
+                                                                                 region_is_abnormal)
+        if self.pretrain_without_lm_model:
+            return {}, classifier_loss_region_selection, classifier_loss_region_abnormal
+        valid_input_ids, valid_attention_mask, valid_region_features = self.get_valid_decoder_input_for_training(
+            class_detected, region_has_sentence, input_ids, attention_mask, top_region_features)
+        if valid_input_ids.shape[0] == 0:
+            return -1
+        language_model_loss = self.language_model(valid_input_ids, valid_attention_mask, valid_region_features, return_loss,
+                                                  past_key_values, position_ids, use_cache)
+        return {}, classifier_loss_region_selection, classifier_loss_region_abnormal, language_model_loss
+
+    def get_valid_decoder_input_for_training(self, class_detected, region_has_sentence, input_ids, attention_mask, region_features):
+        """report_generation_model.py:170-194: regions that were detected AND have a ground-truth sentence."""
+        valid = torch.logical_and(class_detected, region_has_sentence)
+        flat = valid.reshape(-1)
+        return input_ids[flat], attention_mask[flat], region_features[valid]
+
+    def trainable_parameters(self):
+        """What a frozen-detector training run optimises: both region classifiers and the decoder's uk/uv/fst-nn
+        (53.66 M values)."""
+        return (list(self.binary_classifier_region_selection.classifier.parameters()) +
+                list(self.binary_classifier_region_abnormal.classifier.parameters()) +
+                self.language_model.trainable_parameters())
 
     def get_valid_decoder_input_for_evaluation(self, selected_regions, input_ids, attention_mask):
         """report_generation_model.py:196-210: rows of the (batch*29) sentences whose region was selected."""

@@ -81,3 +81,40 @@ def test_gather_with_an_empty_rank_and_all_empty():
     assert torch.equal(ids, i0) and int(sel[2:].sum()) == 0 and torch.equal(sel[:2], s0)
     assert torch.equal(cd[2:], c1) and torch.equal(boxes[2:], d1["top_region_boxes"])  # detections of the empty rank survive
     assert _run("all_empty") == -1
+
+
+# ------------------------------------------------------------------------- training: gradient all-reduce (gloo, world 2)
+def _grad_worker(rank, world, port, ret):
+    from rgrg_amd.dist import allreduce_gradients
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(7)
+        shapes = [(300, 40), (40,), (1000, 64), (64,), (5,)]
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+        for i, p in enumerate(params):
+            base = torch.randn(p.shape, generator=g)        # same stream on both ranks
+            p.grad = base * (rank + 1) if i != 3 else None   # a parameter without gradient is skipped
+        n = allreduce_gradients(params, bucket_bytes=100_000)  # 48 KB + 256 KB + ... -> several buckets
+        if rank == 0:
+            ret["buckets"] = n
+            ret["grads"] = [None if p.grad is None else p.grad.clone() for p in params]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_gradients_averages_over_ranks_in_buckets():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_grad_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["buckets"] >= 2
+    g = torch.Generator().manual_seed(7)
+    for i, s in enumerate([(300, 40), (40,), (1000, 64), (64,), (5,)]):
+        base = torch.randn(s, generator=g)
+        if i == 3:
+            assert ret["grads"][i] is None
+        else:
+            assert torch.allclose(ret["grads"][i], base * 1.5, atol=1e-6)   # (1 + 2) / 2

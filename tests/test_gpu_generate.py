@@ -496,3 +496,30 @@ def test_two_training_steps_follow_the_oracle():
     out = lm.generate(feats.to(DEV), max_length=8)
     assert torch.equal(out.cpu(), o_lm.greedy_generate(sd2, feats, 8))
     m.invalidate_engine()
+
+
+def test_full_training_forward_losses_and_gradients_vs_oracle():
+    """ReportGenerationModel.forward in train() mode (frozen detector): the 4-tuple of the reference's training branch,
+    losses and every trainable tensor's gradient against torch autograd through the oracle on the same images."""
+    from oracle import full_model as o_full
+    fx = load_golden("forward_eval_b2.pt")
+    images = torch.cat([synth.make_images(1, s) for s in fx["meta"]["image_seeds"]], 0)
+    i = fx["inputs"]
+    o_losses, o_grads = o_full.train_losses_and_grads(synth_sd("ragged"), images, i["input_ids"], i["attention_mask"],
+                                                      i["region_has_sentence"], i["region_is_abnormal"])
+    m = _lm_train_model()
+    m.train()
+    out = m(images.to(DEV), None, i["input_ids"].clone().to(DEV), i["attention_mask"].to(DEV), i["region_has_sentence"].to(DEV),
+            i["region_is_abnormal"].to(DEV))
+    assert len(out) == 4 and out[0] == {}
+    for got, ref, tol in zip(out[1:], o_losses, (1e-5, 1e-5, 2e-4)):
+        assert got.requires_grad and abs(got.item() - ref.item()) <= tol
+    total = 5.0 * out[1] + 5.0 * out[2] + 2.0 * out[3]   # train_full_model.py:196-204 loss weights of the shipped config
+    total.backward()
+    named = dict(m.named_parameters())
+    weight = {"binary_classifier_region_selection": 5.0, "binary_classifier_region_abnormal": 5.0, "language_model": 2.0}
+    worst = max(_rel(named[k].grad.cpu(), og * weight[k.split(".")[0]]) for k, og in o_grads.items())
+    assert worst <= 2e-3, worst
+    assert len(o_grads) == 112 and len(m.trainable_parameters()) == 112
+    assert all(p.grad is None for k, p in named.items() if k.startswith("object_detector."))  # frozen
+    m.invalidate_engine()
