@@ -1153,7 +1153,8 @@ struct Lin {
     const float* b = nullptr;  // [N]
     float* packed = nullptr;   // skinny layout
     void* wb = nullptr;        // bf16 copy of w (opt-in many-sequence path)
-    float* wT = nullptr;       // [K][Np] transposed copy, Np = N rounded up to 32 (backward pass: dX = dY W)
+    float* wT = nullptr;       // [K][Np] transposed copy, Np = N rounded up to 256 (backward pass: dX = dY W)
+    void* wTb = nullptr;       // bf16 copy of wT (training under autocast)
     int N = 0, K = 0, NT = 0, KS = 1, ntile = 32;
 };
 
@@ -1840,18 +1841,25 @@ int launch_attn_backward(const float* qkv, const float* ukv, int ld_ukv, int kco
                          float* d_ukv, int S, int H, int T, hipStream_t st);
 
 static int pad32(int n) { return (n + 31) / 32 * 32; }
+static int pad256(int n) { return (n + 255) / 256 * 256; }  // K granularity of the bf16 GEMM pipeline
 
 // transposed copies of the frozen weights the activation gradients flow through (made once)
 static int make_wT(rgrg_decoder* d, Lin& l) {
-    if (l.wT) return RGRG_OK;
-    const int Np = pad32(l.N);
-    int rc = dmalloc(d, (void**)&l.wT, (size_t)l.K * Np * sizeof(float), false);
-    if (rc) return rc;
-    return launch_transpose_pad(l.w, l.wT, l.N, l.K, Np, d->stream);
+    const int Np = pad256(l.N);
+    int rc;
+    if (!l.wT) {
+        if ((rc = dmalloc(d, (void**)&l.wT, (size_t)l.K * Np * sizeof(float), false))) return rc;
+        if ((rc = launch_transpose_pad(l.w, l.wT, l.N, l.K, Np, d->stream))) return rc;
+    }
+    if (d->bf16_gemms && !l.wTb) {
+        if ((rc = dmalloc(d, &l.wTb, (size_t)l.K * Np * 2, false))) return rc;
+        if ((rc = convert_f32_to_bf16(l.wT, l.wTb, (size_t)l.K * Np, d->stream))) return rc;
+    }
+    return RGRG_OK;
 }
 
 static int ensure_wT(rgrg_decoder* d) {
-    if (d->have_wT) return RGRG_OK;
+    if (d->have_wT && (!d->bf16_gemms || d->layers[0].c_attn.wTb)) return RGRG_OK;
     int rc;
     if ((rc = make_wT(d, d->lm_head)) || (rc = make_wT(d, d->ukv)) || (rc = make_wT(d, d->fst2))) return rc;
     for (auto& w : d->layers)
@@ -1874,7 +1882,7 @@ static int tr_reserve(rgrg_decoder* d, size_t rows, size_t seqs) {
     if (rows <= d->tr_rows && seqs <= d->tr_seqs) return RGRG_OK;
     tr_free(d);
     rows = rows > d->tr_rows ? rows : d->tr_rows;
-    const size_t D = (size_t)d->D, L = (size_t)d->n_layer, Sp = (size_t)pad32((int)seqs), VP = (size_t)pad32(d->V);
+    const size_t D = (size_t)d->D, L = (size_t)d->n_layer, Sp = (size_t)pad32((int)seqs), VP = (size_t)pad256(d->V);
     const size_t chunk = rows < (size_t)TF_LOGIT_ROWS ? rows : (size_t)TF_LOGIT_ROWS;
     RGRG_HIP(hipMalloc((void**)&d->tr_xs, (2 * L + 1) * rows * D * 4));
     RGRG_HIP(hipMalloc((void**)&d->tr_qkv, L * rows * 3 * D * 4));
@@ -1902,6 +1910,18 @@ static int tr_gemm(rgrg_decoder* d, const float* X, const float* W, const float*
                    int ldy, int act = RGRG_ACT_NONE) {
     return launch_gemm_dense(X, W, b, R, Y, M, N, K, ldy, act, d->tf_ws, d->tf_ws_floats, d->stream);
 }
+// frozen-weight GEMM of the training pass: forward (Y = X W^T + b) or activation gradient (Y = X W, on the transposed
+// copy); bf16 MFMA when the decoder is in bf16 mode (torch.autocast) and there are more than 128 token rows
+static int tr_lin(rgrg_decoder* d, const Lin& l, bool transposed, const float* X, const float* R, float* Y, int M, int ldy,
+                  int act = RGRG_ACT_NONE) {
+    const int N = transposed ? l.K : l.N, K = transposed ? pad256(l.N) : l.K;
+    const float* W = transposed ? l.wT : l.w;
+    const void* Wb = transposed ? l.wTb : l.wb;
+    const float* b = transposed ? nullptr : l.b;
+    if (d->bf16_gemms && Wb && K % 256 == 0 && M > skinny_max_rows())
+        return launch_gemm_bf16w(X, Wb, b, R, Y, M, N, K, ldy, act, d->stream);
+    return launch_gemm_dense(X, W, b, R, Y, M, N, K, ldy, act, d->tf_ws, d->tf_ws_floats, d->stream);
+}
 }  // namespace rgrg
 
 extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, const int64_t* input_ids,
@@ -1911,7 +1931,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
     RGRG_CHECK_ARG(d && feats && input_ids && loss_out && grad_ukv_w && grad_ukv_b && grad_fst0_w && grad_fst0_b && grad_fst2_w &&
                    grad_fst2_b);
     RGRG_CHECK_ARG(S > 0 && S <= d->max_seqs && T >= 2 && T <= attn_backward_max_t());
-    const int D = d->D, M = S * T, L = d->n_layer, V = d->V, VP = pad32(V), Sp = pad32(S), LD = d->ld_ukv;
+    const int D = d->D, M = S * T, L = d->n_layer, V = d->V, VP = pad256(V), Sp = pad32(S), LD = d->ld_ukv;
     int rc;
     if ((rc = tf_reserve(d, (size_t)M)) || (rc = tr_reserve(d, (size_t)M, (size_t)S))) return rc;
     hipStream_t caller = as_stream(stream), st = d->stream;
@@ -1937,7 +1957,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
         const float* nb = (l + 1 < L) ? d->layers[l + 1].ln1_b : d->lnf_b;
         float* qkv = d->tr_qkv + (size_t)l * M * 3 * D;
         float* ffpre = d->tr_ffpre + (size_t)l * M * 4 * D;
-        if ((rc = tr_gemm(d, d->tf_xn, w.c_attn.w, w.c_attn.b, nullptr, qkv, M, 3 * D, D, 3 * D))) return rc;
+        if ((rc = tr_lin(d, w.c_attn, false, d->tf_xn, nullptr, qkv, M, 3 * D))) return rc;
         if (T + 1 <= 96)
             hipLaunchKernelGGL(attn_prefill_kernel<3>, dim3((items + 3) / 4), dim3(256), 0, st, qkv, d->ukv_out, LD, l * 2 * D,
                                attention_mask, d->tf_att, S, d->H, T);
@@ -1945,12 +1965,12 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
             hipLaunchKernelGGL(attn_prefill_kernel<8>, dim3((items + 3) / 4), dim3(256), 0, st, qkv, d->ukv_out, LD, l * 2 * D,
                                attention_mask, d->tf_att, S, d->H, T);
         RGRG_LAUNCH_CHECK();
-        if ((rc = tr_gemm(d, d->tf_att, w.attn_proj.w, w.attn_proj.b, xs(2 * l), xs(2 * l + 1), M, D, D, D))) return rc;
+        if ((rc = tr_lin(d, w.attn_proj, false, d->tf_att, xs(2 * l), xs(2 * l + 1), M, D))) return rc;
         hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, xs(2 * l + 1), nullptr, nullptr, 1, 0, w.ln2_g, w.ln2_b, d->tf_xn, D);
         RGRG_LAUNCH_CHECK();
-        if ((rc = tr_gemm(d, d->tf_xn, w.c_fc.w, w.c_fc.b, nullptr, ffpre, M, 4 * D, D, 4 * D))) return rc;
+        if ((rc = tr_lin(d, w.c_fc, false, d->tf_xn, nullptr, ffpre, M, 4 * D))) return rc;
         if ((rc = launch_gelu_apply(ffpre, d->tr_ff, (size_t)M * 4 * D, st))) return rc;
-        if ((rc = tr_gemm(d, d->tr_ff, w.mlp_proj.w, w.mlp_proj.b, xs(2 * l + 1), xs(2 * l + 2), M, D, 4 * D, D))) return rc;
+        if ((rc = tr_lin(d, w.mlp_proj, false, d->tr_ff, xs(2 * l + 1), xs(2 * l + 2), M, D))) return rc;
         hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, xs(2 * l + 2), nullptr, nullptr, 1, 0, ng, nb, d->tf_xn, D);
         RGRG_LAUNCH_CHECK();
     }
@@ -1961,14 +1981,14 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
     RGRG_LAUNCH_CHECK();
     for (int r0 = 0; r0 < M; r0 += TF_LOGIT_ROWS) {
         const int rows = (M - r0 < TF_LOGIT_ROWS) ? M - r0 : TF_LOGIT_ROWS;
-        if ((rc = tr_gemm(d, d->tf_xn + (size_t)r0 * D, d->lm_head.w, nullptr, nullptr, d->tr_logits, rows, V, D, VP))) return rc;
+        if ((rc = tr_lin(d, d->lm_head, false, d->tf_xn + (size_t)r0 * D, nullptr, d->tr_logits, rows, VP))) return rc;
         hipLaunchKernelGGL(ce_rows_kernel, dim3(rows), dim3(256), 0, st, d->tr_logits, (size_t)VP, V, r0, ids, attention_mask, T,
                            d->tf_row_loss, d->tf_row_valid, d->tr_row_lse);
         RGRG_LAUNCH_CHECK();
         if ((rc = launch_ce_backward(d->tr_logits, (size_t)VP, V, r0, rows, ids, d->tf_row_valid, d->tr_row_lse, d->tr_count,
                                      loss_scale, st)))
             return rc;
-        if ((rc = tr_gemm(d, d->tr_logits, d->lm_head.wT, nullptr, nullptr, d->tr_dxn + (size_t)r0 * D, rows, D, VP, D))) return rc;
+        if ((rc = tr_lin(d, d->lm_head, true, d->tr_logits, nullptr, d->tr_dxn + (size_t)r0 * D, rows, D))) return rc;
     }
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, d->tf_row_loss, d->tf_row_valid, M, loss_out, (int*)nullptr);
     RGRG_LAUNCH_CHECK();
@@ -1979,20 +1999,20 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
         float* qkv = d->tr_qkv + (size_t)l * M * 3 * D;
         float* ffpre = d->tr_ffpre + (size_t)l * M * 4 * D;
         // x_out = x_mid + mlp_proj(gelu(c_fc(ln_2(x_mid))))
-        if ((rc = tr_gemm(d, d->tr_dx, w.mlp_proj.wT, nullptr, nullptr, d->tr_dbig, M, 4 * D, D, 4 * D))) return rc;
+        if ((rc = tr_lin(d, w.mlp_proj, true, d->tr_dx, nullptr, d->tr_dbig, M, 4 * D))) return rc;
         if ((rc = launch_gelu_backward(d->tr_dbig, ffpre, (size_t)M * 4 * D, st))) return rc;
-        if ((rc = tr_gemm(d, d->tr_dbig, w.c_fc.wT, nullptr, nullptr, d->tr_dxn, M, D, 4 * D, D))) return rc;
+        if ((rc = tr_lin(d, w.c_fc, true, d->tr_dbig, nullptr, d->tr_dxn, M, D))) return rc;
         if ((rc = launch_ln_backward(d->tr_dxn, xs(2 * l + 1), w.ln2_g, d->tr_dx, M, D, 1, st))) return rc;
         // x_mid = x_in + attn_proj(attention(c_attn(ln_1(x_in)), uk(img), uv(img)))
-        if ((rc = tr_gemm(d, d->tr_dx, w.attn_proj.wT, nullptr, nullptr, d->tf_att, M, D, D, D))) return rc;
+        if ((rc = tr_lin(d, w.attn_proj, true, d->tr_dx, nullptr, d->tf_att, M, D))) return rc;
         if ((rc = launch_attn_backward(qkv, d->ukv_out, LD, l * 2 * D, attention_mask, d->tf_att, d->tr_dbig, d->tr_dukv, S, d->H, T, st)))
             return rc;
-        if ((rc = tr_gemm(d, d->tr_dbig, w.c_attn.wT, nullptr, nullptr, d->tr_dxn, M, D, 3 * D, D))) return rc;
+        if ((rc = tr_lin(d, w.c_attn, true, d->tr_dbig, nullptr, d->tr_dxn, M, D))) return rc;
         if ((rc = launch_ln_backward(d->tr_dxn, xs(2 * l), w.ln1_g, d->tr_dx, M, D, 1, st))) return rc;
     }
     // ---------------- uk / uv of every layer (one stacked Linear) and feature_space_transformation_nn
     if ((rc = launch_colsum(d->tr_dukv, grad_ukv_b, S, LD, st))) return rc;
-    if ((rc = tr_gemm(d, d->tr_dukv, d->ukv.wT, nullptr, nullptr, d->tr_dimg, S, D, LD, D))) return rc;
+    if ((rc = tr_gemm(d, d->tr_dukv, d->ukv.wT, nullptr, nullptr, d->tr_dimg, S, D, pad256(LD), D))) return rc;
     if ((rc = launch_transpose_pad(d->tr_dukv, d->tr_t1, S, LD, Sp, st))) return rc;
     if ((rc = launch_transpose_pad(d->img, d->tr_t2, S, D, Sp, st))) return rc;
     if ((rc = tr_gemm(d, d->tr_t1, d->tr_t2, nullptr, nullptr, grad_ukv_w, LD, D, Sp, D))) return rc;
@@ -2000,7 +2020,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
     if ((rc = launch_transpose_pad(d->tr_dimg, d->tr_t1, S, D, Sp, st))) return rc;
     if ((rc = launch_transpose_pad(d->h1, d->tr_t2, S, D, Sp, st))) return rc;
     if ((rc = tr_gemm(d, d->tr_t1, d->tr_t2, nullptr, nullptr, grad_fst2_w, D, D, Sp, D))) return rc;
-    if ((rc = tr_gemm(d, d->tr_dimg, d->fst2.wT, nullptr, nullptr, d->tr_dh1, S, D, D, D))) return rc;
+    if ((rc = tr_gemm(d, d->tr_dimg, d->fst2.wT, nullptr, nullptr, d->tr_dh1, S, D, pad256(D), D))) return rc;
     if ((rc = launch_relu_backward(d->tr_dh1, d->h1, (size_t)S * D, st))) return rc;
     if ((rc = launch_colsum(d->tr_dh1, grad_fst0_b, S, D, st))) return rc;
     if ((rc = launch_transpose_pad(d->tr_dh1, d->tr_t1, S, D, Sp, st))) return rc;
@@ -2026,7 +2046,7 @@ extern "C" int rgrg_decoder_refresh_trainable(rgrg_decoder* d, void* stream) {
             RGRG_LAUNCH_CHECK();
         }
         if (l->wT) {
-            int rc = launch_transpose_pad(l->w, l->wT, l->N, l->K, pad32(l->N), st);
+            int rc = launch_transpose_pad(l->w, l->wT, l->N, l->K, pad256(l->N), st);
             if (rc) return rc;
         }
     }

@@ -496,9 +496,12 @@ class HipEngine:
                    "rgrg_decoder_lm_forward")
         return logits, loss
 
-    def lm_loss_grad(self, feats: Tensor, input_ids: Tensor, attention_mask: Optional[Tensor], loss_scale: float = 1.0):
+    def lm_loss_grad(self, feats: Tensor, input_ids: Tensor, attention_mask: Optional[Tensor], loss_scale: float = 1.0,
+                     bf16: bool = False):
         """Teacher-forced loss and its gradients w.r.t. the trainable decoder weights (rgrg_decoder_lm_loss_grad):
-        -> (loss, {"ukv_w" [L*2*1024,1024], "ukv_b", "fst0_w", "fst0_b", "fst2_w", "fst2_b"})."""
+        -> (loss, {"ukv_w" [L*2*1024,1024], "ukv_b", "fst0_w", "fst0_b", "fst2_w", "fst2_b"}).  bf16=True (torch.autocast,
+        as the reference's training loop uses): the frozen-weight GEMMs of forward and backward run on the bf16 MFMA
+        when there are more than 128 token rows; LayerNorm, softmax, cross entropy and the weight gradients stay fp32."""
         _require_gpu(feats.device)
         S, T = input_ids.shape
         if feats.shape[0] != S:
@@ -509,7 +512,7 @@ class HipEngine:
         if lo < 0 or hi >= self.vocab:
             raise IndexError("index out of range in self")
         dec = self._get_decoder(S, 2)
-        _hip.check(self.lib.rgrg_decoder_set_precision(dec, 0), "rgrg_decoder_set_precision")
+        _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")
         feats = feats.detach().to(torch.float32).contiguous()
         ids = input_ids.to(torch.int64).contiguous()
         am = None if attention_mask is None else attention_mask.to(torch.float32).contiguous()

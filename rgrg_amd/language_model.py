@@ -83,7 +83,8 @@ class _TeacherForcedLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, lm, input_ids, attention_mask, feats, *params):
-        loss, g = lm.engine().lm_loss_grad(feats, input_ids, attention_mask)
+        low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
+        loss, g = lm.engine().lm_loss_grad(feats, input_ids, attention_mask, bf16=bool(low))
         D, grads = 1024, []
         for l in range(len(lm.gpt.h)):  # same order as LanguageModel.trainable_parameters()
             grads += [g["ukv_w"][(2 * l) * D:(2 * l + 1) * D], g["ukv_b"][(2 * l) * D:(2 * l + 1) * D],

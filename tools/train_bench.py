@@ -30,22 +30,27 @@ opt = optim.AdamW(m.trainable_parameters(), lr=5e-5)
 FWD_FLOP_PER_TOKEN = 2 * 353.453e6  # SURVEY 8(d); the backward here is activation gradients only (~1x forward)
 
 
-def step():
+def step(low):
     opt.zero_grad()
-    out = m(images, None, ids.clone(), am, has, abn)
+    if low:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = m(images, None, ids.clone(), am, has, abn)
+    else:
+        out = m(images, None, ids.clone(), am, has, abn)
     total = 5.0 * out[1] + 5.0 * out[2] + 2.0 * out[3]
     total.backward()
     opt.step()
     return [o.item() for o in out[1:]]
 
 
-losses = step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(STEPS):
-    losses = step()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / STEPS
-tok = S * T
-print(f"train step B={B} S={S} T={T}: {dt * 1e3:.1f} ms/step = {B / dt:.1f} images/s = {tok / dt / 1e3:.1f} k tokens/s; "
-      f"decoder fwd+bwd GEMM work {2 * tok * FWD_FLOP_PER_TOKEN / dt / 1e12:.1f} TFLOP/s (fp32); losses {losses}", flush=True)
+for name, low in (("fp32", False), ("bf16 autocast", True)):
+    losses = step(low)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(STEPS):
+        losses = step(low)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / STEPS
+    tok = S * T
+    print(f"train step [{name}] B={B} S={S} T={T}: {dt * 1e3:.1f} ms/step = {B / dt:.1f} images/s = {tok / dt / 1e3:.1f} k tokens/s; "
+          f"decoder fwd+bwd GEMM work {2 * tok * FWD_FLOP_PER_TOKEN / dt / 1e12:.1f} TFLOP/s; losses {losses}", flush=True)
