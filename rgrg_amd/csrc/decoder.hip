@@ -975,7 +975,7 @@ constexpr int TF_MAX_T = 255;
 template <int NT>  // key tiles held in registers: T + 1 <= 32 * NT
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
                                                            int kcol, const float* __restrict__ am, float* __restrict__ out,
-                                                           int S, int H, int T) {
+                                                           int S, int H, int T, float* __restrict__ lse) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int QT = (T + 31) / 32;
     const int item = blockIdx.x * 4 + wave;
@@ -1047,6 +1047,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
         }
     }
     sum += __shfl_xor(sum, 32, 64);
+    if (lse && half == 0 && iq < T) lse[((size_t)s * T + iq) * H + hd] = m + logf(sum);  // kept for the backward pass
     // O^T = V^T P^T : A = V[key(j, half)][dim = lane&31 (+32)], B = register j of the tile
     f32x16 o0, o1;
 #pragma unroll
@@ -1204,7 +1205,7 @@ struct rgrg_decoder {
     // training pass (rgrg_decoder_lm_loss_grad): saved activations and gradient work space, grown on demand
     float *tr_xs = nullptr, *tr_qkv = nullptr, *tr_ffpre = nullptr, *tr_ff = nullptr, *tr_dx = nullptr, *tr_dbig = nullptr,
           *tr_dxn = nullptr, *tr_logits = nullptr, *tr_dukv = nullptr, *tr_t1 = nullptr, *tr_t2 = nullptr, *tr_dimg = nullptr,
-          *tr_dh1 = nullptr, *tr_row_lse = nullptr;
+          *tr_dh1 = nullptr, *tr_row_lse = nullptr, *tr_att = nullptr, *tr_lse = nullptr, *tr_delta = nullptr;
     int* tr_count = nullptr;
     size_t tr_rows = 0, tr_seqs = 0;
     bool have_wT = false;
@@ -1790,10 +1791,10 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
             const int items = S * d->H * ((T + 31) / 32);
             if (T + 1 <= 96)
                 hipLaunchKernelGGL(attn_prefill_kernel<3>, dim3((items + 3) / 4), dim3(256), 0, st, d->tf_qkv, d->ukv_out, d->ld_ukv,
-                                   l * 2 * D, attention_mask, d->tf_att, S, d->H, T);
+                                   l * 2 * D, attention_mask, d->tf_att, S, d->H, T, (float*)nullptr);
             else
                 hipLaunchKernelGGL(attn_prefill_kernel<8>, dim3((items + 3) / 4), dim3(256), 0, st, d->tf_qkv, d->ukv_out, d->ld_ukv,
-                                   l * 2 * D, attention_mask, d->tf_att, S, d->H, T);
+                                   l * 2 * D, attention_mask, d->tf_att, S, d->H, T, (float*)nullptr);
             RGRG_LAUNCH_CHECK();
         }
         if ((rc = tf_linear(d, w.attn_proj, d->tf_att, d->tf_x, d->tf_x, M, D, RGRG_ACT_NONE))) return rc;
@@ -1837,8 +1838,9 @@ int launch_ce_backward(float* logits, size_t ld, int V, int row0, int rows, cons
 int launch_transpose_pad(const float* src, float* dst, int R, int Cc, int Rp, hipStream_t st);
 int launch_colsum(const float* src, float* out, int R, int Cc, hipStream_t st);
 int attn_backward_max_t();
-int launch_attn_backward(const float* qkv, const float* ukv, int ld_ukv, int kcol, const float* am, const float* d_att, float* d_qkv,
-                         float* d_ukv, int S, int H, int T, hipStream_t st);
+int launch_attn_backward(const float* qkv, const float* ukv, int ld_ukv, int kcol, const float* am, const float* d_att,
+                         const float* att, const float* lse, float* delta, float* d_qkv, float* d_ukv, int S, int H, int T,
+                         hipStream_t st);
 
 static int pad32(int n) { return (n + 31) / 32 * 32; }
 static int pad256(int n) { return (n + 255) / 256 * 256; }  // K granularity of the bf16 GEMM pipeline
@@ -1871,7 +1873,7 @@ static int ensure_wT(rgrg_decoder* d) {
 
 static void tr_free(rgrg_decoder* d) {
     float** fs[] = {&d->tr_xs, &d->tr_qkv, &d->tr_ffpre, &d->tr_ff, &d->tr_dx, &d->tr_dbig, &d->tr_dxn, &d->tr_logits,
-                    &d->tr_dukv, &d->tr_t1, &d->tr_t2, &d->tr_dimg, &d->tr_dh1, &d->tr_row_lse};
+                    &d->tr_dukv, &d->tr_t1, &d->tr_t2, &d->tr_dimg, &d->tr_dh1, &d->tr_row_lse, &d->tr_att, &d->tr_lse, &d->tr_delta};
     for (float** f : fs) { if (*f) (void)hipFree(*f); *f = nullptr; }
     if (d->tr_count) (void)hipFree(d->tr_count);
     d->tr_count = nullptr;
@@ -1899,6 +1901,9 @@ static int tr_reserve(rgrg_decoder* d, size_t rows, size_t seqs) {
     RGRG_HIP(hipMalloc((void**)&d->tr_dimg, seqs * D * 4));
     RGRG_HIP(hipMalloc((void**)&d->tr_dh1, seqs * D * 4));
     RGRG_HIP(hipMalloc((void**)&d->tr_row_lse, rows * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_att, L * rows * D * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_lse, L * rows * (size_t)d->H * 4));
+    RGRG_HIP(hipMalloc((void**)&d->tr_delta, rows * (size_t)d->H * 4));
     RGRG_HIP(hipMalloc((void**)&d->tr_count, 4));
     d->tr_rows = rows;
     d->tr_seqs = seqs;
@@ -1958,14 +1963,16 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
         float* qkv = d->tr_qkv + (size_t)l * M * 3 * D;
         float* ffpre = d->tr_ffpre + (size_t)l * M * 4 * D;
         if ((rc = tr_lin(d, w.c_attn, false, d->tf_xn, nullptr, qkv, M, 3 * D))) return rc;
+        float* att = d->tr_att + (size_t)l * MD;              // attention output and row log-sum-exp, kept per layer
+        float* lse = d->tr_lse + (size_t)l * M * d->H;
         if (T + 1 <= 96)
             hipLaunchKernelGGL(attn_prefill_kernel<3>, dim3((items + 3) / 4), dim3(256), 0, st, qkv, d->ukv_out, LD, l * 2 * D,
-                               attention_mask, d->tf_att, S, d->H, T);
+                               attention_mask, att, S, d->H, T, lse);
         else
             hipLaunchKernelGGL(attn_prefill_kernel<8>, dim3((items + 3) / 4), dim3(256), 0, st, qkv, d->ukv_out, LD, l * 2 * D,
-                               attention_mask, d->tf_att, S, d->H, T);
+                               attention_mask, att, S, d->H, T, lse);
         RGRG_LAUNCH_CHECK();
-        if ((rc = tr_lin(d, w.attn_proj, false, d->tf_att, xs(2 * l), xs(2 * l + 1), M, D))) return rc;
+        if ((rc = tr_lin(d, w.attn_proj, false, att, xs(2 * l), xs(2 * l + 1), M, D))) return rc;
         hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, xs(2 * l + 1), nullptr, nullptr, 1, 0, w.ln2_g, w.ln2_b, d->tf_xn, D);
         RGRG_LAUNCH_CHECK();
         if ((rc = tr_lin(d, w.c_fc, false, d->tf_xn, nullptr, ffpre, M, 4 * D))) return rc;
@@ -2005,7 +2012,8 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
         if ((rc = launch_ln_backward(d->tr_dxn, xs(2 * l + 1), w.ln2_g, d->tr_dx, M, D, 1, st))) return rc;
         // x_mid = x_in + attn_proj(attention(c_attn(ln_1(x_in)), uk(img), uv(img)))
         if ((rc = tr_lin(d, w.attn_proj, true, d->tr_dx, nullptr, d->tf_att, M, D))) return rc;
-        if ((rc = launch_attn_backward(qkv, d->ukv_out, LD, l * 2 * D, attention_mask, d->tf_att, d->tr_dbig, d->tr_dukv, S, d->H, T, st)))
+        if ((rc = launch_attn_backward(qkv, d->ukv_out, LD, l * 2 * D, attention_mask, d->tf_att, d->tr_att + (size_t)l * MD,
+                                       d->tr_lse + (size_t)l * M * d->H, d->tr_delta, d->tr_dbig, d->tr_dukv, S, d->H, T, st)))
             return rc;
         if ((rc = tr_lin(d, w.c_attn, true, d->tr_dbig, nullptr, d->tr_dxn, M, D))) return rc;
         if ((rc = launch_ln_backward(d->tr_dxn, xs(2 * l), w.ln1_g, d->tr_dx, M, D, 1, st))) return rc;

@@ -263,6 +263,219 @@ __global__ __launch_bounds__(256) void attn_backward_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------- attention backward on the fp32 matrix core
+// Same register-only structure as attn_prefill_kernel (decoder.hip).  The forward pass kept, per (token, head), the
+// row log-sum-exp; delta = rowsum(dO . O) (= sum_keys P dP) comes from attn_delta_kernel.  Two kernels, no atomics:
+//   dQ : one wave per (sequence, head, 32-query tile), TRANSPOSED tiles S^T = K Q^T and dP^T = V dO^T (a lane = one
+//        query), dS^T registers are the B operand of dQ^T = K^T dS^T;
+//   dK, dV : one wave per (sequence, head, 32-key tile) looping over the query tiles that can see it, UNTRANSPOSED
+//        tiles S = Q K^T and dP = dO V^T (a lane = one key), P / dS registers are the B operand of
+//        dV^T = dO^T P and dK^T = Q^T dS.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O,
+                                                         float* __restrict__ delta, int D, int H) {
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const f32x4 a = reinterpret_cast<const f32x4*>(dO + (size_t)row * D)[tid];
+    const f32x4 b = reinterpret_cast<const f32x4*>(O + (size_t)row * D)[tid];
+    float v = (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    if ((tid & 15) == 0) delta[(size_t)row * H + (tid >> 4)] = v;  // 16 threads x 4 floats = one 64-wide head
+}
+
+__device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+template <int NT>  // key tiles: T + 1 <= 32 * NT
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
+                                                          int kcol, const float* __restrict__ am, const float* __restrict__ d_att,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          float* __restrict__ d_qkv, int S, int H, int T) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int QT = (T + 31) / 32;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= S * H * QT) return;
+    const int qt = item % QT, sh = item / QT, hd = sh % H, s = sh / H;
+    const int NK = T + 1, D = H * 64;
+    const int col = lane & 31, half = lane >> 5;
+    const int iq = qt * 32 + col, iqc = min(iq, T - 1);
+    const int need = min(NK - 1, qt * 32 + 32) / 32 + 1;
+    auto krow = [&](int c) -> const float* {
+        c = min(c, NK - 1);
+        return c == 0 ? ukv + (size_t)s * ld_ukv + kcol + hd * 64 : qkv + ((size_t)s * T + c - 1) * 3 * D + D + hd * 64;
+    };
+    f32x4 qf[8], gf[8];
+    {
+        const float* qp = qkv + ((size_t)s * T + iqc) * 3 * D + hd * 64 + half * 32;
+        const float* gp = d_att + ((size_t)s * T + iqc) * D + hd * 64 + half * 32;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            qf[u] = *reinterpret_cast<const f32x4*>(qp + 4 * u);
+            gf[u] = *reinterpret_cast<const f32x4*>(gp + 4 * u);
+        }
+    }
+    const float lse_q = lse[((size_t)s * T + iqc) * H + hd], delta_q = delta[((size_t)s * T + iqc) * H + hd];
+    f32x16 ds[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        if (kt < need) {
+            f32x4 kf[8], vf[8];
+            const float* kp = krow(kt * 32 + col) + half * 32;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                kf[u] = *reinterpret_cast<const f32x4*>(kp + 4 * u);
+                vf[u] = *reinterpret_cast<const f32x4*>(kp + D + 4 * u);
+            }
+            f32x16 aS, aP;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { aS[r] = 0.f; aP[r] = 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    aS = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u][e], qf[u][e], aS, 0, 0, 0);
+                    aP = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[u][e], gf[u][e], aP, 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = kt * 32 + mfma_row(r, half);
+                float dsv = 0.f;
+                if (c < NK) {
+                    const bool allowed = (c == 0) || (c - 1 <= iq);
+                    const float addm = (c == 0 || !am) ? 0.f : (1.0f - am[(size_t)s * T + c - 1]) * -10000.0f;
+                    const float pr = expf((allowed ? aS[r] / 8.0f : -1e4f) + addm - lse_q);
+                    dsv = allowed ? pr * (aP[r] - delta_q) / 8.0f : 0.f;
+                }
+                ds[kt][r] = dsv;
+            }
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        if (kt < need) {
+            float k0[16], k1[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float* kp = krow(kt * 32 + mfma_row(j, half));
+                k0[j] = kp[col];
+                k1[j] = kp[32 + col];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[j], ds[kt][j], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[j], ds[kt][j], o1, 0, 0, 0);
+            }
+        }
+    }
+    if (iq < T) {
+        float* op = d_qkv + ((size_t)s * T + iq) * 3 * D + hd * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            op[mfma_row(r, half)] = o0[r];
+            op[32 + mfma_row(r, half)] = o1[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
+                                                           int kcol, const float* __restrict__ am, const float* __restrict__ d_att,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           float* __restrict__ d_qkv, float* __restrict__ d_ukv, int S, int H, int T) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int NK = T + 1, D = H * 64;
+    const int KT = (NK + 31) / 32, QT = (T + 31) / 32;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= S * H * KT) return;
+    const int kt = item % KT, sh = item / KT, hd = sh % H, s = sh / H;
+    const int col = lane & 31, half = lane >> 5;
+    const int c = kt * 32 + col, cc = min(c, NK - 1);  // this lane's key (column of S)
+    const bool cvalid = c < NK;
+    const float* kp = (cc == 0 ? ukv + (size_t)s * ld_ukv + kcol + hd * 64 : qkv + ((size_t)s * T + cc - 1) * 3 * D + D + hd * 64) + half * 32;
+    f32x4 kf[8], vf[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        kf[u] = *reinterpret_cast<const f32x4*>(kp + 4 * u);
+        vf[u] = *reinterpret_cast<const f32x4*>(kp + D + 4 * u);
+    }
+    const float addm = (cc == 0 || !am) ? 0.f : (1.0f - am[(size_t)s * T + cc - 1]) * -10000.0f;
+    f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+    const int qt0 = kt == 0 ? 0 : kt - 1;  // first query tile with a query i >= (first key of the tile) - 1
+    for (int qt = qt0; qt < QT; ++qt) {
+        f32x4 qf[8], gf[8];
+        {
+            const int i = min(qt * 32 + col, T - 1);
+            const float* qp = qkv + ((size_t)s * T + i) * 3 * D + hd * 64 + half * 32;
+            const float* gp = d_att + ((size_t)s * T + i) * D + hd * 64 + half * 32;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                qf[u] = *reinterpret_cast<const f32x4*>(qp + 4 * u);
+                gf[u] = *reinterpret_cast<const f32x4*>(gp + 4 * u);
+            }
+        }
+        f32x16 aS, aP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { aS[r] = 0.f; aP[r] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                aS = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[u][e], kf[u][e], aS, 0, 0, 0);
+                aP = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[u][e], vf[u][e], aP, 0, 0, 0);
+            }
+        float a_q0[16], a_q1[16], a_g0[16], a_g1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = qt * 32 + mfma_row(r, half), ic = min(i, T - 1);
+            float pr = 0.f, dsv = 0.f;
+            if (i < T && cvalid) {
+                const float lse_i = lse[((size_t)s * T + i) * H + hd], delta_i = delta[((size_t)s * T + i) * H + hd];
+                const bool allowed = (c == 0) || (c - 1 <= i);
+                pr = expf((allowed ? aS[r] / 8.0f : -1e4f) + addm - lse_i);
+                dsv = allowed ? pr * (aP[r] - delta_i) / 8.0f : 0.f;
+            }
+            aS[r] = pr;   // P   [query r][key col]
+            aP[r] = dsv;  // dS
+            const float* qp = qkv + ((size_t)s * T + ic) * 3 * D + hd * 64;
+            const float* gp = d_att + ((size_t)s * T + ic) * D + hd * 64;
+            a_q0[r] = qp[col]; a_q1[r] = qp[32 + col];
+            a_g0[r] = gp[col]; a_g1[r] = gp[32 + col];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_g0[j], aS[j], dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_g1[j], aS[j], dv1, 0, 0, 0);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_q0[j], aP[j], dk0, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_q1[j], aP[j], dk1, 0, 0, 0);
+        }
+    }
+    if (cvalid) {
+        float* kdst;
+        float* vdst;
+        if (c == 0) {
+            kdst = d_ukv + (size_t)s * ld_ukv + kcol + hd * 64;
+            vdst = kdst + D;
+        } else {
+            kdst = d_qkv + ((size_t)s * T + c - 1) * 3 * D + D + hd * 64;
+            vdst = kdst + D;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dim = mfma_row(r, half);
+            kdst[dim] = dk0[r];
+            kdst[32 + dim] = dk1[r];
+            vdst[dim] = dv0[r];
+            vdst[32 + dim] = dv1[r];
+        }
+    }
+}
+
 // d logits of BCEWithLogitsLoss(pos_weight) over the rows with mask != 0 (mean): ((1-y) - lw + lw sigmoid(x)) * scale / n,
 // lw = 1 + (w-1) y; other rows 0.  dlogits has row stride ld (K-padding of the next GEMM; only column 0 is written).
 __global__ __launch_bounds__(256) void bce_backward_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ mask,
@@ -349,10 +562,29 @@ int launch_colsum(const float* src, float* out, int R, int Cc, hipStream_t st) {
     return RGRG_OK;
 }
 int attn_backward_max_t() { return 4 * AB_KMAX - 1 < 160 ? 4 * AB_KMAX - 1 : 160; }
-int launch_attn_backward(const float* qkv, const float* ukv, int ld_ukv, int kcol, const float* am, const float* d_att, float* d_qkv,
-                         float* d_ukv, int S, int H, int T, hipStream_t st) {
+int launch_attn_backward(const float* qkv, const float* ukv, int ld_ukv, int kcol, const float* am, const float* d_att,
+                         const float* att, const float* lse, float* delta, float* d_qkv, float* d_ukv, int S, int H, int T,
+                         hipStream_t st) {
     RGRG_CHECK_ARG(T >= 1 && T <= attn_backward_max_t());
     const int NK = T + 1;
+    static const bool force_valu = [] { const char* e = getenv("RGRG_ATTN_BWD_VALU"); return e && atoi(e) != 0; }();
+    if (NK <= 160 && att && lse && delta && !force_valu) {
+        const int D = H * 64, M = S * T;
+        hipLaunchKernelGGL(attn_delta_kernel, dim3(M), dim3(256), 0, st, d_att, att, delta, D, H);
+        RGRG_LAUNCH_CHECK();
+        const int qitems = S * H * ((T + 31) / 32), kitems = S * H * ((NK + 31) / 32);
+        if (NK <= 96)
+            hipLaunchKernelGGL(attn_bwd_dq_kernel<3>, dim3((qitems + 3) / 4), dim3(256), 0, st, qkv, ukv, ld_ukv, kcol, am, d_att, lse,
+                               delta, d_qkv, S, H, T);
+        else
+            hipLaunchKernelGGL(attn_bwd_dq_kernel<5>, dim3((qitems + 3) / 4), dim3(256), 0, st, qkv, ukv, ld_ukv, kcol, am, d_att, lse,
+                               delta, d_qkv, S, H, T);
+        RGRG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((kitems + 3) / 4), dim3(256), 0, st, qkv, ukv, ld_ukv, kcol, am, d_att, lse, delta,
+                           d_qkv, d_ukv, S, H, T);
+        RGRG_LAUNCH_CHECK();
+        return RGRG_OK;
+    }
     const size_t lds = ((size_t)NK * 65 * 2 + 2 * AB_QB * 64 + 2 * (size_t)AB_QB * NK + NK) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {

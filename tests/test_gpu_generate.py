@@ -411,16 +411,19 @@ def test_lm_training_pass_gradients_match_reference_fixture():
     m.invalidate_engine()
 
 
-def test_lm_training_pass_vs_oracle_autograd_longer_sequences():
-    """T = 40 (two 32-query blocks in the attention backward, padding inside and across blocks), 9 sequences."""
+@pytest.mark.parametrize("S,T", [(9, 40), (2, 100), (1, 160), (3, 32)])
+def test_lm_training_pass_vs_oracle_autograd_longer_sequences(S, T):
+    """T = 40: two query / key tiles of the matrix-core attention backward with padding inside and across tiles;
+    T = 100: the 5-key-tile variant; T = 160: the LDS fallback (161 keys); T = 32: 33 keys = one key in the second tile."""
     m = _lm_train_model()
     lm = m.language_model
     lm.train()
-    g = torch.Generator().manual_seed(21)
-    S, T = 9, 40
+    g = torch.Generator().manual_seed(21 + T)
     ids = torch.randint(0, 50257, (S, T), generator=g)
     lens = torch.randint(2, T + 1, (S,), generator=g)
-    lens[0], lens[1] = T, 33
+    lens[0] = T
+    if S > 1:
+        lens[1] = min(T, 33)
     am = (torch.arange(T)[None, :] < lens[:, None]).to(torch.int64)
     feats = torch.randn((S, 1024), generator=g)
     o_loss, o_grads = o_lm.lm_loss_and_grads(synth_sd("ragged"), ids, am, feats)
