@@ -270,7 +270,15 @@ class HipEngine:
                                                    size, _stream()), "rgrg_rpn_proposals_f32")
         return props, counts, offsets
 
-    def roi_heads(self, feat: Tensor, props: Tensor, offsets: Tensor, taps: Optional[dict] = None):
+    def _fc6_bf16(self) -> Tensor:
+        """bf16 copy of the (K-permuted) fc6 weight, made on first use of the autocast path."""
+        if getattr(self, "fc6_wb", None) is None:
+            self.fc6_wb = torch.empty(self.fc6_w.shape, dtype=torch.int16, device=self.fc6_w.device)
+            _hip.check(self.lib.rgrg_f32_to_bf16(_hip.ptr(self.fc6_w), _hip.ptr(self.fc6_wb), self.fc6_w.numel(), _stream()),
+                       "rgrg_f32_to_bf16")
+        return self.fc6_wb
+
+    def roi_heads(self, feat: Tensor, props: Tensor, offsets: Tensor, taps: Optional[dict] = None, bf16: bool = False):
         B, FH, FW, Cf = feat.shape
         R = int(offsets[-1].item())  # host sync #1: number of RoIs sizes the box-head launches
         dev = feat.device
@@ -285,7 +293,15 @@ class HipEngine:
             _hip.check(self.lib.rgrg_roi_align_avgpool_f32(_hip.ptr(feat), _hip.ptr(props), _hip.ptr(offsets),
                                                            _hip.ptr(pooled_maps), _hip.ptr(pooled), B, FH, FW, Cf,
                                                            props.shape[1], R, scale, _stream()), "rgrg_roi_align")
-            h = self.linear(pooled_maps.view(R, 64 * Cf), self.fc6_w, self.fc6_b, _hip.ACT_RELU)
+            if bf16 and R > 128:
+                # torch.autocast in the reference runs box_head in half precision: fc6 (81 % of the detector's FLOPs,
+                # custom_roi_heads.py:235) on the bf16 MFMA, fp32 accumulate / bias / ReLU
+                h = torch.empty((R, self.fc6_w.shape[0]), dtype=torch.float32, device=dev)
+                _hip.check(self.lib.rgrg_linear_bf16w_f32(_hip.ptr(pooled_maps), _hip.ptr(self._fc6_bf16()), _hip.ptr(self.fc6_b), None,
+                                                          _hip.ptr(h), R, self.fc6_w.shape[0], 64 * Cf, self.fc6_w.shape[0],
+                                                          _hip.ACT_RELU, _stream()), "rgrg_linear_bf16w_f32")
+            else:
+                h = self.linear(pooled_maps.view(R, 64 * Cf), self.fc6_w, self.fc6_b, _hip.ACT_RELU)
             h = self.linear(h, self.fc7_w, self.fc7_b, _hip.ACT_RELU)
             pred = self.linear(h, self.pred_w, self.pred_b)  # [R,150]: 30 class logits | 120 deltas
             size = float(IMAGE_INPUT_SIZE)
@@ -319,13 +335,14 @@ class HipEngine:
                                                        _hip.ptr(pooled), B, FH, FW, Cf, maxn, R, scale, _stream()), "rgrg_roi_align")
         return maps, pooled
 
-    def detect(self, images: Tensor, taps: Optional[dict] = None):
-        """ObjectDetector.forward (inference): -> (detections, top_region_features, class_detected)."""
+    def detect(self, images: Tensor, taps: Optional[dict] = None, bf16: bool = False):
+        """ObjectDetector.forward (inference): -> (detections, top_region_features, class_detected).  bf16 (opt-in
+        through torch.autocast): fc6 on the bf16 MFMA; trunk, RPN, RoIAlign and the post-processing stay fp32."""
         _require_gpu(images.device)
         images = images.to(torch.float32)
         feat = self.backbone(images)
         props, counts, offsets = self.rpn(feat)
-        cd, scores, boxes, top = self.roi_heads(feat, props, offsets, taps)
+        cd, scores, boxes, top = self.roi_heads(feat, props, offsets, taps, bf16)
         if taps is not None:
             taps.update(features_nhwc=feat, proposals=props, counts=counts, offsets=offsets)
         return {"top_region_boxes": boxes, "top_scores": scores}, top, cd

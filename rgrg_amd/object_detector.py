@@ -182,7 +182,8 @@ class ObjectDetector(EngineOwner):
         if targets is not None or self.training:
             raise NotImplementedError("rgrg_amd implements the inference branch of ObjectDetector.forward "
                                       "(targets=None, eval mode); training is a later row of SURVEY.md 8(f)")
-        detections, top_region_features, class_detected = self.engine().detect(images)
+        low = images.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
+        detections, top_region_features, class_detected = self.engine().detect(images, bf16=bool(low))
         losses: Dict[str, Tensor] = {}
         if not self.return_feature_vectors:
             return losses, detections, class_detected
