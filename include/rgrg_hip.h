@@ -109,6 +109,14 @@ int rgrg_top1_per_class_f32(const float* pred, int ldp, const float* proposals, 
  * (1-y) x - (1 + (w-1) y) log_sigmoid(x).  logits f32 [n], mask/target u8 [n], loss: one f32 (nan when no row). */
 int rgrg_bce_with_logits_masked_f32(const float* logits, const uint8_t* mask, const uint8_t* target, float pos_weight,
                                     int n, float* loss, void* stream);
+/* Replaces the albumentations pipeline of get_image_tensor (src/full_model/generate_reports_for_images.py:129-147;
+ * SURVEY 8(f) rank 4) for a decoded 8-bit gray image already in device memory: LongestMaxSize(512, cv2.INTER_AREA)
+ * [the caller passes new_h/new_w = py3round(dim * 512 / max(h, w))] -> centred zero PadIfNeeded(512, 512) ->
+ * Normalize(mean, std; max_pixel_value 255) -> dst f32 [512*512] (= the [1,1,512,512] tensor).  Down-scaling only
+ * (new_h <= h, new_w <= w).  OpenCV / albumentations are third-party and absent here: arithmetic restated from their
+ * published sources, parity unpinned (oracle/preprocess.py). */
+int rgrg_preprocess_u8_f32(const uint8_t* src, int h, int w, int src_stride, int new_h, int new_w, float mean, float std,
+                           float* dst, void* stream);
 /* BinaryClassifierRegionSelection threshold + mask + row-major compaction
  * (binary_classifier_region_selection.py:53-61): selected = (logit > thr) & detected;
  * sel_rows int32 [n] lists the selected flat (image*29+region) indices in order,

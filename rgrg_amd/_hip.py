@@ -47,6 +47,7 @@ SIGNATURES = {
     "rgrg_top1_per_class_f32": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p]),
     "rgrg_select_regions_f32": (_i, [_p, _p, _f, _p, _p, _p, _i, _p]),
     "rgrg_bce_with_logits_masked_f32": (_i, [_p, _p, _p, C.c_float, _i, _p, _p]),
+    "rgrg_preprocess_u8_f32": (_i, [_p, _i, _i, _i, _i, _i, C.c_float, C.c_float, _p, _p]),
     "rgrg_gather_rows_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "rgrg_decoder_create": (_i, [C.POINTER(DecoderWeights), _i, _i, C.POINTER(_p)]),
     "rgrg_decoder_destroy": (None, [_p]),

@@ -6,6 +6,8 @@
 // operation order of the CPU algorithms it replaces, so that given identical inputs
 // the results are bit-identical except where a transcendental (exp) is involved.
 #include "common.h"
+#include <cfloat>
+#include <cmath>
 
 #pragma clang fp contract(off)
 
@@ -547,6 +549,74 @@ __global__ __launch_bounds__(256) void bce_logits_masked_kernel(const float* __r
     if (threadIdx.x == 0) *loss = (float)(ssum[0] / (double)scnt[0]);
 }
 
+// get_image_tensor (generate_reports_for_images.py:129-147): LongestMaxSize(512, INTER_AREA) -> centred zero
+// PadIfNeeded(512, 512) -> Normalize(mean, std) of an 8-bit gray image, one thread per pixel of the [512,512] output.
+// The INTER_AREA arithmetic follows OpenCV's resize.cpp for 8-bit down-scaling (third-party, restated: see
+// oracle/preprocess.py): mode 1 = 2x2 integer ((a+b+c+d+2)>>2), mode 2 = integer scales (int sum * float(1/area)),
+// mode 3 = fractional coverage tables (double geometry, float weights, float sums: x in table order, then rows in
+// order), saturate_cast = round half to even.  Compiled with fp contraction off (file pragma).
+struct AreaTaps {  // the <= 3 kinds of entries of one destination index: [partial first][full ...][partial last]
+    int first, n_full, last;  // source index of the partial-first entry (-1: none), count of full entries, last (-1: none)
+    int full0;
+    float a_first, a_full, a_last;
+};
+__device__ __forceinline__ AreaTaps area_taps(int d, int ssize, double scale) {
+    AreaTaps t;
+    const double f1 = d * scale, f2 = f1 + scale;
+    const double cell = fmin(scale, (double)ssize - f1);
+    int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+    s2 = min(s2, ssize - 1);
+    s1 = min(s1, s2);
+    t.first = -1; t.last = -1;
+    t.a_first = 0.f; t.a_last = 0.f;
+    if (s1 - f1 > 1e-3) { t.first = s1 - 1; t.a_first = (float)((s1 - f1) / cell); }
+    t.full0 = s1; t.n_full = s2 - s1; t.a_full = (float)(1.0 / cell);
+    if (f2 - s2 > 1e-3) { t.last = s2; t.a_last = (float)(fmin(fmin(f2 - s2, 1.0), cell) / cell); }
+    return t;
+}
+__device__ __forceinline__ float area_row(const unsigned char* __restrict__ r, const AreaTaps& x) {
+    float buf = 0.f;
+    if (x.first >= 0) buf += (float)r[x.first] * x.a_first;
+    for (int i = 0; i < x.n_full; ++i) buf += (float)r[x.full0 + i] * x.a_full;
+    if (x.last >= 0) buf += (float)r[x.last] * x.a_last;
+    return buf;
+}
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ src, int h, int w, int stride, int nh,
+                                                            int nw, int top, int left, double sx, double sy, int mode, int isx,
+                                                            int isy, float mean255, float denom, float* __restrict__ out, int size) {
+    const int ox = blockIdx.x * 16 + (threadIdx.x & 15), oy = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (ox >= size || oy >= size) return;
+    const int x = ox - left, y = oy - top;
+    float v = 0.f;
+    if (x >= 0 && x < nw && y >= 0 && y < nh) {
+        if (mode == 0) {
+            v = (float)src[(size_t)y * stride + x];
+        } else if (mode == 1) {
+            const unsigned char* r0 = src + (size_t)(2 * y) * stride + 2 * x;
+            v = (float)((r0[0] + r0[1] + r0[stride] + r0[stride + 1] + 2) >> 2);
+        } else if (mode == 2) {
+            int sum = 0;
+            for (int j = 0; j < isy; ++j)
+                for (int i = 0; i < isx; ++i) sum += src[(size_t)(y * isy + j) * stride + x * isx + i];
+            v = fminf(fmaxf(rintf((float)sum * (1.0f / (float)(isx * isy))), 0.f), 255.f);
+        } else {
+            const AreaTaps tx = area_taps(x, w, sx), ty = area_taps(y, h, sy);
+            float sum = 0.f;
+            bool firstrow = true;
+            auto add_row = [&](int srow, float beta) {
+                const float b = area_row(src + (size_t)srow * stride, tx);
+                sum = firstrow ? beta * b : sum + beta * b;
+                firstrow = false;
+            };
+            if (ty.first >= 0) add_row(ty.first, ty.a_first);
+            for (int j = 0; j < ty.n_full; ++j) add_row(ty.full0 + j, ty.a_full);
+            if (ty.last >= 0) add_row(ty.last, ty.a_last);
+            v = fminf(fmaxf(rintf(sum), 0.f), 255.f);
+        }
+    }
+    out[(size_t)oy * size + ox] = (v - mean255) * denom;
+}
+
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows,
                                                           float* __restrict__ dst, int D4) {
     const int r = blockIdx.x;
@@ -646,6 +716,24 @@ extern "C" int rgrg_bce_with_logits_masked_f32(const float* logits, const uint8_
                                                float pos_weight, int n, float* loss, void* stream) {
     RGRG_CHECK_ARG(logits && mask && target && loss && n > 0);
     hipLaunchKernelGGL(bce_logits_masked_kernel, dim3(1), dim3(256), 0, as_stream(stream), logits, mask, target, pos_weight, n, loss);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+extern "C" int rgrg_preprocess_u8_f32(const uint8_t* src, int h, int w, int src_stride, int new_h, int new_w, float mean,
+                                      float std, float* dst, void* stream) {
+    constexpr int SIZE = 512;
+    RGRG_CHECK_ARG(src && dst && h > 0 && w > 0 && src_stride >= w && new_h > 0 && new_w > 0 && new_h <= SIZE && new_w <= SIZE);
+    RGRG_CHECK_ARG(new_h <= h && new_w <= w);  // INTER_AREA up-scaling (inputs smaller than 512) is not implemented
+    const double sx = (double)w / new_w, sy = (double)h / new_h;
+    const int isx = (int)lround(sx), isy = (int)lround(sy);
+    int mode = 3;
+    if (new_h == h && new_w == w) mode = 0;
+    else if (fabs(sx - isx) < DBL_EPSILON && fabs(sy - isy) < DBL_EPSILON) mode = (isx == 2 && isy == 2) ? 1 : 2;
+    const int top = (int)((SIZE - new_h) / 2.0), left = (int)((SIZE - new_w) / 2.0);
+    const float mean255 = mean * 255.0f, denom = 1.0f / (std * 255.0f);
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(SIZE / 16, SIZE / 16), dim3(256), 0, as_stream(stream), src, h, w, src_stride, new_h,
+                       new_w, top, left, sx, sy, mode, isx, isy, mean255, denom, dst, SIZE);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }

@@ -82,18 +82,11 @@ def get_report_for_image(model, image_tensor, tokenizer, bert_score, sentence_to
 
 
 def get_image_tensor(image_path):
-    """LongestMaxSize(512, INTER_AREA) -> centred zero PadIfNeeded(512,512) -> Normalize(mean, std)
-    on [0,1]-scaled pixels -> [1,1,512,512] (generate_reports_for_images.py:129-147)."""
-    import cv2  # not installed in the build image: raises ImportError loudly
-    image = cv2.imread(image_path, cv2.IMREAD_UNCHANGED)
-    h, w = image.shape[:2]
-    s = IMAGE_INPUT_SIZE / max(h, w)
-    image = cv2.resize(image, (max(1, round(w * s)), max(1, round(h * s))), interpolation=cv2.INTER_AREA)
-    h, w = image.shape[:2]
-    top, left = (IMAGE_INPUT_SIZE - h) // 2, (IMAGE_INPUT_SIZE - w) // 2
-    image = cv2.copyMakeBorder(image, top, IMAGE_INPUT_SIZE - h - top, left, IMAGE_INPUT_SIZE - w - left, cv2.BORDER_CONSTANT, value=0)
-    x = torch.from_numpy(image).to(torch.float32) / 255.0
-    return ((x - mean) / std)[None, None]
+    """LongestMaxSize(512, INTER_AREA) -> centred zero PadIfNeeded(512,512) -> Normalize(mean, std) -> [1,1,512,512]
+    (generate_reports_for_images.py:129-147), computed on the GPU (``rgrg_amd.preprocess``); only the file decoding is host
+    code (cv2 when installed, else PIL)."""
+    from .preprocess import preprocess_image, read_gray_image
+    return preprocess_image(read_gray_image(image_path), device)
 
 
 def get_model(checkpoint_path):

@@ -338,3 +338,24 @@ def test_linear_bf16w(eng, M, N, K, act, res):
     _hip.check(eng.lib.rgrg_linear_bf16w_f32(Ad.data_ptr(), Wb.data_ptr(), bd.data_ptr(), Rd.data_ptr() if res else None,
                                              y.data_ptr(), M, N, K, N, act, _stream()))
     close(y, ref, 2e-5, 2e-6, f"bf16w linear {M}x{N}x{K}")
+
+
+# ------------------------------------------------------------------------- image preprocessing
+@pytest.mark.parametrize("h,w", [(3056, 2544), (2544, 3056), (1024, 1024), (1536, 1536), (768, 512), (512, 512), (700, 513)])
+def test_preprocess_matches_the_restated_opencv_pipeline(h, w):
+    """rgrg_preprocess_u8_f32 vs oracle/preprocess.py (OpenCV INTER_AREA + albumentations pad/normalize restated; the
+    third-party originals are absent -> unpinned): the rounded 8-bit pixel must be identical, so the float output is
+    bit-identical.  Shapes cover the general table path (5.97x, portrait and landscape), the integer 2x2 and 3x3 fast
+    paths, a 1.5x scale, no resize, and an odd size."""
+    import numpy as np
+    from oracle import preprocess as P
+    from rgrg_amd.preprocess import preprocess_image
+    rng = np.random.default_rng(h * 10007 + w)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img[: h // 3] = (np.arange(w) % 256).astype(np.uint8)  # smooth part: exercises .5 rounding cases less randomly
+    ref = torch.from_numpy(P.get_image_tensor_from_array(img))
+    out = preprocess_image(img, DEV).cpu()
+    assert out.shape == (1, 1, 512, 512) and out.dtype == torch.float32
+    diff = (out - ref).abs()
+    # one 8-bit level = 1/(0.302*255) = 0.013: any rounding disagreement would show as >= 0.013
+    assert diff.max().item() == 0.0, (diff.max().item(), int((diff > 0).sum()))
