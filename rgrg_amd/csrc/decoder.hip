@@ -33,6 +33,8 @@ int launch_gemm_dense(const float* A, const float* W, const float* shift, const 
                       int ldy, int act, float* ws, size_t ws_floats, hipStream_t st);
 int init_gemm_attrs();
 int init_gemm_bf16_attrs();
+int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const float* shift, const float* R, float* Y, void* Y16,
+                         int M, int N, int K, int ldy, int act, hipStream_t st);
 int launch_gemm_bf16w(const float* A, const void* Wb, const float* shift, const float* R, float* Y, int M, int N, int K,
                       int ldy, int act, hipStream_t st);
 int convert_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st);
@@ -406,6 +408,19 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// fp32 -> bf16 bits, round to nearest even (the rounding the bf16 GEMM applies when it stages fp32 activations)
+__device__ __forceinline__ unsigned short bf16_bits_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void store_bf16x4(unsigned short* dst, const f32x4 v) {
+    uint2 o;
+    o.x = (unsigned)bf16_bits_rne(v[0]) | ((unsigned)bf16_bits_rne(v[1]) << 16);
+    o.y = (unsigned)bf16_bits_rne(v[2]) | ((unsigned)bf16_bits_rne(v[3]) << 16);
+    *reinterpret_cast<uint2*>(dst) = o;
+}
+
 // nn.LayerNorm(1024, eps=1e-5) of the row held as one float4 per thread (256 threads)
 __device__ __forceinline__ f32x4 ln_row(const f32x4 v, const float* __restrict__ g, const float* __restrict__ b,
                                         float* sh, int D) {
@@ -428,13 +443,16 @@ __device__ __forceinline__ f32x4 ln_row(const f32x4 v, const float* __restrict__
 __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__ wte, const long long* __restrict__ ids,
                                                        int ld_ids, const int* __restrict__ step, const float* __restrict__ g,
                                                        const float* __restrict__ b, float* __restrict__ x,
-                                                       float* __restrict__ xn, int D, const int* __restrict__ tok_override) {
+                                                       float* __restrict__ xn, int D, const int* __restrict__ tok_override,
+                                                       unsigned short* __restrict__ xn16 = nullptr) {
     __shared__ float sh[4];
     const int s = blockIdx.x, t = *step, tid = threadIdx.x;
     const long long tok = tok_override ? (long long)tok_override[s] : ids[(size_t)s * ld_ids + t];  // beam search feeds the beam tokens
     const f32x4 v = reinterpret_cast<const f32x4*>(wte + (size_t)tok * D)[tid] + reinterpret_cast<const f32x4*>(wte + (size_t)t * D)[tid];
     reinterpret_cast<f32x4*>(x + (size_t)s * D)[tid] = v;
-    reinterpret_cast<f32x4*>(xn + (size_t)s * D)[tid] = ln_row(v, g, b, sh, D);
+    const f32x4 o = ln_row(v, g, b, sh, D);
+    if (xn16) store_bf16x4(xn16 + (size_t)s * D + 4 * tid, o);  // bf16-activation mode: the GEMMs read only this copy
+    else reinterpret_cast<f32x4*>(xn + (size_t)s * D)[tid] = o;
 }
 
 // Residual stream update fused with the split-K combine and the NEXT LayerNorm:
@@ -443,7 +461,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void resid_ln_kernel(float* __restrict__ x, const float* __restrict__ bias,
                                                        const float* __restrict__ part, int KS, int ldp,
                                                        const float* __restrict__ g, const float* __restrict__ b,
-                                                       float* __restrict__ xn, int D) {
+                                                       float* __restrict__ xn, int D, unsigned short* __restrict__ xn16 = nullptr) {
     __shared__ float sh[4];
     const int row = blockIdx.x, tid = threadIdx.x;
     f32x4 v = reinterpret_cast<const f32x4*>(x + (size_t)row * D)[tid];
@@ -455,7 +473,9 @@ __global__ __launch_bounds__(256) void resid_ln_kernel(float* __restrict__ x, co
         v += p + reinterpret_cast<const f32x4*>(bias)[tid];
         reinterpret_cast<f32x4*>(x + (size_t)row * D)[tid] = v;
     }
-    reinterpret_cast<f32x4*>(xn + (size_t)row * D)[tid] = ln_row(v, g, b, sh, D);
+    const f32x4 o = ln_row(v, g, b, sh, D);
+    if (xn16) store_bf16x4(xn16 + (size_t)row * D + 4 * tid, o);
+    else reinterpret_cast<f32x4*>(xn + (size_t)row * D)[tid] = o;
 }
 
 // Pseudo self-attention for ONE new token per sequence (GPT2PseudoAttention.forward with
@@ -589,7 +609,8 @@ template <int ATT_NI>  // a chunk = 32 * ATT_NI keys
 __global__ __launch_bounds__(256) void attn_decode_kv16_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                                u16* __restrict__ kc, u16* __restrict__ vc,
                                                                const int* __restrict__ step, float* __restrict__ out,
-                                                               int S, int H, int T, const int* __restrict__ src) {
+                                                               int S, int H, int T, const int* __restrict__ src,
+                                                               u16* __restrict__ out16) {
     __shared__ float sc[ATT_MAXKEYS];
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -704,9 +725,11 @@ __global__ __launch_bounds__(256) void attn_decode_kv16_kernel(const float* __re
         for (int e = 0; e < 8; ++e) part[wave][d8 * 8 + e] = acc[e];
     }
     __syncthreads();
-    if (threadIdx.x < 64)
-        out[(size_t)s * D + hd * 64 + threadIdx.x] =
-            (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (threadIdx.x < 64) {
+        const float o = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (out16) out16[(size_t)s * D + hd * 64 + threadIdx.x] = (u16)bf16_rne_bits(o);  // feeds the bf16 attn_proj GEMM only
+        else out[(size_t)s * D + hd * 64 + threadIdx.x] = o;
+    }
 }
 
 // image key/value (uk/uv outputs) -> cache slot 0 of every layer
@@ -1210,6 +1233,7 @@ struct rgrg_decoder {
     size_t tr_rows = 0, tr_seqs = 0;
     bool have_wT = false;
     int bf16_gemms = 0;  // 1: bf16-weight MFMA GEMMs on the many-sequence path (not bit-exact; opt-in)
+    unsigned short *xn16 = nullptr, *att16 = nullptr, *ff16 = nullptr;  // bf16 activations of that path (GEMM inputs)
     int gemm_launches_per_step = 0;
 };
 
@@ -1300,7 +1324,8 @@ static bool kv_is_bf16(const rgrg_decoder* d, int rows) { return d->bf16_gemms &
 // (d->part) and the caller's next kernel (resid_ln_kernel) combines them with bias and
 // residual; otherwise a small reduce kernel finishes the job.  > 32 rows: tiled MFMA GEMM.
 static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R, float* Y, int M, int ldy, int act,
-                  bool count, bool defer = false, bool cand = false) {
+                  bool count, bool defer = false, bool cand = false, const unsigned short* X16 = nullptr,
+                  unsigned short* Y16 = nullptr) {
     if (M <= skinny_max_rows() && l.packed) {
         // up to 4 row tiles of 32 sequences in ONE launch: the weights stay in registers across the tiles
         SkinnyArgs a{X, l.packed, l.b, R, Y, d->part, M, l.K, l.N, l.NT, l.KS, ldy, act, nullptr, nullptr, l.ntile};
@@ -1318,7 +1343,8 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
         }
         return RGRG_OK;
     }
-    if (d->bf16_gemms && l.wb && l.K % 64 == 0) return launch_gemm_bf16w(X, l.wb, l.b, R, Y, M, l.N, l.K, ldy, act, d->stream);
+    if (d->bf16_gemms && l.wb && l.K % 256 == 0)
+        return launch_gemm_bf16w_ex(X16 ? nullptr : X, X16, l.wb, l.b, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream);
     return launch_gemm_dense(X, l.w, l.b, R, Y, M, l.N, l.K, ldy, act, d->gemm_ws, d->gemm_ws_floats, d->stream);
 }
 
@@ -1332,8 +1358,14 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
     const int D = d->D;
     const bool skinny = S <= skinny_max_rows();
     int rc;
+    // bf16 many-sequence mode: the GEMM inputs (LayerNorm output, attention output, GELU output) are written ONCE as
+    // bf16 by their producers - the same round-to-nearest-even the GEMM would apply to an fp32 input, so the results
+    // do not change - instead of fp32 that every column tile of the GEMM re-reads and re-rounds
+    unsigned short* xn16 = (kv_is_bf16(d, S) && d->xn16) ? d->xn16 : nullptr;
+    unsigned short* att16 = xn16 ? d->att16 : nullptr;
+    unsigned short* ff16 = xn16 ? d->ff16 : nullptr;
     hipLaunchKernelGGL(embed_ln_kernel, dim3(S), dim3(256), 0, st, d->wte, d->ids, d->max_len, d->step,
-                       d->layers[0].ln1_g, d->layers[0].ln1_b, d->x, d->xn, D, tok_override);
+                       d->layers[0].ln1_g, d->layers[0].ln1_b, d->x, d->xn, D, tok_override, xn16);
     RGRG_LAUNCH_CHECK();
     for (int l = 0; l < d->n_layer; ++l) {
         const LayerW& w = d->layers[l];
@@ -1341,11 +1373,11 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
         float* vc = kc + d->kv_kv_stride;
         const float* ng = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_g : d->lnf_g;
         const float* nb = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_b : d->lnf_b;
-        if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, count))) return rc;
+        if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, count, false, false, xn16))) return rc;
         if (kv_is_bf16(d, S)) {
             u16* kc16 = reinterpret_cast<u16*>(d->kv) + (size_t)l * d->kv_layer_stride;
             hipLaunchKernelGGL((attn_decode_kv16_kernel<5>), dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc16,
-                               kc16 + d->kv_kv_stride, d->step, d->att, S, d->H, d->T, src);
+                               kc16 + d->kv_kv_stride, d->step, d->att, S, d->H, d->T, src, att16);
         } else if (S * d->H <= 4096)
             hipLaunchKernelGGL((attn_decode_kernel<true, 9>), dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc, vc, d->step,
                                d->att, S, d->H, d->T, src);
@@ -1354,17 +1386,17 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
                                d->att, S, d->H, d->T, src);
         RGRG_LAUNCH_CHECK();
         const bool defer_a = skinny && w.attn_proj.KS > 1, defer_m = skinny && w.mlp_proj.KS > 1;
-        if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count, defer_a))) return rc;
+        if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count, defer_a, false, att16))) return rc;
         hipLaunchKernelGGL(resid_ln_kernel, dim3(S), dim3(256), 0, st, d->x, w.attn_proj.b, defer_a ? d->part : nullptr,
-                           w.attn_proj.KS, w.attn_proj.NT * w.attn_proj.ntile, w.ln2_g, w.ln2_b, d->xn, D);
+                           w.attn_proj.KS, w.attn_proj.NT * w.attn_proj.ntile, w.ln2_g, w.ln2_b, d->xn, D, xn16);
         RGRG_LAUNCH_CHECK();
-        if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, count))) return rc;
-        if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->x, S, D, RGRG_ACT_NONE, count, defer_m))) return rc;
+        if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, count, false, false, xn16, ff16))) return rc;
+        if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->x, S, D, RGRG_ACT_NONE, count, defer_m, false, ff16))) return rc;
         hipLaunchKernelGGL(resid_ln_kernel, dim3(S), dim3(256), 0, st, d->x, w.mlp_proj.b, defer_m ? d->part : nullptr,
-                           w.mlp_proj.KS, w.mlp_proj.NT * w.mlp_proj.ntile, ng, nb, d->xn, D);
+                           w.mlp_proj.KS, w.mlp_proj.NT * w.mlp_proj.ntile, ng, nb, d->xn, D, xn16);
         RGRG_LAUNCH_CHECK();
     }
-    if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, false, !beam))) return rc;
+    if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, false, !beam, xn16))) return rc;
     if (beam) return RGRG_OK;  // the caller ranks the logits (beam_row_topk / beam_merge)
     if (!(skinny && d->lm_head.KS == 1 && d->lm_head.ntile == 32)) {
         hipLaunchKernelGGL(logits_candidates_kernel, dim3(16, S), dim3(256), 0, st, d->logits, d->ld_logits, d->V,
@@ -2076,6 +2108,12 @@ extern "C" int rgrg_decoder_set_precision(rgrg_decoder* d, int bf16_gemms) {
             return convert_f32_to_bf16(l.w, l.wb, (size_t)l.N * l.K, d->stream);
         };
         int rc2;
+        if (!d->xn16) {
+            if ((rc2 = dmalloc(d, (void**)&d->xn16, (size_t)d->rows * d->D * 2, false)) ||
+                (rc2 = dmalloc(d, (void**)&d->att16, (size_t)d->rows * d->D * 2, false)) ||
+                (rc2 = dmalloc(d, (void**)&d->ff16, (size_t)d->rows * 4 * d->D * 2, false)))
+                return rc2;
+        }
         if ((rc2 = mk(d->lm_head))) return rc2;
         for (auto& w : d->layers) {
             if ((rc2 = mk(w.c_attn)) || (rc2 = mk(w.attn_proj)) || (rc2 = mk(w.c_fc)) || (rc2 = mk(w.mlp_proj))) return rc2;

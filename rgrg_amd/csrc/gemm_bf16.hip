@@ -19,11 +19,13 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
 struct GemmBf16Params {
-    const float* A;
+    const float* A;    // fp32 activations (rounded to bf16 while staged) ...
+    const u16* A16;    // ... or activations already rounded to bf16 by their producer (A16 kernels)
     const u16* Wb;
     const float* shift;
     const float* R;
     float* Y;
+    u16* Y16;          // non-null: the result is stored as bf16 [M, ldy] instead of fp32 (feeds the next GEMM only)
     int M, N, K, ldy, act;
 };
 
@@ -42,7 +44,7 @@ __device__ __forceinline__ u16 f32_to_bf16_rne(float f) {
 // tile kt+NS are issued before tile kt is computed) and the LDS tiles are double buffered, one barrier per
 // K tile.  Workgroup ids are remapped so that the 1/8 of the grid an XCD receives (ids i mod 8) covers a
 // compact band of column tiles: its L2 then holds that band of W plus A.
-template <int BM, int BN, int THREADS>
+template <int BM, int BN, int THREADS, bool A16>
 __global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Params p, const int mtiles, const int ntiles) {
     constexpr int WAVES = THREADS / 64, WN = WAVES / 2;
     constexpr int TM = BM / 2, TN = BN / WN;    // wave sub-tile
@@ -64,13 +66,15 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Param
     const int nk = p.K / BK16;
 
     const float* aptr[AL];
+    const u16* aptr16[AL];
     const u16* bptr[BL];
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
         // rows/columns past the edge read the last valid one: their products are never stored, and the loop
         // stays branch free (the compiler can then count outstanding loads exactly)
         const int m = min(m0 + lrow + RSTEP * i, p.M - 1);
-        aptr[i] = p.A + (size_t)m * p.K + kchunk * 4;  // this lane: k = 4c..4c+3 and 32+4c..32+4c+3 of each K tile
+        aptr[i] = A16 ? nullptr : p.A + (size_t)m * p.K + kchunk * 4;  // fp32: k = 4c..4c+3 and 32+4c..32+4c+3 of each K tile
+        aptr16[i] = A16 ? p.A16 + (size_t)m * p.K + kchunk * 8 : nullptr;  // bf16: k = 8c..8c+7
     }
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
@@ -79,13 +83,18 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Param
     }
 
     f32x4 ra[NS][AL][2];
+    bf16x8 ra16[NS][AL];
     bf16x8 rb[NS][BL];
 #define RGRG_LOAD_TILE(S, KT)                                                                    \
     {                                                                                            \
         const int koff = (KT) * BK16;                                                            \
         _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                         \
-            ra[S][i][0] = *reinterpret_cast<const f32x4*>(aptr[i] + koff);                       \
-            ra[S][i][1] = *reinterpret_cast<const f32x4*>(aptr[i] + koff + 32);                  \
+            if constexpr (A16) {                                                                 \
+                ra16[S][i] = *reinterpret_cast<const bf16x8*>(aptr16[i] + koff);                 \
+            } else {                                                                             \
+                ra[S][i][0] = *reinterpret_cast<const f32x4*>(aptr[i] + koff);                   \
+                ra[S][i][1] = *reinterpret_cast<const f32x4*>(aptr[i] + koff + 32);              \
+            }                                                                                    \
         }                                                                                        \
         _Pragma("unroll") for (int i = 0; i < BL; ++i)                                           \
             rb[S][i] = *reinterpret_cast<const bf16x8*>(bptr[i] + koff);                         \
@@ -96,14 +105,18 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Param
     {                                                                                            \
         if ((I) < AL) {                                                                          \
             constexpr int i = (I) < AL ? (I) : 0;                                                \
-            bf16x4 lo, hi;                                                                       \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                      \
-                lo[e] = (short)f32_to_bf16_rne(ra[S][i][0][e]);                                  \
-                hi[e] = (short)f32_to_bf16_rne(ra[S][i][1][e]);                                  \
+            if constexpr (A16) {                                                                 \
+                *reinterpret_cast<bf16x8*>(&As[((BUF) * BM + lrow + RSTEP * i) * LDB + kchunk * 8]) = ra16[S][i]; \
+            } else {                                                                             \
+                bf16x4 lo, hi;                                                                   \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                  \
+                    lo[e] = (short)f32_to_bf16_rne(ra[S][i][0][e]);                              \
+                    hi[e] = (short)f32_to_bf16_rne(ra[S][i][1][e]);                              \
+                }                                                                                \
+                u16* dst = &As[((BUF) * BM + lrow + RSTEP * i) * LDB + kchunk * 4];              \
+                *reinterpret_cast<bf16x4*>(dst) = lo;                                            \
+                *reinterpret_cast<bf16x4*>(dst + 32) = hi;                                       \
             }                                                                                    \
-            u16* dst = &As[((BUF) * BM + lrow + RSTEP * i) * LDB + kchunk * 4];                  \
-            *reinterpret_cast<bf16x4*>(dst) = lo;                                                \
-            *reinterpret_cast<bf16x4*>(dst + 32) = hi;                                           \
         } else {                                                                                 \
             constexpr int i = (I) >= AL ? (I) - AL : 0;                                          \
             *reinterpret_cast<bf16x8*>(&Bs[((BUF) * BN + lrow + RSTEP * i) * LDB + kchunk * 8]) = rb[S][i]; \
@@ -195,7 +208,10 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Param
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 const float v = apply_act(acc[mi][ni][r] + sh + rv[r], p.act);
-                if (row < p.M && col < p.N) p.Y[(size_t)row * p.ldy + col] = v;
+                if (row < p.M && col < p.N) {
+                    if (p.Y16) p.Y16[(size_t)row * p.ldy + col] = f32_to_bf16_rne(v);
+                    else p.Y[(size_t)row * p.ldy + col] = v;
+                }
             }
         }
 }
@@ -209,14 +225,19 @@ template <int BM, int BN, int THREADS>
 static int launch_bf16_cfg(const GemmBf16Params& p, hipStream_t st) {
     constexpr size_t lds = (size_t)(2 * BM + 2 * BN) * LDB * sizeof(u16);
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_bf16w_kernel<BM, BN, THREADS>), dim3(mtiles * ntiles), dim3(THREADS), lds, st, p, mtiles, ntiles);
+    if (p.A16)
+        hipLaunchKernelGGL((gemm_bf16w_kernel<BM, BN, THREADS, true>), dim3(mtiles * ntiles), dim3(THREADS), lds, st, p, mtiles, ntiles);
+    else
+        hipLaunchKernelGGL((gemm_bf16w_kernel<BM, BN, THREADS, false>), dim3(mtiles * ntiles), dim3(THREADS), lds, st, p, mtiles, ntiles);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
 
 template <int BM, int BN, int THREADS>
 static int bf16_attr() {
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<BM, BN, THREADS>),
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<BM, BN, THREADS, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<BM, BN, THREADS, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
     return RGRG_OK;
 }
@@ -236,10 +257,12 @@ static int forced_bf16_cfg() {
     return v;
 }
 
-int launch_gemm_bf16w(const float* A, const void* Wb, const float* shift, const float* R, float* Y, int M, int N, int K,
-                      int ldy, int act, hipStream_t st) {
-    RGRG_CHECK_ARG(A && Wb && Y && M > 0 && N > 0 && K > 0 && K % (4 * BK16) == 0 && ldy >= N);  // 4 = pipeline depth NS
-    GemmBf16Params p{A, reinterpret_cast<const u16*>(Wb), shift, R, Y, M, N, K, ldy, act};
+// A16 / Y16 (either may be null): bf16 activations in / out, see GemmBf16Params
+int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const float* shift, const float* R, float* Y, void* Y16,
+                         int M, int N, int K, int ldy, int act, hipStream_t st) {
+    RGRG_CHECK_ARG((A || A16) && Wb && (Y || Y16) && M > 0 && N > 0 && K > 0 && K % (4 * BK16) == 0 && ldy >= N);  // 4 = depth NS
+    GemmBf16Params p{A, reinterpret_cast<const u16*>(A16), reinterpret_cast<const u16*>(Wb), shift, R, Y,
+                     reinterpret_cast<u16*>(Y16), M, N, K, ldy, act};
     int cfg = forced_bf16_cfg();
     if (cfg == 0) {
         const long tiles_big = (long)((M + 127) / 128) * ((N + 127) / 128);
@@ -249,6 +272,11 @@ int launch_gemm_bf16w(const float* A, const void* Wb, const float* shift, const 
         case 1: return launch_bf16_cfg<128, 128, 512>(p, st);
         default: return launch_bf16_cfg<64, 64, 256>(p, st);
     }
+}
+
+int launch_gemm_bf16w(const float* A, const void* Wb, const float* shift, const float* R, float* Y, int M, int N, int K,
+                      int ldy, int act, hipStream_t st) {
+    return launch_gemm_bf16w_ex(A, nullptr, Wb, shift, R, Y, nullptr, M, N, K, ldy, act, st);
 }
 
 int convert_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st) {
