@@ -199,15 +199,26 @@ int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, const int64_t* 
  * pass.  Only what the reference trains in the language model receives a gradient: uk / uv of every
  * GPT2PseudoAttention (src/language_model/language_model.py:50-57) and feature_space_transformation_nn (:230-236);
  * every other GPT-2 tensor is frozen there (:207-213), so the 24 blocks only propagate activation gradients
- * (dX = dY W on transposed weight copies made at the first call).  Dropout is not applied (deterministic pass).
+ * (dX = dY W on transposed weight copies made at the first call).
  *   loss_scale    d(total_loss)/d(language_model_loss), e.g. the loss weight (and an AMP scale)
+ *   dropout_p     0 = deterministic pass.  > 0: GPT-2's four dropout sites of train mode (embedding `drop` :311,
+ *                 attn_dropout on the probabilities :116, resid_dropout :178, the MLP's dropout) with a counter-based
+ *                 generator: mask = f(dropout_seed, layer*4 + site, element index) (Philox4x32-10), recomputed by the
+ *                 backward pass; torch's generator stream cannot be reproduced, so the masks differ from the
+ *                 reference's (rgrg_dropout_mask_f32 exports them for checks).  Needs T <= 159.
+ *   dropout_seed  a fresh value per call
  *   loss_out      one f32, the unscaled loss
  *   grad_ukv_w    f32 [n_layer*2*1024, 1024]  rows = [uk_0; uv_0; uk_1; uv_1; ...]      grad_ukv_b  f32 [n_layer*2*1024]
  *   grad_fst0_w/b, grad_fst2_w/b   f32 [1024,1024] / [1024]  (Linear 0 and 2 of feature_space_transformation_nn)
  * Gradients are WRITTEN (not accumulated).  T <= 160.  Allocates work space on demand (~0.9 MB per token row). */
 int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, const int64_t* input_ids, const float* attention_mask,
-                              int S, int T, float loss_scale, float* loss_out, float* grad_ukv_w, float* grad_ukv_b,
-                              float* grad_fst0_w, float* grad_fst0_b, float* grad_fst2_w, float* grad_fst2_b, void* stream);
+                              int S, int T, float loss_scale, float dropout_p, uint64_t dropout_seed, float* loss_out,
+                              float* grad_ukv_w, float* grad_ukv_b, float* grad_fst0_w, float* grad_fst0_b, float* grad_fst2_w,
+                              float* grad_fst2_b, void* stream);
+/* The dropout mask of one site as the training pass computes it: out[i] = 0 (dropped, probability p) or 1/(1-p), for the
+ * flat element index i of the site's tensor ([S*T,1024] for sites 0/2/3, [S,16,T,T+1] for the attention probabilities);
+ * stream_id = layer*4 + site. */
+int rgrg_dropout_mask_f32(uint64_t seed, uint32_t stream_id, float p, int64_t n, float* out, void* stream);
 /* After an optimizer step changed the trainable decoder weights IN PLACE (the fst0/fst2/ukv pointers given to
  * rgrg_decoder_create): rebuild the kernel-side copies derived from them (packed skinny layouts, transposes). */
 int rgrg_decoder_refresh_trainable(rgrg_decoder* d, void* stream);

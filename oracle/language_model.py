@@ -40,7 +40,8 @@ def _heads(t: Tensor) -> Tensor:
 
 
 def pseudo_attention(sd: SD, p: str, x: Tensor, img: Tensor, add_mask: Tensor,
-                     past: Optional[Tuple[Tensor, Tensor]]) -> Tuple[Tensor, Tuple[Tensor, Tensor]]:
+                     past: Optional[Tuple[Tensor, Tensor]], drop_probs: Optional[Tensor] = None,
+                     drop_out: Optional[Tensor] = None) -> Tuple[Tensor, Tuple[Tensor, Tensor]]:
     """GPT2PseudoAttention.forward (:124-180).  x [S,T,1024]; img [S,1024] (already
     through feature_space_transformation_nn); add_mask [S,1,1,1+T_total]."""
     q, k, v = conv1d(sd, p + "c_attn.", x).split(D_MODEL, dim=2)
@@ -59,12 +60,18 @@ def pseudo_attention(sd: SD, p: str, x: Tensor, img: Tensor, add_mask: Tensor,
     causal = torch.tril(torch.ones((kl, kl), dtype=torch.bool))[kl - ql:kl, :kl]
     w = torch.where(causal, w, torch.tensor(MASK_VALUE, dtype=w.dtype))
     w = F.softmax(w + add_mask, dim=-1)
+    if drop_probs is not None:  # attn_dropout (:116) with an explicit mask (0 or 1/(1-p)), train mode only
+        w = w * drop_probs
     o = torch.matmul(w, V).permute(0, 2, 1, 3).reshape(x.shape[0], ql, D_MODEL)
-    return conv1d(sd, p + "c_proj.", o), (K, V)
+    a = conv1d(sd, p + "c_proj.", o)
+    if drop_out is not None:    # resid_dropout (:178)
+        a = a * drop_out.view_as(a)
+    return a, (K, V)
 
 
 def lm_forward(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_states: Tensor,
-               past: Optional[List[Tuple[Tensor, Tensor]]], position_ids: Tensor, p: str = "language_model."):
+               past: Optional[List[Tuple[Tensor, Tensor]]], position_ids: Tensor, p: str = "language_model.",
+               drop_masks: Optional[Dict[Tuple[int, int], Tensor]] = None):
     """LanguageModel.forward(return_loss=False, use_cache=True) (:258-366)."""
     g = p + "gpt_with_lm_head.transformer."
     f = p + "feature_space_transformation_nn."
@@ -72,6 +79,9 @@ def lm_forward(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_s
                    sd[f + "2.weight"], sd[f + "2.bias"])  # :284
     wte = sd[g + "wte.weight"]
     x = wte[input_ids] + wte[position_ids]  # quirk: positions are embedded with wte, not wpe (:307)
+    dm = drop_masks or {}  # train mode: explicit dropout masks {(layer, site): 0 | 1/(1-p)}; sites as in csrc/common.h
+    if (0, 0) in dm:
+        x = x * dm[(0, 0)].view_as(x)  # self.drop (:311)
     S = input_ids.shape[0]
     am = torch.cat((torch.ones((S, 1), dtype=torch.int64), attention_mask), dim=-1)[:, None, None, :]
     add_mask = (1.0 - am.to(x.dtype)) * -10000.0  # :325-334
@@ -79,10 +89,13 @@ def lm_forward(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_s
     for l in range(N_LAYER):
         b = f"{g}h.{l}."
         h = F.layer_norm(x, (D_MODEL,), sd[b + "ln_1.weight"], sd[b + "ln_1.bias"], LN_EPS)
-        a, present = pseudo_attention(sd, b + "attn.", h, img, add_mask, None if past is None else past[l])
+        a, present = pseudo_attention(sd, b + "attn.", h, img, add_mask, None if past is None else past[l],
+                                      dm.get((l, 1)), dm.get((l, 2)))
         x = a + x
         h = F.layer_norm(x, (D_MODEL,), sd[b + "ln_2.weight"], sd[b + "ln_2.bias"], LN_EPS)
         h = conv1d(sd, b + "mlp.c_proj.", gelu_new(conv1d(sd, b + "mlp.c_fc.", h)))
+        if (l, 3) in dm:
+            h = h * dm[(l, 3)].view_as(h)  # GPT2MLP dropout
         x = h + x
         presents.append(present)
     x = F.layer_norm(x, (D_MODEL,), sd[g + "ln_f.weight"], sd[g + "ln_f.bias"], LN_EPS)
@@ -118,9 +131,11 @@ def trainable_keys(p: str = "language_model.") -> List[str]:
     return keys + [p + f"feature_space_transformation_nn.{i}.{wb}" for i in (0, 2) for wb in ("weight", "bias")]
 
 
-def lm_loss_and_grads(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_states: Tensor, p: str = "language_model."):
-    """``loss = LanguageModel.forward(return_loss=True); loss.backward()`` with dropout off (modules in eval mode,
-    gradients enabled): torch autograd through the restated forward.  Returns (loss, {key: grad})."""
+def lm_loss_and_grads(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_states: Tensor, p: str = "language_model.",
+                      drop_masks: Optional[Dict[Tuple[int, int], Tensor]] = None):
+    """``loss = LanguageModel.forward(return_loss=True); loss.backward()``: torch autograd through the restated forward.
+    Dropout off (modules in eval mode, gradients enabled) unless explicit ``drop_masks`` are given.
+    Returns (loss, {key: grad})."""
     sd2 = dict(sd)
     keys = trainable_keys(p)
     for k in keys:
@@ -128,7 +143,7 @@ def lm_loss_and_grads(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_h
     with torch.enable_grad():
         S, T = input_ids.shape
         pos = torch.arange(T, dtype=torch.long)[None, :]
-        logits, _ = lm_forward(sd2, input_ids, attention_mask, image_hidden_states, None, pos, p)
+        logits, _ = lm_forward(sd2, input_ids, attention_mask, image_hidden_states, None, pos, p, drop_masks)
         labels = input_ids.clone()
         labels[~attention_mask.to(torch.bool)] = -100
         loss = F.cross_entropy(logits[:, :-1, :].reshape(-1, VOCAB), labels[:, 1:].reshape(-1), ignore_index=-100)

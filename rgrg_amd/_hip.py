@@ -55,7 +55,8 @@ SIGNATURES = {
     "rgrg_decoder_beam_search": (_i, [_p, _p, _i, _i, _i, _i, _f, _p, _i, C.POINTER(_i), _p]),
     "rgrg_decoder_set_precision": (_i, [_p, _i]),
     "rgrg_decoder_lm_forward": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p]),
-    "rgrg_decoder_lm_loss_grad": (_i, [_p, _p, _p, _p, _i, _i, C.c_float, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "rgrg_decoder_lm_loss_grad": (_i, [_p, _p, _p, _p, _i, _i, C.c_float, C.c_float, C.c_uint64, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "rgrg_dropout_mask_f32": (_i, [C.c_uint64, C.c_uint32, C.c_float, C.c_int64, _p, _p]),
     "rgrg_decoder_refresh_trainable": (_i, [_p, _p]),
     "rgrg_transpose_pad_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "rgrg_colsum_f32": (_i, [_p, _p, _i, _i, _p]),

@@ -56,4 +56,32 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+
+// Counter-based dropout (training pass): Philox4x32-10 keyed by the call's seed, counter = (element index, stream id).
+// Every element's mask is a pure function of (seed, stream, index), so the backward pass recomputes exactly the
+// mask of the forward pass without storing it, in any kernel and in any order.  Returns 0 (dropped) or 1/(1-p).
+struct DropoutParams {
+    unsigned long long seed;
+    unsigned stream;  // layer * 4 + site (0 embedding, 1 attention probabilities, 2 attn c_proj output, 3 mlp c_proj output)
+    float p;          // 0: no dropout (every helper short-circuits)
+};
+__host__ __device__ __forceinline__ unsigned philox_first_word(unsigned long long seed, unsigned stream, unsigned long long idx) {
+    unsigned c0 = (unsigned)idx, c1 = (unsigned)(idx >> 32), c2 = stream, c3 = 0u;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+__host__ __device__ __forceinline__ float dropout_mask(const DropoutParams& d, unsigned long long idx) {
+    if (d.p <= 0.f) return 1.f;
+    const float u = (float)(philox_first_word(d.seed, d.stream, idx) >> 8) * (1.0f / 16777216.0f);  // [0,1), 24 bits
+    return u < d.p ? 0.f : 1.0f / (1.0f - d.p);
+}
+
 }  // namespace rgrg

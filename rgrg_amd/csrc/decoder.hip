@@ -998,7 +998,7 @@ constexpr int TF_MAX_T = 255;
 template <int NT>  // key tiles held in registers: T + 1 <= 32 * NT
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
                                                            int kcol, const float* __restrict__ am, float* __restrict__ out,
-                                                           int S, int H, int T, float* __restrict__ lse) {
+                                                           int S, int H, int T, float* __restrict__ lse, const DropoutParams drop) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int QT = (T + 31) / 32;
     const int item = blockIdx.x * 4 + wave;
@@ -1087,7 +1087,10 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float pj = sc[kt][j] / sum;
+                float pj = sc[kt][j] / sum;
+                if (drop.p > 0.f)  // attn_dropout on the probabilities (training pass); index = [s][head][query][key]
+                    pj *= dropout_mask(drop, (((unsigned long long)s * H + hd) * T + min(iq, T - 1)) * NK +
+                                                 min(kt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half, NK - 1));
                 o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[j], pj, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[j], pj, o1, 0, 0, 0);
             }
@@ -1823,10 +1826,10 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
             const int items = S * d->H * ((T + 31) / 32);
             if (T + 1 <= 96)
                 hipLaunchKernelGGL(attn_prefill_kernel<3>, dim3((items + 3) / 4), dim3(256), 0, st, d->tf_qkv, d->ukv_out, d->ld_ukv,
-                                   l * 2 * D, attention_mask, d->tf_att, S, d->H, T, (float*)nullptr);
+                                   l * 2 * D, attention_mask, d->tf_att, S, d->H, T, (float*)nullptr, DropoutParams{0ull, 0u, 0.f});
             else
                 hipLaunchKernelGGL(attn_prefill_kernel<8>, dim3((items + 3) / 4), dim3(256), 0, st, d->tf_qkv, d->ukv_out, d->ld_ukv,
-                                   l * 2 * D, attention_mask, d->tf_att, S, d->H, T, (float*)nullptr);
+                                   l * 2 * D, attention_mask, d->tf_att, S, d->H, T, (float*)nullptr, DropoutParams{0ull, 0u, 0.f});
             RGRG_LAUNCH_CHECK();
         }
         if ((rc = tf_linear(d, w.attn_proj, d->tf_att, d->tf_x, d->tf_x, M, D, RGRG_ACT_NONE))) return rc;
@@ -1872,7 +1875,8 @@ int launch_colsum(const float* src, float* out, int R, int Cc, hipStream_t st);
 int attn_backward_max_t();
 int launch_attn_backward(const float* qkv, const float* ukv, int ld_ukv, int kcol, const float* am, const float* d_att,
                          const float* att, const float* lse, float* delta, float* d_qkv, float* d_ukv, int S, int H, int T,
-                         hipStream_t st);
+                         DropoutParams drop, hipStream_t st);
+int launch_dropout_add(const float* src, const float* resid, float* out, size_t n, DropoutParams drop, hipStream_t st);
 
 static int pad32(int n) { return (n + 31) / 32 * 32; }
 static int pad256(int n) { return (n + 255) / 256 * 256; }  // K granularity of the bf16 GEMM pipeline
@@ -1962,12 +1966,14 @@ static int tr_lin(rgrg_decoder* d, const Lin& l, bool transposed, const float* X
 }  // namespace rgrg
 
 extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, const int64_t* input_ids,
-                                         const float* attention_mask, int S, int T, float loss_scale, float* loss_out,
+                                         const float* attention_mask, int S, int T, float loss_scale, float dropout_p,
+                                         uint64_t dropout_seed, float* loss_out,
                                          float* grad_ukv_w, float* grad_ukv_b, float* grad_fst0_w, float* grad_fst0_b,
                                          float* grad_fst2_w, float* grad_fst2_b, void* stream) {
     RGRG_CHECK_ARG(d && feats && input_ids && loss_out && grad_ukv_w && grad_ukv_b && grad_fst0_w && grad_fst0_b && grad_fst2_w &&
                    grad_fst2_b);
     RGRG_CHECK_ARG(S > 0 && S <= d->max_seqs && T >= 2 && T <= attn_backward_max_t());
+    RGRG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || T + 1 <= 160));  // dropout: matrix-core attention only
     const int D = d->D, M = S * T, L = d->n_layer, V = d->V, VP = pad256(V), Sp = pad32(S), LD = d->ld_ukv;
     int rc;
     if ((rc = tf_reserve(d, (size_t)M)) || (rc = tr_reserve(d, (size_t)M, (size_t)S))) return rc;
@@ -1987,6 +1993,12 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
     hipLaunchKernelGGL(embed_seq_ln_kernel, dim3(M), dim3(256), 0, st, d->wte, ids, T, d->layers[0].ln1_g, d->layers[0].ln1_b,
                        xs(0), d->tf_xn, D);
     RGRG_LAUNCH_CHECK();
+    if (dropout_p > 0.f) {  // self.drop on the embeddings (language_model.py:311), then ln_1 of layer 0 again
+        if ((rc = launch_dropout_add(xs(0), nullptr, xs(0), MD, DropoutParams{dropout_seed, 0u, dropout_p}, st))) return rc;
+        hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, xs(0), nullptr, nullptr, 1, 0, d->layers[0].ln1_g,
+                           d->layers[0].ln1_b, d->tf_xn, D);
+        RGRG_LAUNCH_CHECK();
+    }
     const int items = S * d->H * ((T + 31) / 32);
     for (int l = 0; l < L; ++l) {
         const LayerW& w = d->layers[l];
@@ -1997,19 +2009,27 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
         if ((rc = tr_lin(d, w.c_attn, false, d->tf_xn, nullptr, qkv, M, 3 * D))) return rc;
         float* att = d->tr_att + (size_t)l * MD;              // attention output and row log-sum-exp, kept per layer
         float* lse = d->tr_lse + (size_t)l * M * d->H;
+        const DropoutParams dp_att{dropout_seed, (unsigned)(l * 4 + 1), dropout_p}, dp_r1{dropout_seed, (unsigned)(l * 4 + 2), dropout_p},
+            dp_r2{dropout_seed, (unsigned)(l * 4 + 3), dropout_p};
         if (T + 1 <= 96)
             hipLaunchKernelGGL(attn_prefill_kernel<3>, dim3((items + 3) / 4), dim3(256), 0, st, qkv, d->ukv_out, LD, l * 2 * D,
-                               attention_mask, att, S, d->H, T, lse);
+                               attention_mask, att, S, d->H, T, lse, dp_att);
         else
             hipLaunchKernelGGL(attn_prefill_kernel<8>, dim3((items + 3) / 4), dim3(256), 0, st, qkv, d->ukv_out, LD, l * 2 * D,
-                               attention_mask, att, S, d->H, T, lse);
+                               attention_mask, att, S, d->H, T, lse, dp_att);
         RGRG_LAUNCH_CHECK();
-        if ((rc = tr_lin(d, w.attn_proj, false, att, xs(2 * l), xs(2 * l + 1), M, D))) return rc;
+        if (dropout_p > 0.f) {  // resid_dropout: x_mid = x_in + dropout(c_proj(att))
+            if ((rc = tr_lin(d, w.attn_proj, false, att, nullptr, d->tr_dbig, M, D))) return rc;
+            if ((rc = launch_dropout_add(d->tr_dbig, xs(2 * l), xs(2 * l + 1), MD, dp_r1, st))) return rc;
+        } else if ((rc = tr_lin(d, w.attn_proj, false, att, xs(2 * l), xs(2 * l + 1), M, D))) return rc;
         hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, xs(2 * l + 1), nullptr, nullptr, 1, 0, w.ln2_g, w.ln2_b, d->tf_xn, D);
         RGRG_LAUNCH_CHECK();
         if ((rc = tr_lin(d, w.c_fc, false, d->tf_xn, nullptr, ffpre, M, 4 * D))) return rc;
         if ((rc = launch_gelu_apply(ffpre, d->tr_ff, (size_t)M * 4 * D, st))) return rc;
-        if ((rc = tr_lin(d, w.mlp_proj, false, d->tr_ff, xs(2 * l + 1), xs(2 * l + 2), M, D))) return rc;
+        if (dropout_p > 0.f) {  // mlp dropout: x_out = x_mid + dropout(c_proj(gelu(c_fc(.))))
+            if ((rc = tr_lin(d, w.mlp_proj, false, d->tr_ff, nullptr, d->tr_dxn, M, D))) return rc;
+            if ((rc = launch_dropout_add(d->tr_dxn, xs(2 * l + 1), xs(2 * l + 2), MD, dp_r2, st))) return rc;
+        } else if ((rc = tr_lin(d, w.mlp_proj, false, d->tr_ff, xs(2 * l + 1), xs(2 * l + 2), M, D))) return rc;
         hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, xs(2 * l + 2), nullptr, nullptr, 1, 0, ng, nb, d->tf_xn, D);
         RGRG_LAUNCH_CHECK();
     }
@@ -2037,15 +2057,28 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
         const LayerW& w = d->layers[l];
         float* qkv = d->tr_qkv + (size_t)l * M * 3 * D;
         float* ffpre = d->tr_ffpre + (size_t)l * M * 4 * D;
-        // x_out = x_mid + mlp_proj(gelu(c_fc(ln_2(x_mid))))
-        if ((rc = tr_lin(d, w.mlp_proj, true, d->tr_dx, nullptr, d->tr_dbig, M, 4 * D))) return rc;
+        // x_out = x_mid + dropout(mlp_proj(gelu(c_fc(ln_2(x_mid)))))
+        const float* dbr = d->tr_dx;  // gradient entering the branch = dx * mask (same mask as the forward pass)
+        if (dropout_p > 0.f) {
+            if ((rc = launch_dropout_add(d->tr_dx, nullptr, d->tf_att, MD, DropoutParams{dropout_seed, (unsigned)(l * 4 + 3), dropout_p}, st)))
+                return rc;
+            dbr = d->tf_att;
+        }
+        if ((rc = tr_lin(d, w.mlp_proj, true, dbr, nullptr, d->tr_dbig, M, 4 * D))) return rc;
         if ((rc = launch_gelu_backward(d->tr_dbig, ffpre, (size_t)M * 4 * D, st))) return rc;
         if ((rc = tr_lin(d, w.c_fc, true, d->tr_dbig, nullptr, d->tr_dxn, M, D))) return rc;
         if ((rc = launch_ln_backward(d->tr_dxn, xs(2 * l + 1), w.ln2_g, d->tr_dx, M, D, 1, st))) return rc;
-        // x_mid = x_in + attn_proj(attention(c_attn(ln_1(x_in)), uk(img), uv(img)))
-        if ((rc = tr_lin(d, w.attn_proj, true, d->tr_dx, nullptr, d->tf_att, M, D))) return rc;
+        // x_mid = x_in + dropout(attn_proj(attention(c_attn(ln_1(x_in)), uk(img), uv(img))))
+        dbr = d->tr_dx;
+        if (dropout_p > 0.f) {
+            if ((rc = launch_dropout_add(d->tr_dx, nullptr, d->tr_dxn, MD, DropoutParams{dropout_seed, (unsigned)(l * 4 + 2), dropout_p}, st)))
+                return rc;
+            dbr = d->tr_dxn;
+        }
+        if ((rc = tr_lin(d, w.attn_proj, true, dbr, nullptr, d->tf_att, M, D))) return rc;
         if ((rc = launch_attn_backward(qkv, d->ukv_out, LD, l * 2 * D, attention_mask, d->tf_att, d->tr_att + (size_t)l * MD,
-                                       d->tr_lse + (size_t)l * M * d->H, d->tr_delta, d->tr_dbig, d->tr_dukv, S, d->H, T, st)))
+                                       d->tr_lse + (size_t)l * M * d->H, d->tr_delta, d->tr_dbig, d->tr_dukv, S, d->H, T,
+                                       DropoutParams{dropout_seed, (unsigned)(l * 4 + 1), dropout_p}, st)))
             return rc;
         if ((rc = tr_lin(d, w.c_attn, true, d->tr_dbig, nullptr, d->tr_dxn, M, D))) return rc;
         if ((rc = launch_ln_backward(d->tr_dxn, xs(2 * l), w.ln1_g, d->tr_dx, M, D, 1, st))) return rc;

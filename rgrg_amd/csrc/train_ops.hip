@@ -51,6 +51,19 @@ __global__ __launch_bounds__(256) void relu_backward_kernel(float* __restrict__ 
         if (!(h[i] > 0.f)) d[i] = 0.f;
 }
 
+// out = (resid ? resid : 0) + src * mask(index)  (element index = flat position; src may alias out)
+__global__ __launch_bounds__(256) void dropout_add_kernel(const float* __restrict__ src, const float* __restrict__ resid,
+                                                          float* __restrict__ out, size_t n, const DropoutParams drop) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = src[i] * dropout_mask(drop, i);
+        out[i] = resid ? resid[i] + v : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, size_t n, const DropoutParams drop) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = dropout_mask(drop, i);
+}
+
 // LayerNorm backward w.r.t. its input (weight / bias are frozen): one workgroup per row, D == 1024.
 //   xhat = (x - mean) rstd ; t = dy * g ; dx = rstd (t - mean(t) - xhat mean(t xhat)) ; out = (acc ? out : 0) + dx
 __global__ __launch_bounds__(256) void ln_backward_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -292,7 +305,7 @@ template <int NT>  // key tiles: T + 1 <= 32 * NT
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
                                                           int kcol, const float* __restrict__ am, const float* __restrict__ d_att,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          float* __restrict__ d_qkv, int S, int H, int T) {
+                                                          float* __restrict__ d_qkv, int S, int H, int T, const DropoutParams drop) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int QT = (T + 31) / 32;
     const int item = blockIdx.x * 4 + wave;
@@ -346,7 +359,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
                     const bool allowed = (c == 0) || (c - 1 <= iq);
                     const float addm = (c == 0 || !am) ? 0.f : (1.0f - am[(size_t)s * T + c - 1]) * -10000.0f;
                     const float pr = expf((allowed ? aS[r] / 8.0f : -1e4f) + addm - lse_q);
-                    dsv = allowed ? pr * (aP[r] - delta_q) / 8.0f : 0.f;
+                    // attn_dropout: O = (P * mask) V  =>  dP = (dO . V) * mask ; delta = rowsum(dO . O) already includes it
+                    const float mk = dropout_mask(drop, (((unsigned long long)s * H + hd) * T + iqc) * NK + c);
+                    dsv = allowed ? pr * (aP[r] * mk - delta_q) / 8.0f : 0.f;
                 }
                 ds[kt][r] = dsv;
             }
@@ -385,7 +400,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
                                                            int kcol, const float* __restrict__ am, const float* __restrict__ d_att,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           float* __restrict__ d_qkv, float* __restrict__ d_ukv, int S, int H, int T) {
+                                                           float* __restrict__ d_qkv, float* __restrict__ d_ukv, int S, int H, int T,
+                                                           const DropoutParams drop) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NK = T + 1, D = H * 64;
     const int KT = (NK + 31) / 32, QT = (T + 31) / 32;
@@ -438,9 +454,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
                 const float lse_i = lse[((size_t)s * T + i) * H + hd], delta_i = delta[((size_t)s * T + i) * H + hd];
                 const bool allowed = (c == 0) || (c - 1 <= i);
                 pr = expf((allowed ? aS[r] / 8.0f : -1e4f) + addm - lse_i);
-                dsv = allowed ? pr * (aP[r] - delta_i) / 8.0f : 0.f;
+                const float mk = dropout_mask(drop, (((unsigned long long)s * H + hd) * T + i) * NK + c);
+                dsv = allowed ? pr * (aP[r] * mk - delta_i) / 8.0f : 0.f;
+                pr *= mk;  // dV^T = dO^T (P * mask)
             }
-            aS[r] = pr;   // P   [query r][key col]
+            aS[r] = pr;   // P (dropped) [query r][key col]
             aP[r] = dsv;  // dS
             const float* qp = qkv + ((size_t)s * T + ic) * 3 * D + hd * 64;
             const float* gp = d_att + ((size_t)s * T + ic) * D + hd * 64;
@@ -533,6 +551,11 @@ int launch_gelu_backward(float* d, const float* pre, size_t n, hipStream_t st) {
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
+int launch_dropout_add(const float* src, const float* resid, float* out, size_t n, DropoutParams drop, hipStream_t st) {
+    hipLaunchKernelGGL(dropout_add_kernel, dim3(blocks_for(n)), dim3(256), 0, st, src, resid, out, n, drop);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
 int launch_relu_backward(float* d, const float* h, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(relu_backward_kernel, dim3(blocks_for(n)), dim3(256), 0, st, d, h, n);
     RGRG_LAUNCH_CHECK();
@@ -564,7 +587,7 @@ int launch_colsum(const float* src, float* out, int R, int Cc, hipStream_t st) {
 int attn_backward_max_t() { return 4 * AB_KMAX - 1 < 160 ? 4 * AB_KMAX - 1 : 160; }
 int launch_attn_backward(const float* qkv, const float* ukv, int ld_ukv, int kcol, const float* am, const float* d_att,
                          const float* att, const float* lse, float* delta, float* d_qkv, float* d_ukv, int S, int H, int T,
-                         hipStream_t st) {
+                         DropoutParams drop, hipStream_t st) {
     RGRG_CHECK_ARG(T >= 1 && T <= attn_backward_max_t());
     const int NK = T + 1;
     static const bool force_valu = [] { const char* e = getenv("RGRG_ATTN_BWD_VALU"); return e && atoi(e) != 0; }();
@@ -575,16 +598,17 @@ int launch_attn_backward(const float* qkv, const float* ukv, int ld_ukv, int kco
         const int qitems = S * H * ((T + 31) / 32), kitems = S * H * ((NK + 31) / 32);
         if (NK <= 96)
             hipLaunchKernelGGL(attn_bwd_dq_kernel<3>, dim3((qitems + 3) / 4), dim3(256), 0, st, qkv, ukv, ld_ukv, kcol, am, d_att, lse,
-                               delta, d_qkv, S, H, T);
+                               delta, d_qkv, S, H, T, drop);
         else
             hipLaunchKernelGGL(attn_bwd_dq_kernel<5>, dim3((qitems + 3) / 4), dim3(256), 0, st, qkv, ukv, ld_ukv, kcol, am, d_att, lse,
-                               delta, d_qkv, S, H, T);
+                               delta, d_qkv, S, H, T, drop);
         RGRG_LAUNCH_CHECK();
         hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((kitems + 3) / 4), dim3(256), 0, st, qkv, ukv, ld_ukv, kcol, am, d_att, lse, delta,
-                           d_qkv, d_ukv, S, H, T);
+                           d_qkv, d_ukv, S, H, T, drop);
         RGRG_LAUNCH_CHECK();
         return RGRG_OK;
     }
+    RGRG_CHECK_ARG(drop.p == 0.f);  // the LDS fallback (161 keys, or forced) has no dropout
     const size_t lds = ((size_t)NK * 65 * 2 + 2 * AB_QB * 64 + 2 * (size_t)AB_QB * NK + NK) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
@@ -623,6 +647,14 @@ extern "C" int rgrg_bce_with_logits_masked_backward_f32(const float* logits, con
     RGRG_CHECK_ARG(logits && mask && target && dlogits && n > 0 && ld >= 1);
     hipLaunchKernelGGL(bce_backward_kernel, dim3(1), dim3(256), 0, as_stream(stream), logits, mask, target, pos_weight, n, scale,
                        dlogits, ld);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+extern "C" int rgrg_dropout_mask_f32(uint64_t seed, uint32_t stream_id, float p, int64_t n, float* out, void* stream) {
+    RGRG_CHECK_ARG(out && n > 0 && p >= 0.f && p < 1.f);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks_for((size_t)n)), dim3(256), 0, as_stream(stream), out, (size_t)n,
+                       DropoutParams{seed, stream_id, p});
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }

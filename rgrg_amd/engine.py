@@ -514,7 +514,7 @@ class HipEngine:
         return logits, loss
 
     def lm_loss_grad(self, feats: Tensor, input_ids: Tensor, attention_mask: Optional[Tensor], loss_scale: float = 1.0,
-                     bf16: bool = False):
+                     bf16: bool = False, dropout_p: float = 0.0, dropout_seed: int = 0):
         """Teacher-forced loss and its gradients w.r.t. the trainable decoder weights (rgrg_decoder_lm_loss_grad):
         -> (loss, {"ukv_w" [L*2*1024,1024], "ukv_b", "fst0_w", "fst0_b", "fst2_w", "fst2_b"}).  bf16=True (torch.autocast,
         as the reference's training loop uses): the frozen-weight GEMMs of forward and backward run on the bf16 MFMA
@@ -523,8 +523,8 @@ class HipEngine:
         S, T = input_ids.shape
         if feats.shape[0] != S:
             raise ValueError(f"image_hidden_states has {feats.shape[0]} rows, input_ids {S}")
-        if T > 160:
-            raise NotImplementedError("the HIP training pass supports sequences of up to 160 tokens")
+        if T > 160 or (dropout_p > 0 and T > 159):
+            raise NotImplementedError("the HIP training pass supports sequences of up to 160 tokens (159 with dropout)")
         lo, hi = int(input_ids.min().item()), int(input_ids.max().item())
         if lo < 0 or hi >= self.vocab:
             raise IndexError("index out of range in self")
@@ -539,10 +539,19 @@ class HipEngine:
              "fst2_w": torch.empty((1024, 1024), dtype=torch.float32, device=dev), "fst2_b": torch.empty((1024,), dtype=torch.float32, device=dev)}
         loss = torch.empty((), dtype=torch.float32, device=dev)
         _hip.check(self.lib.rgrg_decoder_lm_loss_grad(dec, _hip.ptr(feats), _hip.ptr(ids), None if am is None else _hip.ptr(am), S, T,
-                                                      float(loss_scale), _hip.ptr(loss), _hip.ptr(g["ukv_w"]), _hip.ptr(g["ukv_b"]),
+                                                      float(loss_scale), float(dropout_p), int(dropout_seed) & (2 ** 64 - 1), _hip.ptr(loss),
+                                                      _hip.ptr(g["ukv_w"]), _hip.ptr(g["ukv_b"]),
                                                       _hip.ptr(g["fst0_w"]), _hip.ptr(g["fst0_b"]), _hip.ptr(g["fst2_w"]),
                                                       _hip.ptr(g["fst2_b"]), _stream()), "rgrg_decoder_lm_loss_grad")
         return loss, g
+
+    def dropout_mask(self, seed: int, layer: int, site: int, p: float, shape) -> Tensor:
+        """The training pass's dropout mask of one site (0 or 1/(1-p)); sites: 0 embedding, 1 attention probabilities
+        [S,16,T,T+1], 2 attn c_proj output, 3 mlp c_proj output ([S*T,1024])."""
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        _hip.check(self.lib.rgrg_dropout_mask_f32(int(seed) & (2 ** 64 - 1), layer * 4 + site, float(p), out.numel(), _hip.ptr(out),
+                                                  _stream()), "rgrg_dropout_mask_f32")
+        return out
 
     def sync_trainable(self, state_dict: Dict[str, Tensor]) -> None:
         """Copy the (optimizer-updated) trainable decoder parameters into the engine's buffers and rebuild the

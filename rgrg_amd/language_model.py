@@ -84,7 +84,9 @@ class _TeacherForcedLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lm, input_ids, attention_mask, feats, *params):
         low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
-        loss, g = lm.engine().lm_loss_grad(feats, input_ids, attention_mask, bf16=bool(low))
+        lm.dropout_seed += 1  # a fresh counter-based stream per pass
+        loss, g = lm.engine().lm_loss_grad(feats, input_ids, attention_mask, bf16=bool(low), dropout_p=float(lm.dropout_p),
+                                           dropout_seed=lm.dropout_seed)
         D, grads = 1024, []
         for l in range(len(lm.gpt.h)):  # same order as LanguageModel.trainable_parameters()
             grads += [g["ukv_w"][(2 * l) * D:(2 * l + 1) * D], g["ukv_b"][(2 * l) * D:(2 * l + 1) * D],
@@ -120,6 +122,11 @@ class LanguageModel(EngineOwner):
         self.final_layernorm = self.gpt.ln_f
         self.gpt2_blocks = nn.ModuleList(nn.ModuleList([b.ln_1, b.attn, b.ln_2, b.mlp]) for b in self.gpt.h)
         self.feature_space_transformation_nn = nn.Sequential(nn.Linear(1024, 1024), nn.ReLU(), nn.Linear(1024, 1024))
+        # train-mode dropout of GPT-2 (embd / attention / residual / MLP, all 0.1 in the gpt2-medium config the reference
+        # loads).  Counter-based (seed, site, element) masks: same distribution as the reference's, not the same draws.
+        # Set dropout_p = 0.0 for a deterministic training pass.
+        self.dropout_p = 0.1
+        self.dropout_seed = 0x5EED0000
 
     def forward(self, input_ids: torch.LongTensor, attention_mask: torch.FloatTensor, image_hidden_states: torch.FloatTensor,
                 return_loss: bool = False, past_key_values=None, position_ids: Optional[torch.LongTensor] = None,

@@ -377,6 +377,7 @@ def _lm_train_model():
     m = rgrg_amd.ReportGenerationModel(pretrain_without_lm_model=False)
     m.load_state_dict(synth_sd("ragged"))
     m.to(torch.device("cuda", 0))
+    m.language_model.dropout_p = 0.0  # deterministic pass unless a test asks for dropout
     return m
 
 
@@ -577,3 +578,58 @@ def test_detector_fc6_bf16_under_autocast_close_to_fp32():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         _, det_a, _, cd_a = m.object_detector(images)
     assert torch.equal(cd_a, cd16) and torch.equal(det_a["top_region_boxes"], d16["top_region_boxes"])
+
+
+def test_dropout_masks_are_bernoulli_reproducible_and_stream_separated():
+    m = gpu_model("ragged")
+    eng = m.engine()
+    a = eng.dropout_mask(1234, 3, 2, 0.1, (1 << 20,))
+    assert set(a.unique().tolist()) == {0.0, float(torch.tensor(1.0 / 0.9, dtype=torch.float32))}
+    keep = (a > 0).float().mean().item()
+    assert abs(keep - 0.9) < 5 * (0.09 / (1 << 20)) ** 0.5            # 5 sigma of a Bernoulli(0.9) mean
+    assert torch.equal(a, eng.dropout_mask(1234, 3, 2, 0.1, (1 << 20,)))
+    for other in (eng.dropout_mask(1235, 3, 2, 0.1, (1 << 20,)), eng.dropout_mask(1234, 3, 3, 0.1, (1 << 20,)),
+                  eng.dropout_mask(1234, 4, 2, 0.1, (1 << 20,))):
+        agree = ((a > 0) == (other > 0)).float().mean().item()
+        assert abs(agree - 0.82) < 0.01                                    # independent: 0.9^2 + 0.1^2
+    assert bool((eng.dropout_mask(1, 0, 0, 0.0, (1000,)) == 1).all())
+    b = (a[:-1] > 0) & (a[1:] > 0)                                         # no visible correlation between neighbours
+    assert abs(b.float().mean().item() - 0.81) < 0.005
+
+
+def test_lm_training_pass_with_dropout_matches_oracle_with_the_same_masks():
+    """Train-mode dropout (p = 0.25 here so that it matters) at all four GPT-2 sites: the masks the HIP pass uses are
+    exported (rgrg_dropout_mask_f32) and applied inside the oracle's forward; loss and all gradients must then agree
+    as in the deterministic case - i.e. forward and BOTH attention-backward kernels recompute identical masks."""
+    m = _lm_train_model()
+    lm = m.language_model
+    lm.train()
+    lm.dropout_p = 0.25
+    g = torch.Generator().manual_seed(77)
+    S, T = 4, 40
+    ids = torch.randint(0, 50257, (S, T), generator=g)
+    lens = torch.randint(2, T + 1, (S,), generator=g)
+    lens[0] = T
+    am = (torch.arange(T)[None, :] < lens[:, None]).to(torch.int64)
+    feats = torch.randn((S, 1024), generator=g)
+    seed = lm.dropout_seed + 1                      # the seed the next pass will use
+    loss = lm(ids.clone().to(DEV), am.to(DEV), feats.to(DEV), return_loss=True)
+    loss.backward()
+    assert lm.dropout_seed == seed
+    eng = m.engine()
+    masks = {(0, 0): eng.dropout_mask(seed, 0, 0, 0.25, (S, T, 1024)).cpu()}
+    for l in range(24):
+        masks[(l, 1)] = eng.dropout_mask(seed, l, 1, 0.25, (S, 16, T, T + 1)).cpu()
+        masks[(l, 2)] = eng.dropout_mask(seed, l, 2, 0.25, (S, T, 1024)).cpu()
+        masks[(l, 3)] = eng.dropout_mask(seed, l, 3, 0.25, (S, T, 1024)).cpu()
+    o_loss, o_grads = o_lm.lm_loss_and_grads(synth_sd("ragged"), ids, am, feats, drop_masks=masks)
+    plain, _ = o_lm.lm_loss_and_grads(synth_sd("ragged"), ids, am, feats)
+    assert abs(o_loss.item() - plain.item()) > 1e-3                     # dropout really changed the loss
+    assert abs(loss.item() - o_loss.item()) <= 2e-4, (loss.item(), o_loss.item())
+    named = dict(m.named_parameters())
+    worst = max(_rel(named[k].grad.cpu(), og) for k, og in o_grads.items())
+    assert worst <= 2e-3, worst
+    # a second pass draws different masks
+    loss2 = lm(ids.clone().to(DEV), am.to(DEV), feats.to(DEV), return_loss=True)
+    assert loss2.item() != loss.item()
+    m.invalidate_engine()
