@@ -24,9 +24,7 @@ class AdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if self._lib is None:
-            self._lib = _hip.load()
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = None
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -34,6 +32,10 @@ class AdamW(torch.optim.Optimizer):
                     continue
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                     raise _hip.RgrgHipError("rgrg_amd.optim.AdamW needs contiguous fp32 parameters on the GPU (no CPU fallback)")
+                if self._lib is None:
+                    self._lib = _hip.load()
+                if stream is None:
+                    stream = torch.cuda.current_stream().cuda_stream
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 st = self.state[p]
                 if not st:

@@ -133,3 +133,34 @@ def test_product_never_imports_the_oracle():
             if fn.endswith(".py"):
                 src = open(os.path.join(root, fn)).read()
                 assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_training_and_preprocessing_host_modules_fail_loudly_without_a_gpu(model):
+    """The training / preprocessing host code has no CPU path either, and mirrors the reference's trainable set."""
+    import numpy as np
+    from rgrg_amd import optim
+    from rgrg_amd.preprocess import preprocess_image
+    ps = model.trainable_parameters()
+    assert len(ps) == 112 and sum(p.numel() for p in ps) == 52480000 + 2 * 590593  # decoder uk/uv/fst + two classifiers
+    assert all(p.requires_grad for p in ps)
+    frozen = dict(model.named_parameters())["language_model.gpt_with_lm_head.transformer.h.0.attn.c_attn.weight"]
+    assert not frozen.requires_grad                                     # GPT-2 itself is frozen (language_model.py:207-213)
+    p = torch.nn.Parameter(torch.zeros(8))
+    p.grad = torch.ones(8)
+    with pytest.raises(_hip.RgrgHipError, match="no CPU fallback"):
+        optim.AdamW([p], lr=1e-3).step()
+    with pytest.raises(ValueError):
+        optim.AdamW([p], lr=-1.0)
+    img = np.zeros((1024, 768), np.uint8)
+    with pytest.raises(_hip.RgrgHipError, match="no CPU fallback"):
+        preprocess_image(img, "cpu")
+    with pytest.raises(ValueError):
+        preprocess_image(img.astype(np.float32), "cpu")
+    lm = model.language_model
+    ids, am = torch.zeros((2, 5), dtype=torch.int64), torch.ones((2, 5), dtype=torch.int64)
+    with pytest.raises(NotImplementedError, match="use_cache"):
+        lm(ids, am, torch.zeros(2, 1024), return_loss=False, use_cache=True)
+    with pytest.raises(NotImplementedError, match="position_ids"):
+        lm(ids, am, torch.zeros(2, 1024), return_loss=True, position_ids=torch.ones((2, 5), dtype=torch.int64))
+    assert lm(ids, am, torch.zeros(2, 1024), return_loss=False) is None   # language_model.py:396-399
+    assert lm.dropout_p == 0.1                                            # GPT-2's train-mode dropout, as in the reference
