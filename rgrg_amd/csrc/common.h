@@ -50,6 +50,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Wave-wide sum in 7 VALU instructions (DPP butterflies inside the 16-lane rows, row_bcast across rows, readlane),
+// ~10x less latency than six ds_bpermute round trips; the result is wave-uniform.  Summation order differs from
+// wave_sum: use one or the other consistently where bit-reproducibility against another kernel matters.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_get<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_get<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_get<0x140, 0xf>(v);  // row_mirror: every lane of a 16-lane row holds the row sum
+    v += dpp_get<0x142, 0xa>(v);  // row_bcast15 -> rows 1, 3
+    v += dpp_get<0x143, 0xc>(v);  // row_bcast31 -> rows 2, 3: row 3 holds the wave sum
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -47,6 +47,14 @@ static int skinny_max_rows() {
         if (v > SKINNY_MAX_ROWS) v = SKINNY_MAX_ROWS; if (v < 32) v = 32; }
     return v;
 }
+// Decode plan for <= 128 token rows.  1 (experimental, RGRG_DECODE_PLAN=1): fused - 5 launches per layer (LayerNorm, split-K combine and the
+// embedding are rebuilt by the consumer GEMM while it stages its activations; attn_proj keeps the whole K in one
+// workgroup and adds bias + residual itself).  0 (default): the round-1 sequence (7 launches per layer).
+static int decode_plan() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("RGRG_DECODE_PLAN"); v = e ? atoi(e) : 0; }
+    return v;
+}
 constexpr int BOS_ID = 50256, EOS_ID = 50256, PAD_ID = 50256;
 constexpr float LN_EPS = 1e-5f;
 
@@ -339,6 +347,330 @@ __global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32_wide(const SkinnyArg
     }
 }
 
+
+// ------------------------------------------------------------------ LayerNorm-fused skinny GEMMs (fused decode plan)
+// Where the 32 activation rows of a K = 1024 GEMM come from.  The fused decode plan has no LayerNorm /
+// split-K-combine / embedding launches: every workgroup of the CONSUMER GEMM rebuilds its activation tile while
+// staging it into LDS (the tile is staged by every workgroup anyway):
+//     v   = x[row] (+ pbias + sum_ks part[ks][row], fixed order)        residual stream after the producer GEMM
+//         | wte[token(row)] + wte[step]                                  embedding (quirk language_model.py:307)
+//     xn  = LayerNorm(v) * g + b                                         (nn.LayerNorm(1024, eps 1e-5), two-pass)
+// Workgroup (0,0) also writes v to `xout` - the residual stream the next residual add reads.  `xout` never
+// aliases `x` (other workgroups are still reading it): the plan ping-pongs two buffers.
+struct XSrc {
+    const float* x;
+    const float* part;   // [row tile][KS][32][ldp] partial sums of the producer GEMM, or null
+    const float* pbias;  // bias of the producer GEMM (added with the partials)
+    int KS, ldp;
+    float* xout;
+    const float* g;      // LayerNorm weight / bias; null: no LayerNorm (plain staging)
+    const float* b;
+    const float* wte;    // embedding mode when non-null
+    const long long* ids;
+    int ld_ids;
+    const int* step;
+    const int* tok_override;
+};
+
+constexpr int LNG_K = 1024, LNG_LDX = LNG_K + 4, LNG_XQ = 16;  // 32 rows x 256 float4 over 512 threads
+
+// Row tile `mt` (32 rows x 1024) of the consumer GEMM's activations, first into registers (stage_load: thread t
+// holds column group t & 255 of rows (t >> 8) + 2q, q = 0..15), then into smem[32][LNG_LDX] + LayerNorm in place
+// (stage_finish, ends with a __syncthreads()).  512 threads.  MODE is a compile-time switch so that the 16..80 loads
+// of a thread are branch-free: 0 = x, 1 = x + pbias + 4 split-K partials, 2 / 3 = embedding of ids / of tok_override.  Rows >= M are read like any
+// other row (every buffer is padded to a multiple of 32 rows) and produce values that never reach a stored output.
+constexpr int XS_PLAIN = 0, XS_COMBINE4 = 1, XS_EMBED = 2, XS_EMBED_TOK = 3;
+// Order of the requests matters because vector loads return IN ORDER: the activation rows go first, then the
+// LayerNorm parameters, and the caller's HBM weight stream (`issue_weights`, called once) last - right after the last
+// activation request - so that no wait on an activation load ever waits for an HBM miss.
+template <int MODE, typename F>
+__device__ __forceinline__ void stage_load(f32x4 (&xr)[LNG_XQ], f32x4 (&gg)[4], f32x4 (&bb)[4], const XSrc& xs, int mt,
+                                           F&& issue_weights) {
+    const int tid = threadIdx.x;
+    // LayerNorm parameters (first touch per XCD comes from HBM: requested AFTER the activations, which the L2 / MALL
+    // serve faster and which are needed first), then the weight stream
+    auto issue_tail = [&]() {
+        if (xs.g) {
+            const int lane = tid & 63;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                gg[i] = *reinterpret_cast<const f32x4*>(xs.g + lane * 4 + i * 256);
+                bb[i] = *reinterpret_cast<const f32x4*>(xs.b + lane * 4 + i * 256);
+            }
+        }
+        issue_weights();
+    };
+    const int c4 = tid & 255, r0 = mt * 32 + (tid >> 8);
+    // buffer loads: descriptor (SGPRs, built from kernel arguments) + ONE 32-bit per-thread offset + a scalar offset
+    // per load - the 16..80 loads of a thread share one address register instead of holding 80 pointer pairs
+    auto ldb = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+    };
+    const unsigned voff_x = (unsigned)(tid >> 8) * (LNG_K * 4u) + (unsigned)c4 * 16u;
+    if constexpr (MODE == XS_EMBED || MODE == XS_EMBED_TOK) {
+        const int t = *xs.step;
+        long long tok[LNG_XQ];
+#pragma unroll
+        for (int q = 0; q < LNG_XQ; ++q) {
+            if constexpr (MODE == XS_EMBED_TOK) tok[q] = (long long)xs.tok_override[r0 + 2 * q];  // beam search feeds the beam tokens
+            else tok[q] = xs.ids[(size_t)(r0 + 2 * q) * xs.ld_ids + t];
+        }
+        const f32x4 pos = reinterpret_cast<const f32x4*>(xs.wte + (size_t)t * LNG_K)[c4];
+        f32x4 e[LNG_XQ];
+#pragma unroll
+        for (int q = 0; q < LNG_XQ; ++q) e[q] = reinterpret_cast<const f32x4*>(xs.wte + (size_t)tok[q] * LNG_K)[c4];
+        __builtin_amdgcn_sched_barrier(0);
+        issue_tail();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < LNG_XQ; ++q) xr[q] = e[q] + pos;
+    } else {
+        const unsigned xrow0 = (unsigned)mt * 32 * LNG_K * 4;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs.x), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < LNG_XQ; ++q) xr[q] = ldb(rx, voff_x, xrow0 + (unsigned)q * (2 * LNG_K * 4));
+        if constexpr (MODE == XS_PLAIN) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_tail();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (MODE == XS_COMBINE4) {
+            // 4 partial sums per element = 64 more 16-byte loads per thread, software-pipelined over the K slices:
+            // slice ks + 1 is requested before slice ks is added.  Per element: ((((x + p0) + p1) + p2) + p3) + bias.
+            // The producer has N = 1024 outputs: partial rows are LNG_K floats (checked by the host).
+            const f32x4 pb = reinterpret_cast<const f32x4*>(xs.pbias)[c4];
+            constexpr unsigned ksz = PAD_ROWS * LNG_K * 4, rsz2 = LNG_K * 8;  // bytes: one K slice, two rows
+            const unsigned prow0 = (unsigned)mt * 4 * ksz;
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs.part), 0, 0x7fffffff, 0x00020000);
+            // round r = (K slice r >> 1, rows half r & 1): 8 loads per round, two rounds in flight
+            constexpr int HQ = LNG_XQ / 2;
+            f32x4 pa[HQ], pc[HQ];
+#define XS_ISSUE(buf, r) _Pragma("unroll") for (int q = 0; q < HQ; ++q) buf[q] = ldb(rp, voff_x, prow0 + ((r) >> 1) * ksz + (((r) & 1) * HQ + q) * rsz2)
+// the empty asm pins each add between its two sched_barriers: without it the pure adds sink down to the LDS store and
+// all 80 loaded values stay live (spills)
+#define XS_ADD(buf, r) _Pragma("unroll") for (int q = 0; q < HQ; ++q) { xr[((r) & 1) * HQ + q] += buf[q]; asm volatile("" : "+v"(xr[((r) & 1) * HQ + q])); }
+            XS_ISSUE(pa, 0);
+            XS_ISSUE(pc, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            XS_ADD(pa, 0); XS_ISSUE(pa, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            XS_ADD(pc, 1); XS_ISSUE(pc, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            XS_ADD(pa, 2); XS_ISSUE(pa, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            XS_ADD(pc, 3); XS_ISSUE(pc, 5);
+            __builtin_amdgcn_sched_barrier(0);
+            XS_ADD(pa, 4); XS_ISSUE(pa, 6);
+            __builtin_amdgcn_sched_barrier(0);
+            XS_ADD(pc, 5); XS_ISSUE(pc, 7);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_tail();
+            __builtin_amdgcn_sched_barrier(0);
+            XS_ADD(pa, 6);
+            __builtin_amdgcn_sched_barrier(0);
+            XS_ADD(pc, 7);
+#undef XS_ISSUE
+#undef XS_ADD
+#pragma unroll
+            for (int q = 0; q < LNG_XQ; ++q) xr[q] += pb;
+        }
+    }
+}
+
+// `nrows_lds` < 32 (wide kernel): rows beyond it are not written to LDS.  `writer`: this workgroup also stores the
+// (combined / embedded) residual stream rows to xs.xout.
+__device__ __forceinline__ void stage_finish(float* smem, const f32x4 (&xr)[LNG_XQ], const XSrc& xs, int mt, int M,
+                                             int nrows_lds, bool writer, const f32x4 (&gg)[4], const f32x4 (&bb)[4]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c4 = tid & 255, r0 = mt * 32 + (tid >> 8);
+#pragma unroll
+    for (int q = 0; q < LNG_XQ; ++q) {
+        const int lrow = (tid >> 8) + 2 * q;
+        if (writer && xs.xout && r0 + 2 * q < M) reinterpret_cast<f32x4*>(xs.xout + (size_t)(r0 + 2 * q) * LNG_K)[c4] = xr[q];
+        if (lrow < nrows_lds) *reinterpret_cast<f32x4*>(&smem[lrow * LNG_LDX + c4 * 4]) = xr[q];
+    }
+    __syncthreads();
+    if (xs.g) {
+        // wave w normalises rows w, w+8, w+16, w+24 of the tile (a lane holds 16 floats of a row); the four rows are
+        // independent dependency chains issued together, reductions by DPP (no LDS round trips).  Rows beyond
+        // nrows_lds are computed from a clamped (valid) row and not written back.
+        f32x4 v[4][4];
+        float s[4], s2[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int lrow = min(wave + 8 * rr, nrows_lds - 1);
+            const float* rp = &smem[lrow * LNG_LDX + lane * 4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[rr][i] = *reinterpret_cast<const f32x4*>(rp + i * 256);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            s[rr] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[rr] += (v[rr][i][0] + v[rr][i][1]) + (v[rr][i][2] + v[rr][i][3]);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) s[rr] = wave_sum_dpp(s[rr]) / (float)LNG_K;  // mean
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            s2[rr] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[rr][i][e] -= s[rr];
+                s2[rr] += (v[rr][i][0] * v[rr][i][0] + v[rr][i][1] * v[rr][i][1]) + (v[rr][i][2] * v[rr][i][2] + v[rr][i][3] * v[rr][i][3]);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) s2[rr] = 1.0f / sqrtf(wave_sum_dpp(s2[rr]) / (float)LNG_K + LN_EPS);  // rstd
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            if (wave + 8 * rr < nrows_lds) {
+                float* rp = &smem[(wave + 8 * rr) * LNG_LDX + lane * 4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = v[rr][i][e] * s2[rr] * gg[i][e] + bb[i][e];
+                    *reinterpret_cast<f32x4*>(rp + i * 256) = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// c_attn / c_fc of the fused plan: K = 1024 in one workgroup, 16-column tiles (192 / 256 workgroups); request order
+// in stage_load: LayerNorm parameters, activation tile (L2 / MALL; up to 80 loads per thread, pipelined), and last the
+// wave's 8 one-KiB weight chunks (HBM), which land during the LDS write + LayerNorm.
+template <int MT, int MODE>
+__global__ __launch_bounds__(512) void rgrg_skinny_ln_gemm_f32(const SkinnyArgs a, const XSrc xs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PW = 8, KC = 16, NACC = 8, LDX = LNG_LDX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x;
+    const int chunks = a.K / KC;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.P) + ((size_t)nt * chunks + wave * PW) * 64 + lane;
+    f32x4 w[PW];
+    auto issue_weights = [&]() {
+#pragma unroll
+        for (int c = 0; c < PW; ++c) w[c] = __builtin_nontemporal_load(wp + (size_t)c * 64);
+    };
+    f32x4 xr[LNG_XQ], gg[4], bb[4];
+    stage_load<MODE>(xr, gg, bb, xs, 0, issue_weights);
+    float acc[MT][NACC];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (mt > 0) {
+            stage_load<MODE>(xr, gg, bb, xs, mt, [] {});
+            __syncthreads();  // every wave has finished reading the previous tile
+        }
+        stage_finish(smem, xr, xs, mt, a.M, 32, nt == 0, gg, bb);
+        f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* xa = &smem[(lane & 15) * LDX + wave * PW * KC + (lane >> 4) * 4];
+#pragma unroll
+        for (int c = 0; c < PW; ++c) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xa + c * KC);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(xa + 16 * LDX + c * KC);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], w[c][j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], w[c][j], acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[mt][r] = acc0[r]; acc[mt][4 + r] = acc1[r]; }
+    }
+    float* red = smem;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) red[(wave * NACC + r) * 64 + lane] = acc[mt][r];
+        __syncthreads();
+        const int half = tid >> 8, r = (tid >> 6) & 3, l = tid & 63;
+        float v = red[(0 * 8 + half * 4 + r) * 64 + l];
+#pragma unroll
+        for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[(w2 * 8 + half * 4 + r) * 64 + l];
+        skinny_store(a, mt * 32 + half * 16 + (l >> 4) * 4 + r, nt * 16 + (l & 15), v);
+    }
+}
+
+// lm_head of the fused plan: rgrg_skinny_gemm_f32_wide with the activation rows taken from stage_rows_ln
+// (final LayerNorm + the last mlp_proj's split-K combine)
+template <int MODE>
+__global__ __launch_bounds__(512) void rgrg_skinny_ln_gemm_f32_wide(const SkinnyArgs a, const XSrc xs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PW = 16, KC = 8, LDX = LNG_LDX;
+    float* red = smem + a.M * LDX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunks = a.K / KC;
+    const float* xa = &smem[(lane & 31) * LDX + wave * PW * KC + (lane >> 5) * 4];
+    const f32x4* wbase = reinterpret_cast<const f32x4*>(a.P) + ((size_t)wave * PW) * 64 + lane;
+    f32x4 wa[8], wb[8];
+    auto load8 = [&](f32x4(&w)[8], int nt, int half) {
+        const f32x4* wp = wbase + ((size_t)nt * chunks + half * 8) * 64;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) w[c] = __builtin_nontemporal_load(wp + (size_t)c * 64);
+    };
+    int nt = blockIdx.x;
+    {
+        f32x4 xr[LNG_XQ], gg[4], bb[4];
+        stage_load<MODE>(xr, gg, bb, xs, 0, [&]() { if (nt < a.NT) { load8(wa, nt, 0); load8(wb, nt, 1); } });
+        stage_finish(smem, xr, xs, 0, a.M, a.M, false, gg, bb);
+    }
+    for (; nt < a.NT; nt += gridDim.x) {
+        const int nxt = nt + gridDim.x;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(xa + c * KC);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], wa[c][j], acc, 0, 0, 0);
+        }
+        if (nxt < a.NT) load8(wa, nxt, 0);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(xa + (8 + c) * KC);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], wb[c][j], acc, 0, 0, 0);
+        }
+        if (nxt < a.NT) load8(wb, nxt, 1);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = tid + 512 * q;
+            const int r = idx >> 6, l = idx & 63;
+            float v = red[r * 64 + l];
+#pragma unroll
+            for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[(w2 * 16 + r) * 64 + l];
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+            const int col = nt * 32 + (l & 31);
+            skinny_store(a, row, col, v);
+            if (a.cand_val) {
+                float bv = (col < a.N) ? v + (a.bias ? a.bias[col] : 0.f) : -INFINITY;
+                int bi = col;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(bv, o, 64);
+                    const int oi = __shfl_xor(bi, o, 64);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                if ((l & 31) == 0 && row < a.M) {
+                    a.cand_val[(size_t)row * a.NT + nt] = bv;
+                    a.cand_idx[(size_t)row * a.NT + nt] = bi;
+                }
+            }
+        }
+    }
+}
+
+constexpr size_t LNG_LDS = (size_t)32 * LNG_LDX * sizeof(float);
 constexpr int WIDE_MAX_ROWS = 31;  // 31 staged rows + the 32 KiB reduction buffer fill the 160 KiB LDS
 constexpr size_t WIDE_LDS = (size_t)(WIDE_MAX_ROWS * (16 * SK_WAVES * 8 + 4) + SK_WAVES * 16 * 64) * sizeof(float);
 static_assert(WIDE_LDS <= 160 * 1024, "wide skinny GEMM must fit the 160 KiB LDS");
@@ -481,112 +813,107 @@ __global__ __launch_bounds__(256) void resid_ln_kernel(float* __restrict__ x, co
 // Pseudo self-attention for ONE new token per sequence (GPT2PseudoAttention.forward with
 // layer_past, :162-174, and _attn :84-122: scores / 8, softmax, . V; the causal mask row
 // of a single query and the all-zero padding mask are no-ops in greedy generation).
-// One workgroup per (sequence, head), 4 waves; a 16-lane group owns one key (4 dims per
-// lane), so a wave covers 4 keys and the workgroup 16 keys per iteration.  All K rows (and
-// the V rows of the first 144 keys) are requested up front, so the kernel pays ~2 HBM/L2
-// latencies instead of one per key.
-constexpr int ATT_MAXKEYS = 1040;
+// One workgroup per (sequence, head), 4 waves.  A 16-lane GROUP owns one key at a time (4 dims per lane), so a wave
+// covers 4 consecutive keys (1 KiB of the cache row block) and the workgroup 16 keys per pass.  Every K and V row of a
+// chunk of 16 * ATT_NI keys (144: one chunk up to max_length 142) is requested up front with UNCONDITIONAL loads
+// (indices clamped, results selected afterwards): a conditional load costs a branch + a full s_waitcnt per load and
+// serialises the latencies (the round-1 kernel: 9.7 us).  Each group keeps its own running softmax
+// statistics (max, sum, weighted V sum over ITS keys) - no cross-lane traffic besides the 4-step DPP dot product -
+// and the 16 partial results are merged once through LDS (flash-decoding inside the workgroup, one barrier).
+constexpr int ATT_NI = 9;
 
-// PRELOAD_V: request the V rows of the first 144 keys together with the K rows (one memory latency per
-// workgroup: best when the grid is < 1 round, i.e. few sequences).  !PRELOAD_V: fetch V after the softmax
-// statistics - half the registers, twice the resident workgroups: best when thousands of (sequence, head)
-// workgroups queue up (batch 32: 14848) and the kernel is throughput bound.
-template <bool PRELOAD_V, int ATT_NI>  // a chunk = 16 * ATT_NI keys (9 -> 144 keys: one chunk up to max_length 142)
+__device__ __forceinline__ float group16_sum_dpp(float v) {  // sum over the 16 lanes of a DPP row, result in every lane
+    v += dpp_get<0xB1, 0xf>(v);
+    v += dpp_get<0x4E, 0xf>(v);
+    v += dpp_get<0x141, 0xf>(v);
+    v += dpp_get<0x140, 0xf>(v);
+    return v;
+}
+
+template <bool HAS_SRC>  // beam search: per-slot ancestor table (one more dependent load per key, requested first)
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                           float* __restrict__ kc, float* __restrict__ vc,
                                                           const int* __restrict__ step, float* __restrict__ out,
                                                           int S, int H, int T, const int* __restrict__ src) {
-    __shared__ float sc[ATT_MAXKEYS];
-    __shared__ float part[4][64];
+    __shared__ float pm[16], pl[16];
+    __shared__ __attribute__((aligned(16))) float pacc[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = blockIdx.x / H, hd = blockIdx.x - s * H;
     const int t = *step, nkeys = t + 2, slot = t + 1;
     const int g = lane >> 4, d4 = lane & 15;
     const float* row = qkv + (size_t)s * ld_qkv;
     const int D = H * 64;
+    // beam search: slot j of this beam's history lives in the cache row of the ancestor that wrote it
+    // (src[s][j]); the cache is never physically re-ordered (the reference's _reorder_cache, :492-496)
+    const int* srow = HAS_SRC ? src + (size_t)s * T : nullptr;
+    constexpr int ATT_CHUNK = 16 * ATT_NI;
+    int rowi[ATT_NI];  // first chunk's table entries: the oldest loads, so that waiting for them waits for nothing else
+#pragma unroll
+    for (int i = 0; i < ATT_NI; ++i) rowi[i] = HAS_SRC ? srow[min((i * 4 + wave) * 4 + g, nkeys - 1)] : s;
     const f32x4 q4 = *reinterpret_cast<const f32x4*>(row + hd * 64 + d4 * 4);
     const f32x4 k4 = *reinterpret_cast<const f32x4*>(row + D + hd * 64 + d4 * 4);
     const f32x4 v4 = *reinterpret_cast<const f32x4*>(row + 2 * D + hd * 64 + d4 * 4);
-    float* kbase = kc + ((size_t)s * H + hd) * T * 64;
-    float* vbase = vc + ((size_t)s * H + hd) * T * 64;
-    // beam search: slot j of this beam's history lives in the cache row of the ancestor that wrote it
-    // (src[s][j]); the cache is never physically re-ordered (the reference's _reorder_cache, :492-496)
-    const int* srow = src ? src + (size_t)s * T : nullptr;
-    auto kv_off = [&](int j) -> size_t {
-        const size_t r = srow ? (size_t)srow[j] : (size_t)s;
-        return ((r * H + hd) * T + j) * 64 + d4 * 4;
-    };
-    if (wave == 0 && g == 0) {
-        *reinterpret_cast<f32x4*>(kbase + (size_t)slot * 64 + d4 * 4) = k4;
-        *reinterpret_cast<f32x4*>(vbase + (size_t)slot * 64 + d4 * 4) = v4;
-    }
-    constexpr int ATT_CHUNK = 16 * ATT_NI;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 vv0[ATT_NI];
-    if (!PRELOAD_V) {
-#pragma unroll
-        for (int i = 0; i < ATT_NI; ++i) vv0[i] = zero4;
-    }
+    float m = -INFINITY, l = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int base = 0; base < nkeys; base += ATT_CHUNK) {
-        f32x4 kk[ATT_NI];
+        if (HAS_SRC && base > 0) {
+#pragma unroll
+            for (int i = 0; i < ATT_NI; ++i) rowi[i] = srow[min(base + (i * 4 + wave) * 4 + g, nkeys - 1)];
+        }  // slot t + 1 of the table is stale: that key comes from k4 / v4 below
+        f32x4 kk[ATT_NI], vv[ATT_NI];
+#pragma unroll
+        for (int i = 0; i < ATT_NI; ++i) {
+            const int jc = min(base + (i * 4 + wave) * 4 + g, nkeys - 1);
+            const size_t off = (((size_t)rowi[i] * H + hd) * T + jc) * 64 + d4 * 4;
+            kk[i] = *reinterpret_cast<const f32x4*>(kc + off);
+            vv[i] = *reinterpret_cast<const f32x4*>(vc + off);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // all 2 * ATT_NI loads are in flight before the first dot product waits
+        float sc[ATT_NI];
+        float cmax = -INFINITY;
 #pragma unroll
         for (int i = 0; i < ATT_NI; ++i) {
             const int j = base + (i * 4 + wave) * 4 + g;
-            kk[i] = zero4;
-            if (j < nkeys) kk[i] = (j == slot) ? k4 : *reinterpret_cast<const f32x4*>(kc + kv_off(j));
+            if (j == slot) { kk[i] = k4; vv[i] = v4; }  // selects, not branches: the new token's key / value
+            const float dot = group16_sum_dpp((q4[0] * kk[i][0] + q4[1] * kk[i][1]) + (q4[2] * kk[i][2] + q4[3] * kk[i][3]));
+            sc[i] = j < nkeys ? dot / 8.0f : -INFINITY;
+            cmax = fmaxf(cmax, sc[i]);
         }
-        if (PRELOAD_V && base == 0) {
+        const float m_new = fmaxf(m, cmax);
+        const float scale = (m == -INFINITY) ? 0.f : expf(m - m_new);  // 1 on the first chunk's empty start, never NaN
+        l *= scale;
 #pragma unroll
-            for (int i = 0; i < ATT_NI; ++i) {
-                const int j = (i * 4 + wave) * 4 + g;
-                vv0[i] = zero4;
-                if (j < nkeys) vv0[i] = (j == slot) ? v4 : *reinterpret_cast<const f32x4*>(vc + kv_off(j));
-            }
-        }
+        for (int e = 0; e < 4; ++e) acc[e] *= scale;
 #pragma unroll
         for (int i = 0; i < ATT_NI; ++i) {
             const int j = base + (i * 4 + wave) * 4 + g;
-            float dot = (q4[0] * kk[i][0] + q4[1] * kk[i][1]) + (q4[2] * kk[i][2] + q4[3] * kk[i][3]);
-            dot += __shfl_xor(dot, 1, 64);
-            dot += __shfl_xor(dot, 2, 64);
-            dot += __shfl_xor(dot, 4, 64);
-            dot += __shfl_xor(dot, 8, 64);
-            if (d4 == 0 && j < nkeys) sc[j] = dot / 8.0f;
+            const float p = j < nkeys ? expf(sc[i] - m_new) : 0.f;
+            l += p;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += p * (j < nkeys ? vv[i][e] : 0.f);
         }
+        m = m_new;
     }
-    __syncthreads();
-    float m = -INFINITY;
-    for (int j = lane; j < nkeys; j += 64) m = fmaxf(m, sc[j]);
-    m = wave_max(m);
-    float sum = 0.f;
-    for (int j = lane; j < nkeys; j += 64) sum += expf(sc[j] - m);
-    sum = wave_sum(sum);
-    f32x4 acc = zero4;
-    for (int base = 0; base < nkeys; base += ATT_CHUNK) {
-#pragma unroll
-        for (int i = 0; i < ATT_NI; ++i) {
-            const int j = base + (i * 4 + wave) * 4 + g;
-            if (j < nkeys) {
-                f32x4 vv = vv0[i];
-                if (!PRELOAD_V || base > 0) vv = (j == slot) ? v4 : *reinterpret_cast<const f32x4*>(vc + kv_off(j));
-                const float p = expf(sc[j] - m) / sum;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] += p * vv[e];
-            }
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        acc[e] += __shfl_xor(acc[e], 16, 64);
-        acc[e] += __shfl_xor(acc[e], 32, 64);
-    }
-    if (g == 0) *reinterpret_cast<f32x4*>(&part[wave][d4 * 4]) = acc;
-    __syncthreads();
     if (wave == 0 && g == 0) {
-        f32x4 o = *reinterpret_cast<const f32x4*>(&part[0][d4 * 4]);
+        *reinterpret_cast<f32x4*>(kc + (((size_t)s * H + hd) * T + slot) * 64 + d4 * 4) = k4;
+        *reinterpret_cast<f32x4*>(vc + (((size_t)s * H + hd) * T + slot) * 64 + d4 * 4) = v4;
+    }
+    const int grp = wave * 4 + g;
+    if (d4 == 0) { pm[grp] = m; pl[grp] = l; }
+    *reinterpret_cast<f32x4*>(&pacc[grp][d4 * 4]) = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float M = pm[0];
 #pragma unroll
-        for (int w2 = 1; w2 < 4; ++w2) o += *reinterpret_cast<const f32x4*>(&part[w2][d4 * 4]);
-        *reinterpret_cast<f32x4*>(out + (size_t)s * D + hd * 64 + d4 * 4) = o;
+        for (int k = 1; k < 16; ++k) M = fmaxf(M, pm[k]);
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {  // groups without a key have max -inf and weight exp(-inf) = 0
+            const float wgt = expf(pm[k] - M);
+            L += pl[k] * wgt;
+            o += pacc[k][threadIdx.x] * wgt;
+        }
+        out[(size_t)s * D + hd * 64 + threadIdx.x] = o / L;
     }
 }
 
@@ -601,24 +928,29 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float f) {
 }
 __device__ __forceinline__ float bf16_round(float f) { return __uint_as_float(bf16_rne_bits(f) << 16); }
 
-// Same attention with a bf16 K/V cache (half the bytes of the kernel's only real traffic).  An 8-lane group
-// owns one key (8 dims = one 16-byte load per lane), a wave covers 8 keys and the workgroup 32 keys per
-// pass; q, the scores, the softmax and the accumulation stay fp32.  The new token's k/v are rounded once and
-// the rounded values are used here too, so this step and later steps see the same numbers.
-template <int ATT_NI>  // a chunk = 32 * ATT_NI keys
+// Same attention with a bf16 K/V cache (half the bytes of the kernel's only real traffic).  An 8-lane group owns
+// one key (8 dims = one 16-byte load per lane), a wave covers 8 consecutive keys (1 KiB) and the workgroup 32 keys
+// per pass; q, the scores, the softmax and the accumulation stay fp32.  The new token's k / v are rounded once and the
+// rounded values are used here too, so this step and later steps see the same numbers.  Same structure as
+// attn_decode_kernel: unconditional (clamped) loads of a whole chunk up front, per-group running softmax, one merge.
+template <int KV_NI, bool HAS_SRC>  // a chunk = 32 * KV_NI keys
 __global__ __launch_bounds__(256) void attn_decode_kv16_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                                u16* __restrict__ kc, u16* __restrict__ vc,
                                                                const int* __restrict__ step, float* __restrict__ out,
                                                                int S, int H, int T, const int* __restrict__ src,
                                                                u16* __restrict__ out16) {
-    __shared__ float sc[ATT_MAXKEYS];
-    __shared__ float part[4][64];
+    __shared__ float pm[32], pl[32];
+    __shared__ __attribute__((aligned(16))) float pacc[32][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = blockIdx.x / H, hd = blockIdx.x - s * H;
     const int t = *step, nkeys = t + 2, slot = t + 1;
     const int g = lane >> 3, d8 = lane & 7;
     const float* row = qkv + (size_t)s * ld_qkv;
     const int D = H * 64;
+    const int* srow = HAS_SRC ? src + (size_t)s * T : nullptr;
+    int rowi[KV_NI];  // first chunk's ancestor-table entries: the oldest loads of the kernel
+#pragma unroll
+    for (int i = 0; i < KV_NI; ++i) rowi[i] = HAS_SRC ? srow[min((i * 4 + wave) * 8 + g, nkeys - 1)] : s;
     float q[8], kn[8], vn[8];
     {
         const f32x4 a = *reinterpret_cast<const f32x4*>(row + hd * 64 + d8 * 8);
@@ -634,99 +966,88 @@ __global__ __launch_bounds__(256) void attn_decode_kv16_kernel(const float* __re
             vn[i] = bf16_round(f[i]); vn[4 + i] = bf16_round(h[i]);
         }
     }
-    const int* srow = src ? src + (size_t)s * T : nullptr;
-    auto kv_off = [&](int j) -> size_t {
-        const size_t r = srow ? (size_t)srow[j] : (size_t)s;
-        return ((r * H + hd) * T + j) * 64 + d8 * 8;
-    };
     auto pack8 = [](const float* v) -> u32x4 {
         u32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = (__float_as_uint(v[2 * i]) >> 16) | (__float_as_uint(v[2 * i + 1]) & 0xffff0000u);
         return o;
     };
-    if (wave == 0 && g == 0) {
-        const size_t o = (((size_t)s * H + hd) * T + slot) * 64 + d8 * 8;
-        *reinterpret_cast<u32x4*>(kc + o) = pack8(kn);
-        *reinterpret_cast<u32x4*>(vc + o) = pack8(vn);
-    }
-    constexpr int ATT_CHUNK = 32 * ATT_NI;
-    const u32x4 zero = {0u, 0u, 0u, 0u};
-    for (int base = 0; base < nkeys; base += ATT_CHUNK) {
-        u32x4 kk[ATT_NI];
-#pragma unroll
-        for (int i = 0; i < ATT_NI; ++i) {
-            const int j = base + (i * 4 + wave) * 8 + g;
-            kk[i] = zero;
-            if (j < nkeys && j != slot) kk[i] = *reinterpret_cast<const u32x4*>(kc + kv_off(j));
-        }
-#pragma unroll
-        for (int i = 0; i < ATT_NI; ++i) {
-            const int j = base + (i * 4 + wave) * 8 + g;
-            float dot = 0.f;
-            if (j == slot) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dot += q[e] * kn[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    dot += q[2 * e] * __uint_as_float(kk[i][e] << 16) + q[2 * e + 1] * __uint_as_float(kk[i][e] & 0xffff0000u);
-            }
-            dot += __shfl_xor(dot, 1, 64);
-            dot += __shfl_xor(dot, 2, 64);
-            dot += __shfl_xor(dot, 4, 64);
-            if (d8 == 0 && j < nkeys) sc[j] = dot / 8.0f;
-        }
-    }
-    __syncthreads();
-    float m = -INFINITY;
-    for (int j = lane; j < nkeys; j += 64) m = fmaxf(m, sc[j]);
-    m = wave_max(m);
-    float sum = 0.f;
-    for (int j = lane; j < nkeys; j += 64) sum += expf(sc[j] - m);
-    sum = wave_sum(sum);
-    float acc[8];
+    const u32x4 kn16 = pack8(kn), vn16 = pack8(vn);
+    constexpr int CHUNK = 32 * KV_NI;
+    float m = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int base = 0; base < nkeys; base += ATT_CHUNK) {
-        u32x4 vv[ATT_NI];
+    for (int base = 0; base < nkeys; base += CHUNK) {
+        if (HAS_SRC && base > 0) {
 #pragma unroll
-        for (int i = 0; i < ATT_NI; ++i) {
-            const int j = base + (i * 4 + wave) * 8 + g;
-            vv[i] = zero;
-            if (j < nkeys && j != slot) vv[i] = *reinterpret_cast<const u32x4*>(vc + kv_off(j));
+            for (int i = 0; i < KV_NI; ++i) rowi[i] = srow[min(base + (i * 4 + wave) * 8 + g, nkeys - 1)];
         }
+        u32x4 kk[KV_NI], vv[KV_NI];
 #pragma unroll
-        for (int i = 0; i < ATT_NI; ++i) {
+        for (int i = 0; i < KV_NI; ++i) {
+            const int jc = min(base + (i * 4 + wave) * 8 + g, nkeys - 1);
+            const size_t off = (((size_t)rowi[i] * H + hd) * T + jc) * 64 + d8 * 8;
+            kk[i] = *reinterpret_cast<const u32x4*>(kc + off);
+            vv[i] = *reinterpret_cast<const u32x4*>(vc + off);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // all 2 * KV_NI loads are in flight before the first dot product waits
+        float sc[KV_NI];
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < KV_NI; ++i) {
             const int j = base + (i * 4 + wave) * 8 + g;
-            if (j < nkeys) {
-                const float pj = expf(sc[j] - m) / sum;
-                if (j == slot) {
+            if (j == slot) { kk[i] = kn16; vv[i] = vn16; }
+            float dot = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += pj * vn[e];
-                } else {
+            for (int e = 0; e < 4; ++e)
+                dot += q[2 * e] * __uint_as_float(kk[i][e] << 16) + q[2 * e + 1] * __uint_as_float(kk[i][e] & 0xffff0000u);
+            dot += dpp_get<0xB1, 0xf>(dot);
+            dot += dpp_get<0x4E, 0xf>(dot);
+            dot += dpp_get<0x141, 0xf>(dot);  // row_half_mirror: sum over the 8 lanes of the group
+            sc[i] = j < nkeys ? dot / 8.0f : -INFINITY;
+            cmax = fmaxf(cmax, sc[i]);
+        }
+        const float m_new = fmaxf(m, cmax);
+        const float scale = (m == -INFINITY) ? 0.f : expf(m - m_new);
+        l *= scale;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[2 * e] += pj * __uint_as_float(vv[i][e] << 16);
-                        acc[2 * e + 1] += pj * __uint_as_float(vv[i][e] & 0xffff0000u);
-                    }
-                }
+        for (int e = 0; e < 8; ++e) acc[e] *= scale;
+#pragma unroll
+        for (int i = 0; i < KV_NI; ++i) {
+            const int j = base + (i * 4 + wave) * 8 + g;
+            const float pj = j < nkeys ? expf(sc[i] - m_new) : 0.f;
+            l += pj;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned u = j < nkeys ? vv[i][e] : 0u;
+                acc[2 * e] += pj * __uint_as_float(u << 16);
+                acc[2 * e + 1] += pj * __uint_as_float(u & 0xffff0000u);
             }
         }
+        m = m_new;
     }
+    if (wave == 0 && g == 0) {
+        const size_t o = (((size_t)s * H + hd) * T + slot) * 64 + d8 * 8;
+        *reinterpret_cast<u32x4*>(kc + o) = kn16;
+        *reinterpret_cast<u32x4*>(vc + o) = vn16;
+    }
+    const int grp = wave * 8 + g;
+    if (d8 == 0) { pm[grp] = m; pl[grp] = l; }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        acc[e] += __shfl_xor(acc[e], 8, 64);
-        acc[e] += __shfl_xor(acc[e], 16, 64);
-        acc[e] += __shfl_xor(acc[e], 32, 64);
-    }
-    if (g == 0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) part[wave][d8 * 8 + e] = acc[e];
-    }
+    for (int e = 0; e < 8; ++e) pacc[grp][d8 * 8 + e] = acc[e];
     __syncthreads();
     if (threadIdx.x < 64) {
-        const float o = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        float M = pm[0];
+#pragma unroll
+        for (int k = 1; k < 32; ++k) M = fmaxf(M, pm[k]);
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const float wgt = expf(pm[k] - M);
+            L += pl[k] * wgt;
+            o += pacc[k][threadIdx.x] * wgt;
+        }
+        o /= L;
         if (out16) out16[(size_t)s * D + hd * 64 + threadIdx.x] = (u16)bf16_rne_bits(o);  // feeds the bf16 attn_proj GEMM only
         else out[(size_t)s * D + hd * 64 + threadIdx.x] = o;
     }
@@ -1207,7 +1528,7 @@ struct rgrg_decoder {
     Lin fst0, fst2, ukv, lm_head;
     std::vector<LayerW> layers;
     // workspace
-    float *feats, *h1, *img, *ukv_out, *x, *xn, *qkv, *att, *ff, *logits, *part, *kv, *cand_val, *gemm_ws;
+    float *feats, *h1, *img, *ukv_out, *x, *x2, *xn, *qkv, *att, *ff, *logits, *part, *kv, *cand_val, *gemm_ws;
     size_t gemm_ws_floats;
     int* cand_idx;
     size_t kv_layer_stride, kv_kv_stride;
@@ -1264,6 +1585,11 @@ static int make_lin(rgrg_decoder* d, Lin& l, const float* w, const float* b, int
     if (K == 1024 && N >= 2048 && N <= 8192) {
         // c_attn / c_fc: 16-column tiles -> 192 / 256 workgroups with the whole K each (no partial sums)
         l.ntile = 16; l.KS = 1;
+    } else if (decode_plan() == 1 && N == 1024 && (K == 1024 || K == 4096)) {
+        // fused plan: attn_proj (and fst-nn) keep K in the workgroup (64 workgroups, bias + residual in the epilogue);
+        // mlp_proj splits K over 4 workgroups per 16-column tile (256 workgroups: the fp32 MFMA work needs every CU),
+        // the 4 partial sums are combined by the consumer's staging (XSrc)
+        l.ntile = 16; l.KS = (K == 1024) ? 1 : 4;
     } else {
         l.ntile = 32;
         l.KS = pick_ks((N + 31) / 32, K / 8);
@@ -1307,6 +1633,18 @@ static int skinny_attr() {
     if ((rc = skinny_attr1<NTILE, PW, 3>())) return rc;
     return skinny_attr1<NTILE, PW, 4>();
 }
+template <int MT>
+static int ln_gemm_attr() {
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_ln_gemm_f32<MT, XS_PLAIN>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LNG_LDS));
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_ln_gemm_f32<MT, XS_COMBINE4>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LNG_LDS));
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_ln_gemm_f32<MT, XS_EMBED>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LNG_LDS));
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_ln_gemm_f32<MT, XS_EMBED_TOK>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LNG_LDS));
+    return RGRG_OK;
+}
 static int init_skinny_attrs() {
     int rc;
     if ((rc = skinny_attr<32, 4>())) return rc;
@@ -1315,6 +1653,10 @@ static int init_skinny_attrs() {
     if ((rc = skinny_attr<16, 4>())) return rc;
     RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_gemm_f32_wide),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS));
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_ln_gemm_f32_wide<XS_COMBINE4>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS));
+    int rc2;
+    if ((rc2 = ln_gemm_attr<1>()) || (rc2 = ln_gemm_attr<2>()) || (rc2 = ln_gemm_attr<3>()) || (rc2 = ln_gemm_attr<4>())) return rc2;
     return skinny_attr<16, 8>();
 }
 
@@ -1351,11 +1693,118 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
     return launch_gemm_dense(X, l.w, l.b, R, Y, M, l.N, l.K, ldy, act, d->gemm_ws, d->gemm_ws_floats, d->stream);
 }
 
+
+// Y[:M] = act(LN(xs) W^T + b) on the LayerNorm-fused skinny GEMM (K = 1024, 16-column tiles, whole K per workgroup)
+static int ln_linear(rgrg_decoder* d, const Lin& l, const XSrc& xs, float* Y, int M, int ldy, int act, bool count,
+                     bool cand = false) {
+    if (l.K != LNG_K || !l.packed) { set_error("ln_linear: K=%d unsupported", l.K); return RGRG_EINVAL; }
+    SkinnyArgs a{nullptr, l.packed, l.b, nullptr, Y, nullptr, M, l.K, l.N, l.NT, 1, ldy, act, nullptr, nullptr, l.ntile};
+    const int mode = xs.wte ? (xs.tok_override ? XS_EMBED_TOK : XS_EMBED) : (xs.part ? XS_COMBINE4 : XS_PLAIN);
+    if (mode == XS_COMBINE4 && (xs.KS != 4 || xs.ldp != LNG_K)) { set_error("ln_linear: the producer must split K 4 ways over %d columns (got %d, %d)", LNG_K, xs.KS, xs.ldp); return RGRG_EINVAL; }
+    const dim3 blk(64 * SK_WAVES);
+    if (l.ntile == 32) {  // lm_head: persistent wide kernel
+        if (!(l.KS == 1 && l.NT > 512 && M <= WIDE_MAX_ROWS && mode == XS_COMBINE4)) { set_error("ln_linear: wide kernel needs <= %d rows", WIDE_MAX_ROWS); return RGRG_EINVAL; }
+        if (cand) { a.cand_val = d->cand_val; a.cand_idx = d->cand_idx; }
+        hipLaunchKernelGGL(rgrg_skinny_ln_gemm_f32_wide<XS_COMBINE4>, dim3(256), blk, WIDE_LDS, d->stream, a, xs);
+    } else {
+        if (l.KS != 1) { set_error("ln_linear: split-K layer"); return RGRG_EINVAL; }
+        const int mt = (M + PAD_ROWS - 1) / PAD_ROWS;
+#define LNG_LAUNCH(MT_, MODE_) hipLaunchKernelGGL((rgrg_skinny_ln_gemm_f32<MT_, MODE_>), dim3(l.NT), blk, LNG_LDS, d->stream, a, xs)
+#define LNG_MODES(MT_) do { if (mode == XS_PLAIN) LNG_LAUNCH(MT_, XS_PLAIN); else if (mode == XS_COMBINE4) LNG_LAUNCH(MT_, XS_COMBINE4); else if (mode == XS_EMBED) LNG_LAUNCH(MT_, XS_EMBED); else LNG_LAUNCH(MT_, XS_EMBED_TOK); } while (0)
+        if (mt == 1) LNG_MODES(1);
+        else if (mt == 2) LNG_MODES(2);
+        else if (mt == 3) LNG_MODES(3);
+        else if (mt == 4) LNG_MODES(4);
+        else { set_error("ln_linear: %d rows exceed 4 row tiles", M); return RGRG_EINVAL; }
+#undef LNG_MODES
+#undef LNG_LAUNCH
+    }
+    RGRG_LAUNCH_CHECK();
+    if (count) {
+        d->gemm_bytes_per_step += (size_t)l.N * l.K * sizeof(float);
+        d->gemm_launches_per_step += 1;
+    }
+    return RGRG_OK;
+}
+
+static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsigned short* att16) {
+    hipStream_t st = d->stream;
+    const int D = d->D;
+    float* kc = d->kv + (size_t)l * d->kv_layer_stride;
+    float* vc = kc + d->kv_kv_stride;
+    if (kv_is_bf16(d, S)) {
+        u16* kc16 = reinterpret_cast<u16*>(d->kv) + (size_t)l * d->kv_layer_stride;
+        if (src)
+            hipLaunchKernelGGL((attn_decode_kv16_kernel<5, true>), dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc16,
+                               kc16 + d->kv_kv_stride, d->step, d->att, S, d->H, d->T, src, att16);
+        else
+            hipLaunchKernelGGL((attn_decode_kv16_kernel<5, false>), dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc16,
+                               kc16 + d->kv_kv_stride, d->step, d->att, S, d->H, d->T, src, att16);
+    } else if (src)
+        hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc, vc, d->step,
+                           d->att, S, d->H, d->T, src);
+    else
+        hipLaunchKernelGGL(attn_decode_kernel<false>, dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc, vc, d->step,
+                           d->att, S, d->H, d->T, src);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+// One decode step of the fused plan (<= 128 token rows): 24 * 5 + 2 = 122 launches
+//   per layer: c_attn' [embedding | previous mlp_proj combine, + ln_1] -> attention -> attn_proj' [+ bias + residual,
+//   in place] -> c_fc' [ln_2, gelu] -> mlp_proj (4 partial sums)   |   lm_head' [combine + ln_f, arg-max candidates]
+//   -> argmax + bookkeeping.  The residual stream ping-pongs between d->x and d->x2.
+static int enqueue_step_fused(rgrg_decoder* d, int S, bool count, const int* tok_override, const int* src, bool beam) {
+    if (count) { d->gemm_bytes_per_step = 0; d->gemm_launches_per_step = 0; }
+    hipStream_t st = d->stream;
+    const int D = d->D;
+    int rc;
+    float* cur = d->x;   // holds x_mid of the previous layer (its mlp_proj partials are pending in d->part)
+    float* nxt = d->x2;
+    const Lin* prev_mlp = nullptr;
+    for (int l = 0; l < d->n_layer; ++l) {
+        const LayerW& w = d->layers[l];
+        XSrc xs{};
+        xs.g = w.ln1_g; xs.b = w.ln1_b; xs.xout = nxt;
+        if (l == 0) {
+            xs.wte = d->wte; xs.ids = d->ids; xs.ld_ids = d->max_len; xs.step = d->step; xs.tok_override = tok_override;
+        } else {
+            xs.x = cur; xs.part = d->part; xs.pbias = prev_mlp->b; xs.KS = prev_mlp->KS; xs.ldp = prev_mlp->NT * prev_mlp->ntile;
+        }
+        if ((rc = ln_linear(d, w.c_attn, xs, d->qkv, S, 3 * D, RGRG_ACT_NONE, count))) return rc;
+        if ((rc = launch_attention(d, l, S, src, nullptr))) return rc;
+        if ((rc = linear(d, w.attn_proj, d->att, nxt, nxt, S, D, RGRG_ACT_NONE, count))) return rc;
+        XSrc x2{};
+        x2.x = nxt; x2.g = w.ln2_g; x2.b = w.ln2_b;
+        if ((rc = ln_linear(d, w.c_fc, x2, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, count))) return rc;
+        if ((rc = linear(d, w.mlp_proj, d->ff, nullptr, nullptr, S, D, RGRG_ACT_NONE, count, true))) return rc;
+        prev_mlp = &w.mlp_proj;
+        float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (S <= WIDE_MAX_ROWS) {
+        XSrc xf{};
+        xf.x = cur; xf.part = d->part; xf.pbias = prev_mlp->b; xf.KS = prev_mlp->KS; xf.ldp = prev_mlp->NT * prev_mlp->ntile;
+        xf.g = d->lnf_g; xf.b = d->lnf_b;
+        if ((rc = ln_linear(d, d->lm_head, xf, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, !beam))) return rc;
+    } else {
+        hipLaunchKernelGGL(resid_ln_kernel, dim3(S), dim3(256), 0, st, cur, prev_mlp->b, d->part, prev_mlp->KS,
+                           prev_mlp->NT * prev_mlp->ntile, d->lnf_g, d->lnf_b, d->xn, D, (unsigned short*)nullptr);
+        RGRG_LAUNCH_CHECK();
+        if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, false, !beam))) return rc;
+    }
+    if (beam) return RGRG_OK;
+    hipLaunchKernelGGL(argmax_update_kernel, dim3(S), dim3(256), 0, st, d->cand_val, d->cand_idx, d->lm_head.NT, d->ids,
+                       d->max_len, d->finished, d->step, d->done_len, d->sync, S);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
 // One decode step.  <= 32 sequences: 1 + 24*7 + 2 = 171 launches (lm_head emits arg-max candidates)
 //   embed+ln1 | per layer: c_attn, attention, attn_proj(partials), resid+ln2, c_fc+gelu,
 //   mlp_proj(partials), resid+ln1(next layer / ln_f) | lm_head, argmax+bookkeeping
 static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_override = nullptr, const int* src = nullptr,
                         bool beam = false) {
+    if (decode_plan() == 1 && S <= skinny_max_rows() && d->lm_head.packed) return enqueue_step_fused(d, S, count, tok_override, src, beam);
     if (count) { d->gemm_bytes_per_step = 0; d->gemm_launches_per_step = 0; }
     hipStream_t st = d->stream;
     const int D = d->D;
@@ -1372,22 +1821,10 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
     RGRG_LAUNCH_CHECK();
     for (int l = 0; l < d->n_layer; ++l) {
         const LayerW& w = d->layers[l];
-        float* kc = d->kv + (size_t)l * d->kv_layer_stride;
-        float* vc = kc + d->kv_kv_stride;
         const float* ng = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_g : d->lnf_g;
         const float* nb = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_b : d->lnf_b;
         if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, count, false, false, xn16))) return rc;
-        if (kv_is_bf16(d, S)) {
-            u16* kc16 = reinterpret_cast<u16*>(d->kv) + (size_t)l * d->kv_layer_stride;
-            hipLaunchKernelGGL((attn_decode_kv16_kernel<5>), dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc16,
-                               kc16 + d->kv_kv_stride, d->step, d->att, S, d->H, d->T, src, att16);
-        } else if (S * d->H <= 4096)
-            hipLaunchKernelGGL((attn_decode_kernel<true, 9>), dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc, vc, d->step,
-                               d->att, S, d->H, d->T, src);
-        else
-            hipLaunchKernelGGL((attn_decode_kernel<false, 5>), dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc, vc, d->step,
-                               d->att, S, d->H, d->T, src);
-        RGRG_LAUNCH_CHECK();
+        if ((rc = launch_attention(d, l, S, src, att16))) return rc;
         const bool defer_a = skinny && w.attn_proj.KS > 1, defer_m = skinny && w.mlp_proj.KS > 1;
         if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count, defer_a, false, att16))) return rc;
         hipLaunchKernelGGL(resid_ln_kernel, dim3(S), dim3(256), 0, st, d->x, w.attn_proj.b, defer_a ? d->part : nullptr,
@@ -1484,6 +1921,7 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     TRY(dmalloc(d, (void**)&d->img, R * D * 4, true));
     TRY(dmalloc(d, (void**)&d->ukv_out, R * d->ld_ukv * 4, true));
     TRY(dmalloc(d, (void**)&d->x, R * D * 4, true));
+    TRY(dmalloc(d, (void**)&d->x2, R * D * 4, true));
     TRY(dmalloc(d, (void**)&d->xn, R * D * 4, true));
     TRY(dmalloc(d, (void**)&d->qkv, R * 3 * D * 4, true));
     TRY(dmalloc(d, (void**)&d->att, R * D * 4, true));
@@ -2179,6 +2617,7 @@ extern "C" int rgrg_decoder_time_gemms(rgrg_decoder* d, int S, int iters, float*
     d->gemm_launches_per_step = 0;
     float total = 0.f;
     int rc = RGRG_OK;
+    const bool fused = decode_plan() == 1 && S <= WIDE_MAX_ROWS;
     // the 97 weight-streaming GEMM launches of one decode step, back to back in step order, between ONE
     // pair of events on the decoder's stream (the two event records amortise over the 97 launches)
     for (int it = 0; it < iters && !rc; ++it) {
@@ -2186,12 +2625,29 @@ extern "C" int rgrg_decoder_time_gemms(rgrg_decoder* d, int S, int iters, float*
         RGRG_HIP(hipEventRecord(e0, d->stream));
         for (int l = 0; l < d->n_layer && !rc; ++l) {
             const LayerW& w = d->layers[l];
+            if (fused) {  // the GEMM launches of the fused plan, LayerNorm / combine prologues included
+                XSrc xs{};
+                xs.x = d->x; xs.g = w.ln1_g; xs.b = w.ln1_b; xs.xout = d->x2;
+                xs.part = d->part; xs.pbias = w.mlp_proj.b; xs.KS = w.mlp_proj.KS; xs.ldp = w.mlp_proj.NT * w.mlp_proj.ntile;
+                if ((rc = ln_linear(d, w.c_attn, xs, d->qkv, S, 3 * D, RGRG_ACT_NONE, c))) break;
+                if ((rc = linear(d, w.attn_proj, d->att, d->x2, d->x2, S, D, RGRG_ACT_NONE, c))) break;
+                XSrc x2{};
+                x2.x = d->x2; x2.g = w.ln2_g; x2.b = w.ln2_b;
+                if ((rc = ln_linear(d, w.c_fc, x2, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, c))) break;
+                if ((rc = linear(d, w.mlp_proj, d->ff, nullptr, nullptr, S, D, RGRG_ACT_NONE, c, true))) break;
+                continue;
+            }
             if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, c, true))) break;
             if ((rc = linear(d, w.attn_proj, d->att, nullptr, d->h1, S, D, RGRG_ACT_NONE, c, true))) break;
             if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, c, true))) break;
             if ((rc = linear(d, w.mlp_proj, d->ff, nullptr, d->h1, S, D, RGRG_ACT_NONE, c, true))) break;
         }
-        if (!rc) rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, c, true, true);
+        if (!rc && fused) {
+            const Lin& pm = d->layers[d->n_layer - 1].mlp_proj;
+            XSrc xf{};
+            xf.x = d->x; xf.part = d->part; xf.pbias = pm.b; xf.KS = pm.KS; xf.ldp = pm.NT * pm.ntile; xf.g = d->lnf_g; xf.b = d->lnf_b;
+            rc = ln_linear(d, d->lm_head, xf, d->logits, S, d->ld_logits, RGRG_ACT_NONE, c, true);
+        } else if (!rc) rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, c, true, true);
         if (rc) break;
         RGRG_HIP(hipEventRecord(e1, d->stream));
         RGRG_HIP(hipEventSynchronize(e1));
