@@ -47,12 +47,13 @@ static int skinny_max_rows() {
         if (v > SKINNY_MAX_ROWS) v = SKINNY_MAX_ROWS; if (v < 32) v = 32; }
     return v;
 }
-// Decode plan for <= 128 token rows.  1 (experimental, RGRG_DECODE_PLAN=1): fused - 5 launches per layer (LayerNorm, split-K combine and the
-// embedding are rebuilt by the consumer GEMM while it stages its activations; attn_proj keeps the whole K in one
-// workgroup and adds bias + residual itself).  0 (default): the round-1 sequence (7 launches per layer).
+// Decode plan for <= 128 token rows.  1 (default): fused, fragment-direct (skinny_direct.inc) - 5 launches per layer:
+// LayerNorm folded into the consumer GEMM's weights, split-K combine and embedding rebuilt while the consumer loads its
+// A fragments, attn_proj adds bias + residual itself.  0 (RGRG_DECODE_PLAN=0): the round-1 sequence (7 launches per
+// layer, LDS-staged GEMMs, separate LayerNorm / combine kernels), kept for A/B timing.
 static int decode_plan() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("RGRG_DECODE_PLAN"); v = e ? atoi(e) : 0; }
+    if (v < 0) { const char* e = getenv("RGRG_DECODE_PLAN"); v = e ? atoi(e) : 1; }
     return v;
 }
 constexpr int BOS_ID = 50256, EOS_ID = 50256, PAD_ID = 50256;
@@ -348,329 +349,8 @@ __global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32_wide(const SkinnyArg
 }
 
 
-// ------------------------------------------------------------------ LayerNorm-fused skinny GEMMs (fused decode plan)
-// Where the 32 activation rows of a K = 1024 GEMM come from.  The fused decode plan has no LayerNorm /
-// split-K-combine / embedding launches: every workgroup of the CONSUMER GEMM rebuilds its activation tile while
-// staging it into LDS (the tile is staged by every workgroup anyway):
-//     v   = x[row] (+ pbias + sum_ks part[ks][row], fixed order)        residual stream after the producer GEMM
-//         | wte[token(row)] + wte[step]                                  embedding (quirk language_model.py:307)
-//     xn  = LayerNorm(v) * g + b                                         (nn.LayerNorm(1024, eps 1e-5), two-pass)
-// Workgroup (0,0) also writes v to `xout` - the residual stream the next residual add reads.  `xout` never
-// aliases `x` (other workgroups are still reading it): the plan ping-pongs two buffers.
-struct XSrc {
-    const float* x;
-    const float* part;   // [row tile][KS][32][ldp] partial sums of the producer GEMM, or null
-    const float* pbias;  // bias of the producer GEMM (added with the partials)
-    int KS, ldp;
-    float* xout;
-    const float* g;      // LayerNorm weight / bias; null: no LayerNorm (plain staging)
-    const float* b;
-    const float* wte;    // embedding mode when non-null
-    const long long* ids;
-    int ld_ids;
-    const int* step;
-    const int* tok_override;
-};
+#include "skinny_direct.inc"
 
-constexpr int LNG_K = 1024, LNG_LDX = LNG_K + 4, LNG_XQ = 16;  // 32 rows x 256 float4 over 512 threads
-
-// Row tile `mt` (32 rows x 1024) of the consumer GEMM's activations, first into registers (stage_load: thread t
-// holds column group t & 255 of rows (t >> 8) + 2q, q = 0..15), then into smem[32][LNG_LDX] + LayerNorm in place
-// (stage_finish, ends with a __syncthreads()).  512 threads.  MODE is a compile-time switch so that the 16..80 loads
-// of a thread are branch-free: 0 = x, 1 = x + pbias + 4 split-K partials, 2 / 3 = embedding of ids / of tok_override.  Rows >= M are read like any
-// other row (every buffer is padded to a multiple of 32 rows) and produce values that never reach a stored output.
-constexpr int XS_PLAIN = 0, XS_COMBINE4 = 1, XS_EMBED = 2, XS_EMBED_TOK = 3;
-// Order of the requests matters because vector loads return IN ORDER: the activation rows go first, then the
-// LayerNorm parameters, and the caller's HBM weight stream (`issue_weights`, called once) last - right after the last
-// activation request - so that no wait on an activation load ever waits for an HBM miss.
-template <int MODE, typename F>
-__device__ __forceinline__ void stage_load(f32x4 (&xr)[LNG_XQ], f32x4 (&gg)[4], f32x4 (&bb)[4], const XSrc& xs, int mt,
-                                           F&& issue_weights) {
-    const int tid = threadIdx.x;
-    // LayerNorm parameters (first touch per XCD comes from HBM: requested AFTER the activations, which the L2 / MALL
-    // serve faster and which are needed first), then the weight stream
-    auto issue_tail = [&]() {
-        if (xs.g) {
-            const int lane = tid & 63;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                gg[i] = *reinterpret_cast<const f32x4*>(xs.g + lane * 4 + i * 256);
-                bb[i] = *reinterpret_cast<const f32x4*>(xs.b + lane * 4 + i * 256);
-            }
-        }
-        issue_weights();
-    };
-    const int c4 = tid & 255, r0 = mt * 32 + (tid >> 8);
-    // buffer loads: descriptor (SGPRs, built from kernel arguments) + ONE 32-bit per-thread offset + a scalar offset
-    // per load - the 16..80 loads of a thread share one address register instead of holding 80 pointer pairs
-    auto ldb = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) -> f32x4 {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
-    };
-    const unsigned voff_x = (unsigned)(tid >> 8) * (LNG_K * 4u) + (unsigned)c4 * 16u;
-    if constexpr (MODE == XS_EMBED || MODE == XS_EMBED_TOK) {
-        const int t = *xs.step;
-        long long tok[LNG_XQ];
-#pragma unroll
-        for (int q = 0; q < LNG_XQ; ++q) {
-            if constexpr (MODE == XS_EMBED_TOK) tok[q] = (long long)xs.tok_override[r0 + 2 * q];  // beam search feeds the beam tokens
-            else tok[q] = xs.ids[(size_t)(r0 + 2 * q) * xs.ld_ids + t];
-        }
-        const f32x4 pos = reinterpret_cast<const f32x4*>(xs.wte + (size_t)t * LNG_K)[c4];
-        f32x4 e[LNG_XQ];
-#pragma unroll
-        for (int q = 0; q < LNG_XQ; ++q) e[q] = reinterpret_cast<const f32x4*>(xs.wte + (size_t)tok[q] * LNG_K)[c4];
-        __builtin_amdgcn_sched_barrier(0);
-        issue_tail();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < LNG_XQ; ++q) xr[q] = e[q] + pos;
-    } else {
-        const unsigned xrow0 = (unsigned)mt * 32 * LNG_K * 4;
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs.x), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-        for (int q = 0; q < LNG_XQ; ++q) xr[q] = ldb(rx, voff_x, xrow0 + (unsigned)q * (2 * LNG_K * 4));
-        if constexpr (MODE == XS_PLAIN) {
-            __builtin_amdgcn_sched_barrier(0);
-            issue_tail();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (MODE == XS_COMBINE4) {
-            // 4 partial sums per element = 64 more 16-byte loads per thread, software-pipelined over the K slices:
-            // slice ks + 1 is requested before slice ks is added.  Per element: ((((x + p0) + p1) + p2) + p3) + bias.
-            // The producer has N = 1024 outputs: partial rows are LNG_K floats (checked by the host).
-            const f32x4 pb = reinterpret_cast<const f32x4*>(xs.pbias)[c4];
-            constexpr unsigned ksz = PAD_ROWS * LNG_K * 4, rsz2 = LNG_K * 8;  // bytes: one K slice, two rows
-            const unsigned prow0 = (unsigned)mt * 4 * ksz;
-            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs.part), 0, 0x7fffffff, 0x00020000);
-            // round r = (K slice r >> 1, rows half r & 1): 8 loads per round, two rounds in flight
-            constexpr int HQ = LNG_XQ / 2;
-            f32x4 pa[HQ], pc[HQ];
-#define XS_ISSUE(buf, r) _Pragma("unroll") for (int q = 0; q < HQ; ++q) buf[q] = ldb(rp, voff_x, prow0 + ((r) >> 1) * ksz + (((r) & 1) * HQ + q) * rsz2)
-// the empty asm pins each add between its two sched_barriers: without it the pure adds sink down to the LDS store and
-// all 80 loaded values stay live (spills)
-#define XS_ADD(buf, r) _Pragma("unroll") for (int q = 0; q < HQ; ++q) { xr[((r) & 1) * HQ + q] += buf[q]; asm volatile("" : "+v"(xr[((r) & 1) * HQ + q])); }
-            XS_ISSUE(pa, 0);
-            XS_ISSUE(pc, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            XS_ADD(pa, 0); XS_ISSUE(pa, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            XS_ADD(pc, 1); XS_ISSUE(pc, 3);
-            __builtin_amdgcn_sched_barrier(0);
-            XS_ADD(pa, 2); XS_ISSUE(pa, 4);
-            __builtin_amdgcn_sched_barrier(0);
-            XS_ADD(pc, 3); XS_ISSUE(pc, 5);
-            __builtin_amdgcn_sched_barrier(0);
-            XS_ADD(pa, 4); XS_ISSUE(pa, 6);
-            __builtin_amdgcn_sched_barrier(0);
-            XS_ADD(pc, 5); XS_ISSUE(pc, 7);
-            __builtin_amdgcn_sched_barrier(0);
-            issue_tail();
-            __builtin_amdgcn_sched_barrier(0);
-            XS_ADD(pa, 6);
-            __builtin_amdgcn_sched_barrier(0);
-            XS_ADD(pc, 7);
-#undef XS_ISSUE
-#undef XS_ADD
-#pragma unroll
-            for (int q = 0; q < LNG_XQ; ++q) xr[q] += pb;
-        }
-    }
-}
-
-// `nrows_lds` < 32 (wide kernel): rows beyond it are not written to LDS.  `writer`: this workgroup also stores the
-// (combined / embedded) residual stream rows to xs.xout.
-__device__ __forceinline__ void stage_finish(float* smem, const f32x4 (&xr)[LNG_XQ], const XSrc& xs, int mt, int M,
-                                             int nrows_lds, bool writer, const f32x4 (&gg)[4], const f32x4 (&bb)[4]) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c4 = tid & 255, r0 = mt * 32 + (tid >> 8);
-#pragma unroll
-    for (int q = 0; q < LNG_XQ; ++q) {
-        const int lrow = (tid >> 8) + 2 * q;
-        if (writer && xs.xout && r0 + 2 * q < M) reinterpret_cast<f32x4*>(xs.xout + (size_t)(r0 + 2 * q) * LNG_K)[c4] = xr[q];
-        if (lrow < nrows_lds) *reinterpret_cast<f32x4*>(&smem[lrow * LNG_LDX + c4 * 4]) = xr[q];
-    }
-    __syncthreads();
-    if (xs.g) {
-        // wave w normalises rows w, w+8, w+16, w+24 of the tile (a lane holds 16 floats of a row); the four rows are
-        // independent dependency chains issued together, reductions by DPP (no LDS round trips).  Rows beyond
-        // nrows_lds are computed from a clamped (valid) row and not written back.
-        f32x4 v[4][4];
-        float s[4], s2[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int lrow = min(wave + 8 * rr, nrows_lds - 1);
-            const float* rp = &smem[lrow * LNG_LDX + lane * 4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[rr][i] = *reinterpret_cast<const f32x4*>(rp + i * 256);
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            s[rr] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s[rr] += (v[rr][i][0] + v[rr][i][1]) + (v[rr][i][2] + v[rr][i][3]);
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) s[rr] = wave_sum_dpp(s[rr]) / (float)LNG_K;  // mean
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            s2[rr] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[rr][i][e] -= s[rr];
-                s2[rr] += (v[rr][i][0] * v[rr][i][0] + v[rr][i][1] * v[rr][i][1]) + (v[rr][i][2] * v[rr][i][2] + v[rr][i][3] * v[rr][i][3]);
-            }
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) s2[rr] = 1.0f / sqrtf(wave_sum_dpp(s2[rr]) / (float)LNG_K + LN_EPS);  // rstd
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            if (wave + 8 * rr < nrows_lds) {
-                float* rp = &smem[(wave + 8 * rr) * LNG_LDX + lane * 4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = v[rr][i][e] * s2[rr] * gg[i][e] + bb[i][e];
-                    *reinterpret_cast<f32x4*>(rp + i * 256) = o;
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// c_attn / c_fc of the fused plan: K = 1024 in one workgroup, 16-column tiles (192 / 256 workgroups); request order
-// in stage_load: LayerNorm parameters, activation tile (L2 / MALL; up to 80 loads per thread, pipelined), and last the
-// wave's 8 one-KiB weight chunks (HBM), which land during the LDS write + LayerNorm.
-template <int MT, int MODE>
-__global__ __launch_bounds__(512) void rgrg_skinny_ln_gemm_f32(const SkinnyArgs a, const XSrc xs) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int PW = 8, KC = 16, NACC = 8, LDX = LNG_LDX;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt = blockIdx.x;
-    const int chunks = a.K / KC;
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.P) + ((size_t)nt * chunks + wave * PW) * 64 + lane;
-    f32x4 w[PW];
-    auto issue_weights = [&]() {
-#pragma unroll
-        for (int c = 0; c < PW; ++c) w[c] = __builtin_nontemporal_load(wp + (size_t)c * 64);
-    };
-    f32x4 xr[LNG_XQ], gg[4], bb[4];
-    stage_load<MODE>(xr, gg, bb, xs, 0, issue_weights);
-    float acc[MT][NACC];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        if (mt > 0) {
-            stage_load<MODE>(xr, gg, bb, xs, mt, [] {});
-            __syncthreads();  // every wave has finished reading the previous tile
-        }
-        stage_finish(smem, xr, xs, mt, a.M, 32, nt == 0, gg, bb);
-        f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        const float* xa = &smem[(lane & 15) * LDX + wave * PW * KC + (lane >> 4) * 4];
-#pragma unroll
-        for (int c = 0; c < PW; ++c) {
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xa + c * KC);
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(xa + 16 * LDX + c * KC);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], w[c][j], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], w[c][j], acc1, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { acc[mt][r] = acc0[r]; acc[mt][4 + r] = acc1[r]; }
-    }
-    float* red = smem;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < NACC; ++r) red[(wave * NACC + r) * 64 + lane] = acc[mt][r];
-        __syncthreads();
-        const int half = tid >> 8, r = (tid >> 6) & 3, l = tid & 63;
-        float v = red[(0 * 8 + half * 4 + r) * 64 + l];
-#pragma unroll
-        for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[(w2 * 8 + half * 4 + r) * 64 + l];
-        skinny_store(a, mt * 32 + half * 16 + (l >> 4) * 4 + r, nt * 16 + (l & 15), v);
-    }
-}
-
-// lm_head of the fused plan: rgrg_skinny_gemm_f32_wide with the activation rows taken from stage_rows_ln
-// (final LayerNorm + the last mlp_proj's split-K combine)
-template <int MODE>
-__global__ __launch_bounds__(512) void rgrg_skinny_ln_gemm_f32_wide(const SkinnyArgs a, const XSrc xs) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int PW = 16, KC = 8, LDX = LNG_LDX;
-    float* red = smem + a.M * LDX;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunks = a.K / KC;
-    const float* xa = &smem[(lane & 31) * LDX + wave * PW * KC + (lane >> 5) * 4];
-    const f32x4* wbase = reinterpret_cast<const f32x4*>(a.P) + ((size_t)wave * PW) * 64 + lane;
-    f32x4 wa[8], wb[8];
-    auto load8 = [&](f32x4(&w)[8], int nt, int half) {
-        const f32x4* wp = wbase + ((size_t)nt * chunks + half * 8) * 64;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) w[c] = __builtin_nontemporal_load(wp + (size_t)c * 64);
-    };
-    int nt = blockIdx.x;
-    {
-        f32x4 xr[LNG_XQ], gg[4], bb[4];
-        stage_load<MODE>(xr, gg, bb, xs, 0, [&]() { if (nt < a.NT) { load8(wa, nt, 0); load8(wb, nt, 1); } });
-        stage_finish(smem, xr, xs, 0, a.M, a.M, false, gg, bb);
-    }
-    for (; nt < a.NT; nt += gridDim.x) {
-        const int nxt = nt + gridDim.x;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(xa + c * KC);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], wa[c][j], acc, 0, 0, 0);
-        }
-        if (nxt < a.NT) load8(wa, nxt, 0);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(xa + (8 + c) * KC);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], wb[c][j], acc, 0, 0, 0);
-        }
-        if (nxt < a.NT) load8(wb, nxt, 1);
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int idx = tid + 512 * q;
-            const int r = idx >> 6, l = idx & 63;
-            float v = red[r * 64 + l];
-#pragma unroll
-            for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[(w2 * 16 + r) * 64 + l];
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-            const int col = nt * 32 + (l & 31);
-            skinny_store(a, row, col, v);
-            if (a.cand_val) {
-                float bv = (col < a.N) ? v + (a.bias ? a.bias[col] : 0.f) : -INFINITY;
-                int bi = col;
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(bv, o, 64);
-                    const int oi = __shfl_xor(bi, o, 64);
-                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                }
-                if ((l & 31) == 0 && row < a.M) {
-                    a.cand_val[(size_t)row * a.NT + nt] = bv;
-                    a.cand_idx[(size_t)row * a.NT + nt] = bi;
-                }
-            }
-        }
-    }
-}
-
-constexpr size_t LNG_LDS = (size_t)32 * LNG_LDX * sizeof(float);
 constexpr int WIDE_MAX_ROWS = 31;  // 31 staged rows + the 32 KiB reduction buffer fill the 160 KiB LDS
 constexpr size_t WIDE_LDS = (size_t)(WIDE_MAX_ROWS * (16 * SK_WAVES * 8 + 4) + SK_WAVES * 16 * 64) * sizeof(float);
 static_assert(WIDE_LDS <= 160 * 1024, "wide skinny GEMM must fit the 160 KiB LDS");
@@ -834,7 +514,7 @@ template <bool HAS_SRC>  // beam search: per-slot ancestor table (one more depen
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                           float* __restrict__ kc, float* __restrict__ vc,
                                                           const int* __restrict__ step, float* __restrict__ out,
-                                                          int S, int H, int T, const int* __restrict__ src) {
+                                                          int S, int H, int T, const int* __restrict__ src, int frag_out) {
     __shared__ float pm[16], pl[16];
     __shared__ __attribute__((aligned(16))) float pacc[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -913,7 +593,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
             L += pl[k] * wgt;
             o += pacc[k][threadIdx.x] * wgt;
         }
-        out[(size_t)s * D + hd * 64 + threadIdx.x] = o / L;
+        // fused plan: the attention output is attn_proj's A operand -> fragment-major (skinny_direct.inc)
+        out[frag_out ? frag_off(s, hd * 64 + threadIdx.x, D) : (size_t)s * D + hd * 64 + threadIdx.x] = o / L;
     }
 }
 
@@ -1504,6 +1185,10 @@ struct Lin {
     float* wT = nullptr;       // [K][Np] transposed copy, Np = N rounded up to 256 (backward pass: dX = dY W)
     void* wTb = nullptr;       // bf16 copy of wT (training under autocast)
     int N = 0, K = 0, NT = 0, KS = 1, ntile = 32;
+    // fused decode plan (skinny_direct.inc): `packed` holds 16-column fragments, pre-scaled by the LayerNorm weight of
+    // the LayerNorm this GEMM consumes when lnf is set; c1 / c2 are the folded vectors of that LayerNorm
+    bool direct = false, lnf = false;
+    float *c1 = nullptr, *c2 = nullptr;
 };
 
 struct LayerW {
@@ -1580,16 +1265,30 @@ static int pick_ks(int NT, int chunks) {
     return ks;
 }
 
-static int make_lin(rgrg_decoder* d, Lin& l, const float* w, const float* b, int N, int K, bool pack) {
+static int make_lin(rgrg_decoder* d, Lin& l, const float* w, const float* b, int N, int K, bool pack,
+                    bool direct = false, const float* ln_g = nullptr, const float* ln_b = nullptr) {
     l.w = w; l.b = b; l.N = N; l.K = K;
+    if (direct && decode_plan() == 1) {
+        // fused plan: 16-column tiles, one 1024-wide K slice per workgroup (mlp_proj: 4 slices -> 256 workgroups, the
+        // fp32 MFMA work needs every CU; the 4 partial sums are added by the consumer while it loads its fragments)
+        if (K % DK_SLICE != 0 || (ln_g && K != DK_SLICE)) { set_error("decoder: K=%d unsupported by the fused plan", K); return RGRG_EINVAL; }
+        l.direct = true; l.ntile = 16; l.KS = K / DK_SLICE; l.NT = (N + 15) / 16; l.lnf = ln_g != nullptr;
+        int rc = dmalloc(d, (void**)&l.packed, (size_t)l.NT * 16 * K * sizeof(float), false);
+        if (rc) return rc;
+        hipLaunchKernelGGL(pack_weights16_scaled_kernel, dim3(2048), dim3(256), 0, d->stream, w, ln_g, l.packed, N, K, l.NT);
+        RGRG_LAUNCH_CHECK();
+        if (l.lnf) {
+            if ((rc = dmalloc(d, (void**)&l.c1, (size_t)N * sizeof(float), false)) ||
+                (rc = dmalloc(d, (void**)&l.c2, (size_t)N * sizeof(float), false)))
+                return rc;
+            hipLaunchKernelGGL(ln_fold_vectors_kernel, dim3((N + 3) / 4), dim3(256), 0, d->stream, w, ln_g, ln_b, b, l.c1, l.c2, N, K);
+            RGRG_LAUNCH_CHECK();
+        }
+        return RGRG_OK;
+    }
     if (K == 1024 && N >= 2048 && N <= 8192) {
         // c_attn / c_fc: 16-column tiles -> 192 / 256 workgroups with the whole K each (no partial sums)
         l.ntile = 16; l.KS = 1;
-    } else if (decode_plan() == 1 && N == 1024 && (K == 1024 || K == 4096)) {
-        // fused plan: attn_proj (and fst-nn) keep K in the workgroup (64 workgroups, bias + residual in the epilogue);
-        // mlp_proj splits K over 4 workgroups per 16-column tile (256 workgroups: the fp32 MFMA work needs every CU),
-        // the 4 partial sums are combined by the consumer's staging (XSrc)
-        l.ntile = 16; l.KS = (K == 1024) ? 1 : 4;
     } else {
         l.ntile = 32;
         l.KS = pick_ks((N + 31) / 32, K / 8);
@@ -1633,18 +1332,6 @@ static int skinny_attr() {
     if ((rc = skinny_attr1<NTILE, PW, 3>())) return rc;
     return skinny_attr1<NTILE, PW, 4>();
 }
-template <int MT>
-static int ln_gemm_attr() {
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_ln_gemm_f32<MT, XS_PLAIN>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LNG_LDS));
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_ln_gemm_f32<MT, XS_COMBINE4>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LNG_LDS));
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_ln_gemm_f32<MT, XS_EMBED>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LNG_LDS));
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_ln_gemm_f32<MT, XS_EMBED_TOK>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LNG_LDS));
-    return RGRG_OK;
-}
 static int init_skinny_attrs() {
     int rc;
     if ((rc = skinny_attr<32, 4>())) return rc;
@@ -1653,10 +1340,6 @@ static int init_skinny_attrs() {
     if ((rc = skinny_attr<16, 4>())) return rc;
     RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_gemm_f32_wide),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS));
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_ln_gemm_f32_wide<XS_COMBINE4>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS));
-    int rc2;
-    if ((rc2 = ln_gemm_attr<1>()) || (rc2 = ln_gemm_attr<2>()) || (rc2 = ln_gemm_attr<3>()) || (rc2 = ln_gemm_attr<4>())) return rc2;
     return skinny_attr<16, 8>();
 }
 
@@ -1671,7 +1354,7 @@ static bool kv_is_bf16(const rgrg_decoder* d, int rows) { return d->bf16_gemms &
 static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R, float* Y, int M, int ldy, int act,
                   bool count, bool defer = false, bool cand = false, const unsigned short* X16 = nullptr,
                   unsigned short* Y16 = nullptr) {
-    if (M <= skinny_max_rows() && l.packed) {
+    if (M <= skinny_max_rows() && l.packed && !l.direct) {
         // up to 4 row tiles of 32 sequences in ONE launch: the weights stay in registers across the tiles
         SkinnyArgs a{X, l.packed, l.b, R, Y, d->part, M, l.K, l.N, l.NT, l.KS, ldy, act, nullptr, nullptr, l.ntile};
         if (cand && l.KS == 1 && l.ntile == 32) { a.cand_val = d->cand_val; a.cand_idx = d->cand_idx; }
@@ -1694,40 +1377,7 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
 }
 
 
-// Y[:M] = act(LN(xs) W^T + b) on the LayerNorm-fused skinny GEMM (K = 1024, 16-column tiles, whole K per workgroup)
-static int ln_linear(rgrg_decoder* d, const Lin& l, const XSrc& xs, float* Y, int M, int ldy, int act, bool count,
-                     bool cand = false) {
-    if (l.K != LNG_K || !l.packed) { set_error("ln_linear: K=%d unsupported", l.K); return RGRG_EINVAL; }
-    SkinnyArgs a{nullptr, l.packed, l.b, nullptr, Y, nullptr, M, l.K, l.N, l.NT, 1, ldy, act, nullptr, nullptr, l.ntile};
-    const int mode = xs.wte ? (xs.tok_override ? XS_EMBED_TOK : XS_EMBED) : (xs.part ? XS_COMBINE4 : XS_PLAIN);
-    if (mode == XS_COMBINE4 && (xs.KS != 4 || xs.ldp != LNG_K)) { set_error("ln_linear: the producer must split K 4 ways over %d columns (got %d, %d)", LNG_K, xs.KS, xs.ldp); return RGRG_EINVAL; }
-    const dim3 blk(64 * SK_WAVES);
-    if (l.ntile == 32) {  // lm_head: persistent wide kernel
-        if (!(l.KS == 1 && l.NT > 512 && M <= WIDE_MAX_ROWS && mode == XS_COMBINE4)) { set_error("ln_linear: wide kernel needs <= %d rows", WIDE_MAX_ROWS); return RGRG_EINVAL; }
-        if (cand) { a.cand_val = d->cand_val; a.cand_idx = d->cand_idx; }
-        hipLaunchKernelGGL(rgrg_skinny_ln_gemm_f32_wide<XS_COMBINE4>, dim3(256), blk, WIDE_LDS, d->stream, a, xs);
-    } else {
-        if (l.KS != 1) { set_error("ln_linear: split-K layer"); return RGRG_EINVAL; }
-        const int mt = (M + PAD_ROWS - 1) / PAD_ROWS;
-#define LNG_LAUNCH(MT_, MODE_) hipLaunchKernelGGL((rgrg_skinny_ln_gemm_f32<MT_, MODE_>), dim3(l.NT), blk, LNG_LDS, d->stream, a, xs)
-#define LNG_MODES(MT_) do { if (mode == XS_PLAIN) LNG_LAUNCH(MT_, XS_PLAIN); else if (mode == XS_COMBINE4) LNG_LAUNCH(MT_, XS_COMBINE4); else if (mode == XS_EMBED) LNG_LAUNCH(MT_, XS_EMBED); else LNG_LAUNCH(MT_, XS_EMBED_TOK); } while (0)
-        if (mt == 1) LNG_MODES(1);
-        else if (mt == 2) LNG_MODES(2);
-        else if (mt == 3) LNG_MODES(3);
-        else if (mt == 4) LNG_MODES(4);
-        else { set_error("ln_linear: %d rows exceed 4 row tiles", M); return RGRG_EINVAL; }
-#undef LNG_MODES
-#undef LNG_LAUNCH
-    }
-    RGRG_LAUNCH_CHECK();
-    if (count) {
-        d->gemm_bytes_per_step += (size_t)l.N * l.K * sizeof(float);
-        d->gemm_launches_per_step += 1;
-    }
-    return RGRG_OK;
-}
-
-static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsigned short* att16) {
+static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsigned short* att16, int frag_out = 0) {
     hipStream_t st = d->stream;
     const int D = d->D;
     float* kc = d->kv + (size_t)l * d->kv_layer_stride;
@@ -1742,56 +1392,105 @@ static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsig
                                kc16 + d->kv_kv_stride, d->step, d->att, S, d->H, d->T, src, att16);
     } else if (src)
         hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc, vc, d->step,
-                           d->att, S, d->H, d->T, src);
+                           d->att, S, d->H, d->T, src, frag_out);
     else
         hipLaunchKernelGGL(attn_decode_kernel<false>, dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc, vc, d->step,
-                           d->att, S, d->H, d->T, src);
+                           d->att, S, d->H, d->T, src, frag_out);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
 
+// One GEMM of the fused plan.  `a` arrives with the operand / output pointers and `act` set; the layer fills the rest.
+static int direct_linear(rgrg_decoder* d, const Lin& l, DirectArgs a, int mode, int M, bool count, bool cand = false) {
+    if (!l.direct) { set_error("direct_linear: layer was not packed for the fused plan"); return RGRG_EINVAL; }
+    if (l.lnf && mode == DX_PLAIN && !a.Xf) { set_error("direct_linear: missing operand"); return RGRG_EINVAL; }
+    a.P = l.packed; a.bias = l.lnf ? l.c2 : l.b; a.c1 = l.c1;
+    a.M = M; a.K = l.K; a.N = l.N; a.NT = l.NT; a.KS = l.KS;
+    if (l.KS > 1) a.part_out = d->part;
+    if (cand) { a.cand_val = d->cand_val; a.cand_idx = d->cand_idx; }
+    const int mt = (M + PAD_ROWS - 1) / PAD_ROWS;
+    const dim3 grid(l.NT, l.KS), blk(64 * SK_WAVES);
+    hipStream_t st = d->stream;
+    if (l.lnf && mode == DX_COMBINE4 && l.NT > 512 && mt == 1) {  // lm_head, one row tile: persistent kernel
+        hipLaunchKernelGGL((rgrg_skinny_direct_wide_f32<DX_COMBINE4, true>), dim3(256), blk, 0, st, a);
+    } else {
+#define DX_LAUNCH(MT_, MODE_, LNF_) hipLaunchKernelGGL((rgrg_skinny_direct_f32<MT_, MODE_, LNF_>), grid, blk, 0, st, a)
+#define DX_MODES(MT_)                                                                        \
+    do {                                                                                     \
+        if (!l.lnf && mode == DX_PLAIN) DX_LAUNCH(MT_, DX_PLAIN, false);                     \
+        else if (l.lnf && mode == DX_PLAIN) DX_LAUNCH(MT_, DX_PLAIN, true);                  \
+        else if (l.lnf && mode == DX_COMBINE4) DX_LAUNCH(MT_, DX_COMBINE4, true);            \
+        else if (l.lnf && mode == DX_EMBED) DX_LAUNCH(MT_, DX_EMBED, true);                  \
+        else if (l.lnf && mode == DX_EMBED_TOK) DX_LAUNCH(MT_, DX_EMBED_TOK, true);          \
+        else { set_error("direct_linear: unsupported mode %d (lnf %d)", mode, (int)l.lnf); return RGRG_EINVAL; } \
+    } while (0)
+        if (mt == 1) DX_MODES(1);
+        else if (mt == 2) DX_MODES(2);
+        else if (mt == 3) DX_MODES(3);
+        else if (mt == 4) DX_MODES(4);
+        else { set_error("direct_linear: %d rows exceed 4 row tiles", M); return RGRG_EINVAL; }
+#undef DX_MODES
+#undef DX_LAUNCH
+    }
+    RGRG_LAUNCH_CHECK();
+    if (count) {
+        d->gemm_bytes_per_step += (size_t)l.N * l.K * sizeof(float);
+        d->gemm_launches_per_step += 1;
+    }
+    return RGRG_OK;
+}
+
+// The GEMMs of layer l of the fused plan (everything but the attention); `cur` holds x_mid of the previous layer in
+// fragment-major order with its mlp_proj partial sums pending in d->part, `nxt` receives this layer's residual stream.
+static int enqueue_layer_gemms(rgrg_decoder* d, int l, int S, bool count, const int* tok_override, const float* cur, float* nxt,
+                               int part) {  // part: 0 = c_attn', 1 = attn_proj' .. mlp_proj
+    const LayerW& w = d->layers[l];
+    const int D = d->D;
+    int rc;
+    if (part == 0) {
+        DirectArgs a{};
+        a.xout = nxt; a.Y = d->qkv; a.ldy = 3 * D; a.act = RGRG_ACT_NONE;
+        int mode;
+        if (l == 0) {
+            a.wte = d->wte; a.ids = d->ids; a.ld_ids = d->max_len; a.step = d->step; a.tok_override = tok_override;
+            mode = tok_override ? DX_EMBED_TOK : DX_EMBED;
+        } else {
+            a.Xf = cur; a.part = d->part;
+            mode = DX_COMBINE4;
+        }
+        return direct_linear(d, w.c_attn, a, mode, S, count);
+    }
+    DirectArgs p{};  // attn_proj': x += att W^T + b, in place (every element is read and written by the same thread)
+    p.Xf = d->att; p.Rf = nxt; p.Yf = nxt; p.act = RGRG_ACT_NONE;
+    if ((rc = direct_linear(d, w.attn_proj, p, DX_PLAIN, S, count))) return rc;
+    DirectArgs f{};  // c_fc': gelu_new(ln_2(x) W^T + b)
+    f.Xf = nxt; f.Yf = d->ff; f.act = RGRG_ACT_GELU_NEW;
+    if ((rc = direct_linear(d, w.c_fc, f, DX_PLAIN, S, count))) return rc;
+    DirectArgs m{};  // mlp_proj: 4 partial sums (slice 0 carries the bias)
+    m.Xf = d->ff; m.act = RGRG_ACT_NONE;
+    return direct_linear(d, w.mlp_proj, m, DX_PLAIN, S, count);
+}
+
 // One decode step of the fused plan (<= 128 token rows): 24 * 5 + 2 = 122 launches
-//   per layer: c_attn' [embedding | previous mlp_proj combine, + ln_1] -> attention -> attn_proj' [+ bias + residual,
-//   in place] -> c_fc' [ln_2, gelu] -> mlp_proj (4 partial sums)   |   lm_head' [combine + ln_f, arg-max candidates]
-//   -> argmax + bookkeeping.  The residual stream ping-pongs between d->x and d->x2.
+//   per layer: c_attn' [embedding | previous mlp_proj combine; ln_1 folded] -> attention -> attn_proj' [+ bias +
+//   residual, in place] -> c_fc' [ln_2 folded, gelu] -> mlp_proj (4 partial sums)
+//   lm_head' [combine; ln_f folded; arg-max candidates] -> argmax + bookkeeping.
+// The residual stream ping-pongs between d->x and d->x2; x, att, ff and the partial sums are fragment-major.
 static int enqueue_step_fused(rgrg_decoder* d, int S, bool count, const int* tok_override, const int* src, bool beam) {
     if (count) { d->gemm_bytes_per_step = 0; d->gemm_launches_per_step = 0; }
     hipStream_t st = d->stream;
-    const int D = d->D;
     int rc;
-    float* cur = d->x;   // holds x_mid of the previous layer (its mlp_proj partials are pending in d->part)
+    float* cur = d->x;
     float* nxt = d->x2;
-    const Lin* prev_mlp = nullptr;
     for (int l = 0; l < d->n_layer; ++l) {
-        const LayerW& w = d->layers[l];
-        XSrc xs{};
-        xs.g = w.ln1_g; xs.b = w.ln1_b; xs.xout = nxt;
-        if (l == 0) {
-            xs.wte = d->wte; xs.ids = d->ids; xs.ld_ids = d->max_len; xs.step = d->step; xs.tok_override = tok_override;
-        } else {
-            xs.x = cur; xs.part = d->part; xs.pbias = prev_mlp->b; xs.KS = prev_mlp->KS; xs.ldp = prev_mlp->NT * prev_mlp->ntile;
-        }
-        if ((rc = ln_linear(d, w.c_attn, xs, d->qkv, S, 3 * D, RGRG_ACT_NONE, count))) return rc;
-        if ((rc = launch_attention(d, l, S, src, nullptr))) return rc;
-        if ((rc = linear(d, w.attn_proj, d->att, nxt, nxt, S, D, RGRG_ACT_NONE, count))) return rc;
-        XSrc x2{};
-        x2.x = nxt; x2.g = w.ln2_g; x2.b = w.ln2_b;
-        if ((rc = ln_linear(d, w.c_fc, x2, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, count))) return rc;
-        if ((rc = linear(d, w.mlp_proj, d->ff, nullptr, nullptr, S, D, RGRG_ACT_NONE, count, true))) return rc;
-        prev_mlp = &w.mlp_proj;
+        if ((rc = enqueue_layer_gemms(d, l, S, count, tok_override, cur, nxt, 0))) return rc;
+        if ((rc = launch_attention(d, l, S, src, nullptr, 1))) return rc;
+        if ((rc = enqueue_layer_gemms(d, l, S, count, tok_override, cur, nxt, 1))) return rc;
         float* tmp = cur; cur = nxt; nxt = tmp;
     }
-    if (S <= WIDE_MAX_ROWS) {
-        XSrc xf{};
-        xf.x = cur; xf.part = d->part; xf.pbias = prev_mlp->b; xf.KS = prev_mlp->KS; xf.ldp = prev_mlp->NT * prev_mlp->ntile;
-        xf.g = d->lnf_g; xf.b = d->lnf_b;
-        if ((rc = ln_linear(d, d->lm_head, xf, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, !beam))) return rc;
-    } else {
-        hipLaunchKernelGGL(resid_ln_kernel, dim3(S), dim3(256), 0, st, cur, prev_mlp->b, d->part, prev_mlp->KS,
-                           prev_mlp->NT * prev_mlp->ntile, d->lnf_g, d->lnf_b, d->xn, D, (unsigned short*)nullptr);
-        RGRG_LAUNCH_CHECK();
-        if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, false, !beam))) return rc;
-    }
+    DirectArgs h{};
+    h.Xf = cur; h.part = d->part; h.Y = d->logits; h.ldy = d->ld_logits; h.act = RGRG_ACT_NONE;
+    if ((rc = direct_linear(d, d->lm_head, h, DX_COMBINE4, S, count, !beam))) return rc;
     if (beam) return RGRG_OK;
     hipLaunchKernelGGL(argmax_update_kernel, dim3(S), dim3(256), 0, st, d->cand_val, d->cand_idx, d->lm_head.NT, d->ids,
                        d->max_len, d->finished, d->step, d->done_len, d->sync, S);
@@ -1804,7 +1503,7 @@ static int enqueue_step_fused(rgrg_decoder* d, int S, bool count, const int* tok
 //   mlp_proj(partials), resid+ln1(next layer / ln_f) | lm_head, argmax+bookkeeping
 static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_override = nullptr, const int* src = nullptr,
                         bool beam = false) {
-    if (decode_plan() == 1 && S <= skinny_max_rows() && d->lm_head.packed) return enqueue_step_fused(d, S, count, tok_override, src, beam);
+    if (d->lm_head.direct && S <= skinny_max_rows()) return enqueue_step_fused(d, S, count, tok_override, src, beam);
     if (count) { d->gemm_bytes_per_step = 0; d->gemm_launches_per_step = 0; }
     hipStream_t st = d->stream;
     const int D = d->D;
@@ -1902,16 +1601,16 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     TRY(make_lin(d, d->fst0, w->fst0_w, w->fst0_b, D, D, true));
     TRY(make_lin(d, d->fst2, w->fst2_w, w->fst2_b, D, D, true));
     TRY(make_lin(d, d->ukv, w->ukv_w, w->ukv_b, w->n_layer * 2 * D, D, true));
-    TRY(make_lin(d, d->lm_head, w->wte, nullptr, w->vocab, D, true));
+    TRY(make_lin(d, d->lm_head, w->wte, nullptr, w->vocab, D, true, true, w->lnf_g, w->lnf_b));
     d->layers.resize(w->n_layer);
     for (int l = 0; l < w->n_layer; ++l) {
         const rgrg_decoder_layer_weights& s = w->layers[l];
         LayerW& t = d->layers[l];
         t.ln1_g = s.ln1_g; t.ln1_b = s.ln1_b; t.ln2_g = s.ln2_g; t.ln2_b = s.ln2_b;
-        TRY(make_lin(d, t.c_attn, s.c_attn_w, s.c_attn_b, 3 * D, D, true));
-        TRY(make_lin(d, t.attn_proj, s.attn_proj_w, s.attn_proj_b, D, D, true));
-        TRY(make_lin(d, t.c_fc, s.c_fc_w, s.c_fc_b, 4 * D, D, true));
-        TRY(make_lin(d, t.mlp_proj, s.mlp_proj_w, s.mlp_proj_b, D, 4 * D, true));
+        TRY(make_lin(d, t.c_attn, s.c_attn_w, s.c_attn_b, 3 * D, D, true, true, s.ln1_g, s.ln1_b));
+        TRY(make_lin(d, t.attn_proj, s.attn_proj_w, s.attn_proj_b, D, D, true, true));
+        TRY(make_lin(d, t.c_fc, s.c_fc_w, s.c_fc_b, 4 * D, D, true, true, s.ln2_g, s.ln2_b));
+        TRY(make_lin(d, t.mlp_proj, s.mlp_proj_w, s.mlp_proj_b, D, 4 * D, true, true));
     }
     const size_t R = d->rows;
     d->ld_logits = d->lm_head.NT * d->lm_head.ntile;
@@ -2617,7 +2316,7 @@ extern "C" int rgrg_decoder_time_gemms(rgrg_decoder* d, int S, int iters, float*
     d->gemm_launches_per_step = 0;
     float total = 0.f;
     int rc = RGRG_OK;
-    const bool fused = decode_plan() == 1 && S <= WIDE_MAX_ROWS;
+    const bool fused = d->lm_head.direct;
     // the 97 weight-streaming GEMM launches of one decode step, back to back in step order, between ONE
     // pair of events on the decoder's stream (the two event records amortise over the 97 launches)
     for (int it = 0; it < iters && !rc; ++it) {
@@ -2625,16 +2324,9 @@ extern "C" int rgrg_decoder_time_gemms(rgrg_decoder* d, int S, int iters, float*
         RGRG_HIP(hipEventRecord(e0, d->stream));
         for (int l = 0; l < d->n_layer && !rc; ++l) {
             const LayerW& w = d->layers[l];
-            if (fused) {  // the GEMM launches of the fused plan, LayerNorm / combine prologues included
-                XSrc xs{};
-                xs.x = d->x; xs.g = w.ln1_g; xs.b = w.ln1_b; xs.xout = d->x2;
-                xs.part = d->part; xs.pbias = w.mlp_proj.b; xs.KS = w.mlp_proj.KS; xs.ldp = w.mlp_proj.NT * w.mlp_proj.ntile;
-                if ((rc = ln_linear(d, w.c_attn, xs, d->qkv, S, 3 * D, RGRG_ACT_NONE, c))) break;
-                if ((rc = linear(d, w.attn_proj, d->att, d->x2, d->x2, S, D, RGRG_ACT_NONE, c))) break;
-                XSrc x2{};
-                x2.x = d->x2; x2.g = w.ln2_g; x2.b = w.ln2_b;
-                if ((rc = ln_linear(d, w.c_fc, x2, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, c))) break;
-                if ((rc = linear(d, w.mlp_proj, d->ff, nullptr, nullptr, S, D, RGRG_ACT_NONE, c, true))) break;
+            if (fused) {  // the GEMM launches of the fused plan (combine / folded LayerNorm included), step order
+                if ((rc = enqueue_layer_gemms(d, l ? l : 1, S, c, nullptr, d->x, d->x2, 0))) break;
+                if ((rc = enqueue_layer_gemms(d, l, S, c, nullptr, d->x, d->x2, 1))) break;
                 continue;
             }
             if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, c, true))) break;
@@ -2643,10 +2335,9 @@ extern "C" int rgrg_decoder_time_gemms(rgrg_decoder* d, int S, int iters, float*
             if ((rc = linear(d, w.mlp_proj, d->ff, nullptr, d->h1, S, D, RGRG_ACT_NONE, c, true))) break;
         }
         if (!rc && fused) {
-            const Lin& pm = d->layers[d->n_layer - 1].mlp_proj;
-            XSrc xf{};
-            xf.x = d->x; xf.part = d->part; xf.pbias = pm.b; xf.KS = pm.KS; xf.ldp = pm.NT * pm.ntile; xf.g = d->lnf_g; xf.b = d->lnf_b;
-            rc = ln_linear(d, d->lm_head, xf, d->logits, S, d->ld_logits, RGRG_ACT_NONE, c, true);
+            DirectArgs h{};
+            h.Xf = d->x; h.part = d->part; h.Y = d->logits; h.ldy = d->ld_logits; h.act = RGRG_ACT_NONE;
+            rc = direct_linear(d, d->lm_head, h, DX_COMBINE4, S, c, true);
         } else if (!rc) rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, c, true, true);
         if (rc) break;
         RGRG_HIP(hipEventRecord(e1, d->stream));
