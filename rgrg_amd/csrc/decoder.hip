@@ -1271,7 +1271,7 @@ static int make_lin(rgrg_decoder* d, Lin& l, const float* w, const float* b, int
     if (direct && decode_plan() == 1) {
         // fused plan: 16-column tiles, one 1024-wide K slice per workgroup (mlp_proj: 4 slices -> 256 workgroups, the
         // fp32 MFMA work needs every CU; the 4 partial sums are added by the consumer while it loads its fragments)
-        if (K % DK_SLICE != 0 || (ln_g && K != DK_SLICE)) { set_error("decoder: K=%d unsupported by the fused plan", K); return RGRG_EINVAL; }
+        if (!(K == DK_SLICE || (K == 4 * DK_SLICE && !ln_g && N == DK_SLICE))) { set_error("decoder: N=%d K=%d unsupported by the fused plan", N, K); return RGRG_EINVAL; }
         l.direct = true; l.ntile = 16; l.KS = K / DK_SLICE; l.NT = (N + 15) / 16; l.lnf = ln_g != nullptr;
         int rc = dmalloc(d, (void**)&l.packed, (size_t)l.NT * 16 * K * sizeof(float), false);
         if (rc) return rc;
@@ -1460,13 +1460,14 @@ static int enqueue_layer_gemms(rgrg_decoder* d, int l, int S, bool count, const 
         }
         return direct_linear(d, w.c_attn, a, mode, S, count);
     }
-    DirectArgs p{};  // attn_proj': x += att W^T + b, in place (every element is read and written by the same thread)
-    p.Xf = d->att; p.Rf = nxt; p.Yf = nxt; p.act = RGRG_ACT_NONE;
+    DirectArgs p{};  // attn_proj': x += att W^T + b, in place (every element is read and written by the same thread);
+    p.Xf = d->att; p.Rf = nxt; p.Yf = nxt; p.act = RGRG_ACT_NONE;  // its epilogue also zeroes mlp_proj's accumulators
+    p.zero_acc = d->part;
     if ((rc = direct_linear(d, w.attn_proj, p, DX_PLAIN, S, count))) return rc;
     DirectArgs f{};  // c_fc': gelu_new(ln_2(x) W^T + b)
     f.Xf = nxt; f.Yf = d->ff; f.act = RGRG_ACT_GELU_NEW;
     if ((rc = direct_linear(d, w.c_fc, f, DX_PLAIN, S, count))) return rc;
-    DirectArgs m{};  // mlp_proj: 4 partial sums (slice 0 carries the bias)
+    DirectArgs m{};  // mlp_proj: 4 K slices accumulate pairwise into d->part (slice 0 carries the bias)
     m.Xf = d->ff; m.act = RGRG_ACT_NONE;
     return direct_linear(d, w.mlp_proj, m, DX_PLAIN, S, count);
 }
