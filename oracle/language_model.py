@@ -29,9 +29,17 @@ def gelu_new(x: Tensor) -> Tensor:
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
 
 
-def conv1d(sd: SD, p: str, x: Tensor) -> Tensor:
-    """HF Conv1D / Conv1DWithTrainedWeights: weight is [in,out] (:22,27)."""
+def _r16(t: Tensor) -> Tensor:
+    """Round to bfloat16 and back (what a bf16 store / operand conversion does; round to nearest even)."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def conv1d(sd: SD, p: str, x: Tensor, bf16: bool = False) -> Tensor:
+    """HF Conv1D / Conv1DWithTrainedWeights: weight is [in,out] (:22,27).  ``bf16``: emulation of the reference's
+    autocast GEMM (both operands rounded to bf16, fp32 accumulation, fp32 bias) - used to check the opt-in bf16 path."""
     w = sd[p + "weight"]
+    if bf16:
+        x, w = _r16(x), _r16(w)
     return torch.addmm(sd[p + "bias"], x.reshape(-1, x.shape[-1]), w).view(*x.shape[:-1], w.shape[-1])
 
 
@@ -41,13 +49,18 @@ def _heads(t: Tensor) -> Tensor:
 
 def pseudo_attention(sd: SD, p: str, x: Tensor, img: Tensor, add_mask: Tensor,
                      past: Optional[Tuple[Tensor, Tensor]], drop_probs: Optional[Tensor] = None,
-                     drop_out: Optional[Tensor] = None) -> Tuple[Tensor, Tuple[Tensor, Tensor]]:
+                     drop_out: Optional[Tensor] = None, bf16: bool = False) -> Tuple[Tensor, Tuple[Tensor, Tensor]]:
     """GPT2PseudoAttention.forward (:124-180).  x [S,T,1024]; img [S,1024] (already
-    through feature_space_transformation_nn); add_mask [S,1,1,1+T_total]."""
-    q, k, v = conv1d(sd, p + "c_attn.", x).split(D_MODEL, dim=2)
+    through feature_space_transformation_nn); add_mask [S,1,1,1+T_total].  ``bf16``: bf16 GEMM operands and a bf16
+    K/V cache (the reference under autocast), scores / softmax / accumulation in fp32."""
+    q, k, v = conv1d(sd, p + "c_attn.", x, bf16).split(D_MODEL, dim=2)
+    if bf16:
+        k, v = _r16(k), _r16(v)
     if past is None:
         k_img = F.linear(img[:, None, :], sd[p + "uk.weight"], sd[p + "uk.bias"])
         v_img = F.linear(img[:, None, :], sd[p + "uv.weight"], sd[p + "uv.bias"])
+        if bf16:
+            k_img, v_img = _r16(k_img), _r16(v_img)
         K = _heads(torch.cat((k_img, k), dim=1))
         V = _heads(torch.cat((v_img, v), dim=1))
     else:
@@ -63,7 +76,7 @@ def pseudo_attention(sd: SD, p: str, x: Tensor, img: Tensor, add_mask: Tensor,
     if drop_probs is not None:  # attn_dropout (:116) with an explicit mask (0 or 1/(1-p)), train mode only
         w = w * drop_probs
     o = torch.matmul(w, V).permute(0, 2, 1, 3).reshape(x.shape[0], ql, D_MODEL)
-    a = conv1d(sd, p + "c_proj.", o)
+    a = conv1d(sd, p + "c_proj.", o, bf16)
     if drop_out is not None:    # resid_dropout (:178)
         a = a * drop_out.view_as(a)
     return a, (K, V)
@@ -71,8 +84,10 @@ def pseudo_attention(sd: SD, p: str, x: Tensor, img: Tensor, add_mask: Tensor,
 
 def lm_forward(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_states: Tensor,
                past: Optional[List[Tuple[Tensor, Tensor]]], position_ids: Tensor, p: str = "language_model.",
-               drop_masks: Optional[Dict[Tuple[int, int], Tensor]] = None):
-    """LanguageModel.forward(return_loss=False, use_cache=True) (:258-366)."""
+               drop_masks: Optional[Dict[Tuple[int, int], Tensor]] = None, bf16: bool = False):
+    """LanguageModel.forward(return_loss=False, use_cache=True) (:258-366).  ``bf16``: the decoder blocks and lm_head
+    with bf16 GEMM operands / bf16 K/V cache (LayerNorm, residual stream, softmax in fp32) - the arithmetic of the
+    build's opt-in bf16 path, for checking it against something other than itself."""
     g = p + "gpt_with_lm_head.transformer."
     f = p + "feature_space_transformation_nn."
     img = F.linear(F.relu(F.linear(image_hidden_states, sd[f + "0.weight"], sd[f + "0.bias"])),
@@ -90,16 +105,17 @@ def lm_forward(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_s
         b = f"{g}h.{l}."
         h = F.layer_norm(x, (D_MODEL,), sd[b + "ln_1.weight"], sd[b + "ln_1.bias"], LN_EPS)
         a, present = pseudo_attention(sd, b + "attn.", h, img, add_mask, None if past is None else past[l],
-                                      dm.get((l, 1)), dm.get((l, 2)))
+                                      dm.get((l, 1)), dm.get((l, 2)), bf16)
         x = a + x
         h = F.layer_norm(x, (D_MODEL,), sd[b + "ln_2.weight"], sd[b + "ln_2.bias"], LN_EPS)
-        h = conv1d(sd, b + "mlp.c_proj.", gelu_new(conv1d(sd, b + "mlp.c_fc.", h)))
+        h = conv1d(sd, b + "mlp.c_proj.", gelu_new(conv1d(sd, b + "mlp.c_fc.", h, bf16)), bf16)
         if (l, 3) in dm:
             h = h * dm[(l, 3)].view_as(h)  # GPT2MLP dropout
         x = h + x
         presents.append(present)
     x = F.layer_norm(x, (D_MODEL,), sd[g + "ln_f.weight"], sd[g + "ln_f.bias"], LN_EPS)
-    logits = F.linear(x, sd[p + "gpt_with_lm_head.lm_head.weight"])  # [S,T,50257]
+    lmw = sd[p + "gpt_with_lm_head.lm_head.weight"]
+    logits = F.linear(_r16(x), _r16(lmw)) if bf16 else F.linear(x, lmw)  # [S,T,50257]
     return logits, presents
 
 

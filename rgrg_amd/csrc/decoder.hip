@@ -914,32 +914,37 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
 
 // Per batch item: log_softmax + beam score for the nb*K row candidates, then the top K = 2*nb
 // of the item (score desc; ties: lower flat index beam*V + token first) - language_model.py:545-561.
-__global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ row_max, const float* __restrict__ row_logsum,
-                                                        const float* __restrict__ top_val, const int* __restrict__ top_tok,
-                                                        const float* __restrict__ beam_scores, int nb, int K, int V,
-                                                        float* __restrict__ out_score, int* __restrict__ out_tok,
-                                                        int* __restrict__ out_beam) {
-    const int item = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(128) void beam_merge_kernel(const float* __restrict__ row_max, const float* __restrict__ row_logsum,
+                                                         const float* __restrict__ top_val, const int* __restrict__ top_tok,
+                                                         const float* __restrict__ beam_scores, int nb, int K, int V,
+                                                         float* __restrict__ out_score, int* __restrict__ out_tok,
+                                                         int* __restrict__ out_beam) {
+    // n = nb * 2 nb candidates (<= 128 for nb <= 8): one thread each, ranked against all others through LDS
+    __shared__ float ssc[128];
+    __shared__ long long sflat[128];
+    const int item = blockIdx.x, tid = threadIdx.x;
     const int n = nb * K;
     float sc = -INFINITY;
     long long flat = 0x7fffffffffffLL;
     int tok = 0, b = 0;
-    if (lane < n) {
-        b = lane / K;
+    if (tid < n) {
+        b = tid / K;
         const int row = item * nb + b;
-        const float v = top_val[(size_t)row * BEAM_K + (lane - b * K)];
-        tok = top_tok[(size_t)row * BEAM_K + (lane - b * K)];
+        const float v = top_val[(size_t)row * BEAM_K + (tid - b * K)];
+        tok = top_tok[(size_t)row * BEAM_K + (tid - b * K)];
         sc = ((v - row_max[row]) - row_logsum[row]) + beam_scores[row];
         flat = (long long)b * V + tok;
     }
+    ssc[tid] = sc;
+    sflat[tid] = flat;
+    __syncthreads();
     int rank = 0;
     for (int j = 0; j < n; ++j) {
-        const float oj = __shfl(sc, j, 64);
-        const int lo = __shfl((int)(flat & 0xffffffffLL), j, 64), hi = __shfl((int)(flat >> 32), j, 64);
-        const long long fj = ((long long)hi << 32) | (unsigned)lo;
+        const float oj = ssc[j];
+        const long long fj = sflat[j];
         if (oj > sc || (oj == sc && fj < flat)) ++rank;
     }
-    if (lane < n && rank < K) {
+    if (tid < n && rank < K) {
         out_score[item * K + rank] = sc;
         out_tok[item * K + rank] = tok;
         out_beam[item * K + rank] = b;
@@ -1809,7 +1814,7 @@ extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int
                 if (!rc) {
                     hipLaunchKernelGGL(beam_row_topk_kernel, dim3(R), dim3(256), 0, st, d->logits, d->ld_logits, d->V, K,
                                        d->row_max, d->row_logsum, d->top_val, d->top_tok);
-                    hipLaunchKernelGGL(beam_merge_kernel, dim3(S), dim3(64), 0, st, d->row_max, d->row_logsum, d->top_val,
+                    hipLaunchKernelGGL(beam_merge_kernel, dim3(S), dim3(128), 0, st, d->row_max, d->row_logsum, d->top_val,
                                        d->top_tok, d->beam_scores, nb, K, d->V, d->cand_score, d->cand_tok, d->cand_beam);
                 }
                 hipError_t e = hipStreamEndCapture(st, &graph);
