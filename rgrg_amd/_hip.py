@@ -16,6 +16,7 @@ c_float_p = C.c_void_p  # device pointers travel as void*
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p
 
 ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
+ABI_VERSION = 2  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
 
 
 class RgrgHipError(RuntimeError):
@@ -78,17 +79,20 @@ def library_path() -> str:
 
 
 def load() -> C.CDLL:
-    """Load the in-tree shared library (building it first if hipcc is available and it
-    is missing/stale).  Raises RgrgHipError when it cannot be loaded."""
+    """Load the in-tree shared library.  It is (re)built first when it is missing or older than its sources and hipcc
+    is available; the ABI version of whatever gets loaded must match the ctypes signatures above (a stale library
+    with new argument lists would corrupt memory silently).  Raises RgrgHipError when it cannot be loaded."""
     global _lib
     if _lib is not None:
         return _lib
     path = library_path()
-    if not os.path.exists(path):
+    if _build.is_stale():
         try:
             _build.build_library()
         except Exception as e:  # noqa: BLE001
-            raise RgrgHipError(f"librgrg_hip.so is missing and could not be built: {e}") from e
+            if not os.path.exists(path):
+                raise RgrgHipError(f"librgrg_hip.so is missing and could not be built: {e}") from e
+            # no toolchain on this box (e.g. a deployment image): the ABI check below decides
     try:
         lib = C.CDLL(path)
     except OSError as e:
@@ -97,6 +101,10 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
+    got = lib.rgrg_abi_version()
+    if got != ABI_VERSION:
+        raise RgrgHipError(f"{path} has ABI version {got}, this package expects {ABI_VERSION}: rebuild it "
+                           "(python -m rgrg_amd.build)")
     _lib = lib
     return lib
 

@@ -25,13 +25,27 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the RGRG HIP library cannot be built (ROCm toolchain required)")
 
 
+HASH_PATH = os.path.join(LIB_DIR, "librgrg_hip.srchash")
+HEADERS = ("common.h", "skinny_direct.inc")
+
+
+def _source_hash() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "rgrg_hip.h")]
+    for d in deps:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+    """True when the library is missing or was built from other sources.  Content hash, not mtimes: the snapshot
+    that carries the built library to a GPU box does not preserve file times."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"),
-                                                       os.path.join(HERE, "..", "include", "rgrg_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(HASH_PATH) as f:
+        return f.read().strip() != _source_hash()
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
@@ -52,6 +66,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     tmp = LIB_PATH + ".tmp"
     subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs, check=True)
     os.replace(tmp, LIB_PATH)
+    with open(HASH_PATH, "w") as f:
+        f.write(_source_hash() + "\n")
     return LIB_PATH
 
 

@@ -25,74 +25,148 @@ def shard_bounds(n_images: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + per + (1 if rank < rem else 0)
 
 
-def generate_sharded(model, images_local: torch.Tensor, max_length: Optional[int], group: Optional[dist.ProcessGroup] = None
-                     ) -> GenerateOutput:
+def generate_sharded(model, images_local: torch.Tensor, max_length: Optional[int], group: Optional[dist.ProcessGroup] = None,
+                     equal_shards: bool = True) -> GenerateOutput:
     """``generate()`` of the whole (rank-order concatenated) batch: every rank runs the three
-    stages on its own image shard, then one all_gather assembles the single-process result.
-    Equal shard sizes are required (fixed-shape collective)."""
+    stages on its own image shard, then ONE all_gather assembles the single-process result.
+
+    The collective has a fixed shape, so it needs the same number of images on every rank and a bound on the
+    sequence length.  When the caller cannot promise the former (``equal_shards=False``: ``shard_bounds`` of a batch
+    that does not divide by the world size) or gives no ``max_length`` (the reference's greedy search then runs until
+    every row has emitted EOS), one extra 2-word all_reduce(MAX) agrees on the padded shard size and length first."""
     _, detections, top_region_features, class_detected = model.object_detector(images_local)
     selected, feats = model.binary_classifier_region_selection(top_region_features, class_detected, return_loss=False)
     ids = model.language_model.generate(feats, max_length) if feats.shape[0] > 0 else None
-    return gather_generate_outputs(ids, selected, detections, class_detected, max_length, images_local.device, group)
+    n_pad = images_local.shape[0]
+    if max_length is None or not equal_shards:
+        t = torch.tensor([0 if ids is None else ids.shape[1], n_pad], dtype=torch.int64, device=images_local.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        if max_length is None:
+            max_length = max(int(t[0]), 1)
+        n_pad = int(t[1])
+    return gather_generate_outputs(ids, selected, detections, class_detected, max_length, images_local.device, group, n_pad)
 
 
 def gather_generate_outputs(out_ids: Optional[torch.Tensor], sel: torch.Tensor, det: Dict[str, torch.Tensor],
                             cd: torch.Tensor, max_length: int, device: torch.device,
-                            group: Optional[dist.ProcessGroup] = None) -> GenerateOutput:
+                            group: Optional[dist.ProcessGroup] = None, n_pad: Optional[int] = None) -> GenerateOutput:
     """All-gather the per-rank stage outputs (``out_ids`` is None when the rank selected no
     region) into what a single process would have returned for the concatenated batch.
 
-    One fixed-shape all_gather: ids padded to [29*n_local, max_length] int64 plus a packed
-    per-image record (selected | detected | score bits | box bits), ~31 KB per image, so there
-    is exactly one collective.  The single-process L' is the longest row of the WHOLE batch:
+    One fixed-shape all_gather: ids padded to [29*n_pad, max_length] int64 plus a packed
+    per-image record (selected | detected | score bits | box bits | valid | L'), ~31 KB per image, so there
+    is exactly one collective; ``n_pad`` >= the local image count pads short shards with invalid images that are
+    dropped again after the gather.  The single-process L' is the longest row of the WHOLE batch:
     after the gather the ids are trimmed to the global maximum length."""
     world = dist.get_world_size(group)
     n_local_images = sel.shape[0]
-    rows = NUM_REGIONS * n_local_images
-    ids = torch.full((rows, max_length), PAD_TOKEN_ID, dtype=torch.int64, device=device)
-    meta = torch.zeros((n_local_images, NUM_REGIONS * 7 + 1), dtype=torch.int64, device=device)
-    meta[:, 0:29] = sel.to(torch.int64)
-    meta[:, 29:58] = cd.to(torch.int64)
-    meta[:, 58:87] = det["top_scores"].contiguous().view(torch.int32).to(torch.int64)
-    meta[:, 87:203] = det["top_region_boxes"].contiguous().view(n_local_images, -1).view(torch.int32).to(torch.int64)
+    n_pad = n_local_images if n_pad is None else int(n_pad)
+    assert n_pad >= n_local_images and max_length is not None and max_length >= 1
+    ids = torch.full((NUM_REGIONS * n_pad, max_length), PAD_TOKEN_ID, dtype=torch.int64, device=device)
+    meta = torch.zeros((n_pad, NUM_REGIONS * 7 + 2), dtype=torch.int64, device=device)
+    n = n_local_images
+    meta[:n, 0:29] = sel.to(torch.int64)
+    meta[:n, 29:58] = cd.to(torch.int64)
+    meta[:n, 58:87] = det["top_scores"].contiguous().view(torch.int32).to(torch.int64)
+    meta[:n, 87:203] = det["top_region_boxes"].contiguous().view(n, -1).view(torch.int32).to(torch.int64)
+    meta[:n, 203] = 1  # a real image of this rank
     if out_ids is not None:
         ids[: out_ids.shape[0], : out_ids.shape[1]] = out_ids
-        meta[:, -1] = out_ids.shape[1]
-    payload = torch.cat([ids.view(n_local_images, -1), meta], dim=1).contiguous()
+        meta[:, 204] = out_ids.shape[1]
+    payload = torch.cat([ids.view(n_pad, -1), meta], dim=1).contiguous()
     gathered = [torch.empty_like(payload) for _ in range(world)]
     dist.all_gather(gathered, payload, group=group)
     allp = torch.cat(gathered, 0)
-    n_img = allp.shape[0]
-    ids_all = allp[:, : NUM_REGIONS * max_length].reshape(n_img, NUM_REGIONS, max_length)
+    ids_all = allp[:, : NUM_REGIONS * max_length].reshape(world * n_pad, NUM_REGIONS, max_length)
     meta_all = allp[:, NUM_REGIONS * max_length:]
-    sel_all = meta_all[:, 0:29].bool()
-    cd_all = meta_all[:, 29:58].bool()
-    scores = meta_all[:, 58:87].to(torch.int32).view(torch.float32)
-    boxes = meta_all[:, 87:203].to(torch.int32).view(torch.float32).view(n_img, NUM_REGIONS, 4)
-    if int(sel_all.sum()) == 0:
+    valid = meta_all[:, 203].bool()
+    sel_pad = meta_all[:, 0:29].bool()
+    if int(sel_pad.sum()) == 0:
         return -1
     # each rank's rows are compact (its selected regions first): re-compact over the whole batch
     out_rows = []
     for r in range(world):
-        blk = slice(r * n_local_images, (r + 1) * n_local_images)
-        n_sel = int(sel_all[blk].sum())
+        blk = slice(r * n_pad, (r + 1) * n_pad)
+        n_sel = int(sel_pad[blk].sum())
         out_rows.append(ids_all[blk].reshape(-1, max_length)[:n_sel])
-    L = int(meta_all[:, -1].max())
-    return torch.cat(out_rows, 0)[:, :L].contiguous(), sel_all, {"top_region_boxes": boxes, "top_scores": scores}, cd_all
+    L = int(meta_all[:, 204].max())
+    m = meta_all[valid]
+    n_img = m.shape[0]
+    scores = m[:, 58:87].to(torch.int32).view(torch.float32)
+    boxes = m[:, 87:203].to(torch.int32).view(torch.float32).view(n_img, NUM_REGIONS, 4)
+    return (torch.cat(out_rows, 0)[:, :L].contiguous(), m[:, 0:29].bool(), {"top_region_boxes": boxes, "top_scores": scores},
+            m[:, 29:58].bool())
+
+
+class GradBuckets:
+    """Persistent flat gradient buckets for the data-parallel training step (SURVEY.md 8(e) "Training"): the ``.grad``
+    of every trainable parameter is a VIEW into one of a few flat fp32 buffers (autograd accumulates into the views in
+    place), so the all-reduce runs directly on the buffers - no packing copy before and no unpacking copy after the
+    collective (2 x 215 MB per step saved against torch.cat + copy_).  Use ``zero()`` (or
+    ``optimizer.zero_grad(set_to_none=False)``) between steps so that the views survive."""
+
+    def __init__(self, params, bucket_bytes: int = 64 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []
+        cur, cur_bytes = [], 0
+        groups = []
+        for p in self.params:
+            nbytes = p.numel() * p.element_size()
+            if cur and (cur_bytes + nbytes > bucket_bytes or p.device != cur[0].device or p.dtype != cur[0].dtype):
+                groups.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            groups.append(cur)
+        for grp in groups:
+            flat = torch.zeros(sum(p.numel() for p in grp), dtype=grp[0].dtype, device=grp[0].device)
+            off = 0
+            for p in grp:
+                n = p.numel()
+                view = flat[off:off + n].view_as(p)
+                if p.grad is not None:
+                    view.copy_(p.grad)
+                p.grad = view
+                off += n
+            self.buckets.append(flat)
+
+    def zero(self) -> None:
+        for flat in self.buckets:
+            flat.zero_()
+
+    def owns_all_grads(self) -> bool:
+        """False when something replaced a ``.grad`` (e.g. ``zero_grad(set_to_none=True)``)."""
+        spans = [(f.data_ptr(), f.data_ptr() + f.numel() * f.element_size()) for f in self.buckets]
+        return all(p.grad is not None and any(lo <= p.grad.data_ptr() < hi for lo, hi in spans) for p in self.params)
+
+    def allreduce(self, group=None, average: bool = True) -> int:
+        """Sum (average) the buckets over the ranks with asynchronous all-reduces (RCCL over xGMI: a ring moves
+        2(N-1)/N x 215 MB per rank per step; large buckets keep the per-link ring efficient).  The HIP backward is one
+        fused call per module, so there is nothing to overlap the reduction with except the other buckets."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0
+        if not self.owns_all_grads():
+            raise RuntimeError("GradBuckets: a .grad no longer points into the flat buckets (use zero() / zero_grad(set_to_none=False))")
+        world = dist.get_world_size(group)
+        works = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True) for flat in self.buckets]
+        for w, flat in zip(works, self.buckets):
+            w.wait()
+            if average and world > 1:
+                flat.div_(world)
+        return len(self.buckets)
 
 
 def allreduce_gradients(params, group=None, bucket_bytes: int = 64 << 20, average: bool = True) -> int:
-    """Gradient synchronisation of the frozen-detector training step (SURVEY.md 8(e) "Training"): every rank holds a
-    full replica and a shard of the batch; after ``backward()`` the gradients of the 53.7 M trainable values (215 MB
-    fp32) are packed into a few flat buckets, summed with asynchronous all-reduces (RCCL over xGMI; a ring moves
-    2(N-1)/N x 215 MB per rank per step) and unpacked, divided by the world size when ``average`` (the DDP
-    convention).  The HIP backward is one fused call per module, so there is nothing to overlap the reduction with
-    except the other buckets; large buckets keep the per-link ring efficient.  Returns the number of buckets."""
+    """Gradient synchronisation for parameters whose gradients are ordinary separate tensors: packed into a few flat
+    buckets, all-reduced, unpacked (two extra passes over the gradients - prefer ``GradBuckets``, whose buckets ARE the
+    gradients).  Every rank holds a full replica and a shard of the batch; divided by the world size when ``average``
+    (the DDP convention).  Returns the number of buckets."""
     if not (dist.is_available() and dist.is_initialized()):
         return 0
     world = dist.get_world_size(group)
     grads = [p.grad for p in params if p.grad is not None]
-    if world == 1 or not grads:
+    if not grads:
         return 0
     buckets, cur, cur_bytes = [], [], 0
     for g in grads:
@@ -110,7 +184,7 @@ def allreduce_gradients(params, group=None, bucket_bytes: int = 64 << 20, averag
         pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True), flat, b))
     for work, flat, b in pending:
         work.wait()
-        if average:
+        if average and world > 1:
             flat.div_(world)
         off = 0
         for g in b:

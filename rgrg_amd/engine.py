@@ -26,8 +26,23 @@ def _require_gpu(device: torch.device) -> None:
                                 "'cuda' (there is no CPU fallback)")
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _on_engine_device(cls):
+    """Every engine entry point runs with the engine's device current: librgrg_hip.so allocates, creates streams and
+    launches on the CURRENT device, so a model on cuda:1 must not be driven while cuda:0 is current (single-process
+    multi-GPU, generate_sharded without set_device)."""
+    import functools
+
+    def wrap(fn):
+        @functools.wraps(fn)
+        def inner(self, *a, **k):
+            with torch.cuda.device(self.device):
+                return fn(self, *a, **k)
+        return inner
+
+    for name, fn in list(vars(cls).items()):
+        if callable(fn) and not name.startswith("__") and name != "_s":
+            setattr(cls, name, wrap(fn))
+    return cls
 
 
 def pick_splitk(M: int, N: int, K: int) -> int:
@@ -83,14 +98,22 @@ def _bn_affine(sd: Dict[str, Tensor], p: str) -> Tuple[Tensor, Tensor]:
     return alpha.contiguous(), beta.contiguous()
 
 
+@_on_engine_device
 class HipEngine:
     def __init__(self, state_dict: Dict[str, Tensor], device: torch.device):
         _require_gpu(device)
-        self.lib = _hip.load()
-        arch = C.create_string_buffer(64)
-        _hip.check(self.lib.rgrg_device_arch(device.index or 0, arch, 64), "rgrg_device_arch")
-        self.arch = arch.value.decode()
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
+        self.lib = _hip.load()
+        self._decoder = None
+        self._init(state_dict)
+
+    def _init(self, state_dict: Dict[str, Tensor]) -> None:
+        device = self.device
+        arch = C.create_string_buffer(64)
+        _hip.check(self.lib.rgrg_device_arch(device.index, arch, 64), "rgrg_device_arch")
+        self.arch = arch.value.decode()
         sd = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in state_dict.items()
               if v.dtype.is_floating_point}
         self._decoder = None
@@ -109,6 +132,10 @@ class HipEngine:
             self.abn = [(sd[a + f"{i}.weight"].contiguous(), sd[a + f"{i}.bias"].contiguous()) for i in (0, 2, 4)]
         if self.has_decoder:
             self._pack_decoder(sd)
+
+    def _s(self) -> int:
+        """The caller's stream ON THE ENGINE'S DEVICE (a ``void*`` for the C ABI)."""
+        return torch.cuda.current_stream(self.device).cuda_stream
 
     # ------------------------------------------------------------------ packing
     def _pack_detector(self, sd):
@@ -218,7 +245,7 @@ class HipEngine:
         sk = pick_splitk(M, N, K) if splitk is None else splitk
         ws = torch.empty((sk, M, N), dtype=torch.float32, device=x.device) if sk > 1 else None
         _hip.check(self.lib.rgrg_linear_f32(_hip.ptr(x), _hip.ptr(w), None, _hip.ptr(b), _hip.ptr(residual), _hip.ptr(y),
-                                            M, N, K, N, act, sk, _hip.ptr(ws), _stream()), "rgrg_linear_f32")
+                                            M, N, K, N, act, sk, _hip.ptr(ws), self._s()), "rgrg_linear_f32")
         return y
 
     def conv(self, x: Tensor, c: _Conv, act: int, residual: Optional[Tensor] = None) -> Tensor:
@@ -232,7 +259,7 @@ class HipEngine:
         ws = torch.empty((sk, M, N), dtype=torch.float32, device=x.device) if sk > 1 else None
         _hip.check(self.lib.rgrg_conv2d_nhwc_f32(_hip.ptr(x), _hip.ptr(c.w), _hip.ptr(c.scale), _hip.ptr(c.shift),
                                                  _hip.ptr(residual), _hip.ptr(y), B, H, W, Cin, c.cout, c.kh, c.kw,
-                                                 c.stride, c.pad, act, sk, _hip.ptr(ws), _stream()),
+                                                 c.stride, c.pad, act, sk, _hip.ptr(ws), self._s()),
                    "rgrg_conv2d_nhwc_f32")
         return y
 
@@ -244,9 +271,9 @@ class HipEngine:
         x = images.reshape(B, H, W).contiguous()
         y = torch.empty((B, H // 2, W // 2, 64), dtype=torch.float32, device=x.device)
         _hip.check(self.lib.rgrg_stem_conv7x7_f32(_hip.ptr(x), _hip.ptr(self.stem_w), _hip.ptr(self.stem_scale),
-                                                  _hip.ptr(self.stem_shift), _hip.ptr(y), B, H, W, _stream()), "stem")
+                                                  _hip.ptr(self.stem_shift), _hip.ptr(y), B, H, W, self._s()), "stem")
         p = torch.empty((B, H // 4, W // 4, 64), dtype=torch.float32, device=x.device)
-        _hip.check(self.lib.rgrg_maxpool3x3s2_nhwc_f32(_hip.ptr(y), _hip.ptr(p), B, H // 2, W // 2, 64, _stream()), "maxpool")
+        _hip.check(self.lib.rgrg_maxpool3x3s2_nhwc_f32(_hip.ptr(y), _hip.ptr(p), B, H // 2, W // 2, 64, self._s()), "maxpool")
         x = p
         for blk in self.blocks:
             o = self.conv(x, blk["c1"], _hip.ACT_RELU)
@@ -267,14 +294,14 @@ class HipEngine:
         _hip.check(self.lib.rgrg_rpn_proposals_f32(_hip.ptr(head), _hip.ptr(self.anchors), _hip.ptr(props),
                                                    _hip.ptr(counts), _hip.ptr(offsets), B, FH * FW, self.num_anchors,
                                                    RPN_PRE_NMS_TOP_N, RPN_POST_NMS_TOP_N, RPN_NMS_THRESH, 1e-3, size,
-                                                   size, _stream()), "rgrg_rpn_proposals_f32")
+                                                   size, self._s()), "rgrg_rpn_proposals_f32")
         return props, counts, offsets
 
     def _fc6_bf16(self) -> Tensor:
         """bf16 copy of the (K-permuted) fc6 weight, made on first use of the autocast path."""
         if getattr(self, "fc6_wb", None) is None:
             self.fc6_wb = torch.empty(self.fc6_w.shape, dtype=torch.int16, device=self.fc6_w.device)
-            _hip.check(self.lib.rgrg_f32_to_bf16(_hip.ptr(self.fc6_w), _hip.ptr(self.fc6_wb), self.fc6_w.numel(), _stream()),
+            _hip.check(self.lib.rgrg_f32_to_bf16(_hip.ptr(self.fc6_w), _hip.ptr(self.fc6_wb), self.fc6_w.numel(), self._s()),
                        "rgrg_f32_to_bf16")
         return self.fc6_wb
 
@@ -292,14 +319,14 @@ class HipEngine:
             scale = 2.0 ** round(__import__("math").log2(FH / IMAGE_INPUT_SIZE))
             _hip.check(self.lib.rgrg_roi_align_avgpool_f32(_hip.ptr(feat), _hip.ptr(props), _hip.ptr(offsets),
                                                            _hip.ptr(pooled_maps), _hip.ptr(pooled), B, FH, FW, Cf,
-                                                           props.shape[1], R, scale, _stream()), "rgrg_roi_align")
+                                                           props.shape[1], R, scale, self._s()), "rgrg_roi_align")
             if bf16 and R > 128:
                 # torch.autocast in the reference runs box_head in half precision: fc6 (81 % of the detector's FLOPs,
                 # custom_roi_heads.py:235) on the bf16 MFMA, fp32 accumulate / bias / ReLU
                 h = torch.empty((R, self.fc6_w.shape[0]), dtype=torch.float32, device=dev)
                 _hip.check(self.lib.rgrg_linear_bf16w_f32(_hip.ptr(pooled_maps), _hip.ptr(self._fc6_bf16()), _hip.ptr(self.fc6_b), None,
                                                           _hip.ptr(h), R, self.fc6_w.shape[0], 64 * Cf, self.fc6_w.shape[0],
-                                                          _hip.ACT_RELU, _stream()), "rgrg_linear_bf16w_f32")
+                                                          _hip.ACT_RELU, self._s()), "rgrg_linear_bf16w_f32")
             else:
                 h = self.linear(pooled_maps.view(R, 64 * Cf), self.fc6_w, self.fc6_b, _hip.ACT_RELU)
             h = self.linear(h, self.fc7_w, self.fc7_b, _hip.ACT_RELU)
@@ -307,7 +334,7 @@ class HipEngine:
             size = float(IMAGE_INPUT_SIZE)
             _hip.check(self.lib.rgrg_top1_per_class_f32(_hip.ptr(pred), pred.shape[1], _hip.ptr(props), _hip.ptr(offsets),
                                                         _hip.ptr(pooled), _hip.ptr(cd), _hip.ptr(scores), _hip.ptr(boxes),
-                                                        _hip.ptr(feats), B, Cf, props.shape[1], size, size, _stream()),
+                                                        _hip.ptr(feats), B, Cf, props.shape[1], size, size, self._s()),
                        "rgrg_top1_per_class_f32")
             if taps is not None:
                 taps.update(pooled_maps=pooled_maps, pooled=pooled, pred=pred)
@@ -332,7 +359,7 @@ class HipEngine:
         pooled = torch.empty((R, Cf), dtype=torch.float32, device=feat_nhwc.device)
         scale = 2.0 ** round(__import__("math").log2(FH / IMAGE_INPUT_SIZE))
         _hip.check(self.lib.rgrg_roi_align_avgpool_f32(_hip.ptr(feat_nhwc), _hip.ptr(props), _hip.ptr(offsets), _hip.ptr(maps),
-                                                       _hip.ptr(pooled), B, FH, FW, Cf, maxn, R, scale, _stream()), "rgrg_roi_align")
+                                                       _hip.ptr(pooled), B, FH, FW, Cf, maxn, R, scale, self._s()), "rgrg_roi_align")
         return maps, pooled
 
     def detect(self, images: Tensor, taps: Optional[dict] = None, bf16: bool = False):
@@ -361,18 +388,18 @@ class HipEngine:
         t = target.reshape(-1).to(torch.uint8).contiguous()
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
         _hip.check(self.lib.rgrg_bce_with_logits_masked_f32(_hip.ptr(logits), _hip.ptr(m), _hip.ptr(t), float(pos_weight), n,
-                                                            _hip.ptr(loss), _stream()), "rgrg_bce_with_logits_masked_f32")
+                                                            _hip.ptr(loss), self._s()), "rgrg_bce_with_logits_masked_f32")
         return loss
 
     def _transpose_pad(self, x: Tensor, rows_padded: int) -> Tensor:
         R, Cc = x.shape
         out = torch.empty((Cc, rows_padded), dtype=torch.float32, device=x.device)
-        _hip.check(self.lib.rgrg_transpose_pad_f32(_hip.ptr(x), _hip.ptr(out), R, Cc, rows_padded, _stream()), "rgrg_transpose_pad_f32")
+        _hip.check(self.lib.rgrg_transpose_pad_f32(_hip.ptr(x), _hip.ptr(out), R, Cc, rows_padded, self._s()), "rgrg_transpose_pad_f32")
         return out
 
     def _colsum(self, x: Tensor) -> Tensor:
         out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
-        _hip.check(self.lib.rgrg_colsum_f32(_hip.ptr(x), _hip.ptr(out), x.shape[0], x.shape[1], _stream()), "rgrg_colsum_f32")
+        _hip.check(self.lib.rgrg_colsum_f32(_hip.ptr(x), _hip.ptr(out), x.shape[0], x.shape[1], self._s()), "rgrg_colsum_f32")
         return out
 
     def classifier_loss_grad(self, mlp, x: Tensor, mask: Tensor, target: Tensor, pos_weight: float):
@@ -389,17 +416,17 @@ class HipEngine:
         t = target.reshape(-1).to(torch.uint8).contiguous()
         dlog = torch.zeros((n, 32), dtype=torch.float32, device=x.device)  # column 0 = d logits, 31 columns of K padding
         _hip.check(self.lib.rgrg_bce_with_logits_masked_backward_f32(_hip.ptr(logits), _hip.ptr(m), _hip.ptr(t), float(pos_weight), n,
-                                                                     1.0, _hip.ptr(dlog), 32, _stream()),
+                                                                     1.0, _hip.ptr(dlog), 32, self._s()),
                    "rgrg_bce_with_logits_masked_backward_f32")
         dlogT = self._transpose_pad(dlog, npad)                       # [32, npad], row 0 = d logits
         dW4 = self.linear(dlogT[:1].contiguous(), self._transpose_pad(h2, npad), None)          # [1,128]
         db4 = self._colsum(dlog)[:1].contiguous()
         dh2 = self.linear(dlog, self._transpose_pad(W4, 32), None)   # [n,128] = dlog W4
-        _hip.check(self.lib.rgrg_relu_backward_f32(_hip.ptr(dh2), _hip.ptr(h2), dh2.numel(), _stream()), "rgrg_relu_backward_f32")
+        _hip.check(self.lib.rgrg_relu_backward_f32(_hip.ptr(dh2), _hip.ptr(h2), dh2.numel(), self._s()), "rgrg_relu_backward_f32")
         dW2 = self.linear(self._transpose_pad(dh2, npad), self._transpose_pad(h1, npad), None)   # [128,512]
         db2 = self._colsum(dh2)
         dh1 = self.linear(dh2, self._transpose_pad(W2, W2.shape[0]), None)                        # [n,512] = dh2 W2
-        _hip.check(self.lib.rgrg_relu_backward_f32(_hip.ptr(dh1), _hip.ptr(h1), dh1.numel(), _stream()), "rgrg_relu_backward_f32")
+        _hip.check(self.lib.rgrg_relu_backward_f32(_hip.ptr(dh1), _hip.ptr(h1), dh1.numel(), self._s()), "rgrg_relu_backward_f32")
         dW0 = self.linear(self._transpose_pad(dh1, npad), self._transpose_pad(x, npad), None)    # [512,1024]
         db0 = self._colsum(dh1)
         return loss, logits, [dW0, db0, dW2, db2, dW4, db4]
@@ -418,7 +445,7 @@ class HipEngine:
         rows = torch.empty((n,), dtype=torch.int32, device=x.device)
         cnt = torch.empty((1,), dtype=torch.int32, device=x.device)
         _hip.check(self.lib.rgrg_select_regions_f32(_hip.ptr(logits), _hip.ptr(ones), SELECTION_LOGIT_THRESHOLD, _hip.ptr(pred),
-                                                    _hip.ptr(rows), _hip.ptr(cnt), n, _stream()), "rgrg_select_regions_f32")
+                                                    _hip.ptr(rows), _hip.ptr(cnt), n, self._s()), "rgrg_select_regions_f32")
         return loss, pred.view(B, Rg).bool()
 
     def select(self, top_region_features: Tensor, class_detected: Tensor, taps: Optional[dict] = None):
@@ -431,12 +458,12 @@ class HipEngine:
         rows = torch.empty((n,), dtype=torch.int32, device=x.device)
         nsel = torch.empty((1,), dtype=torch.int32, device=x.device)
         _hip.check(self.lib.rgrg_select_regions_f32(_hip.ptr(logits), _hip.ptr(det), SELECTION_LOGIT_THRESHOLD,
-                                                    _hip.ptr(sel), _hip.ptr(rows), _hip.ptr(nsel), n, _stream()),
+                                                    _hip.ptr(sel), _hip.ptr(rows), _hip.ptr(nsel), n, self._s()),
                    "rgrg_select_regions_f32")
         S = int(nsel.item())  # host sync #2 (the reference syncs here too: report_generation_model.py:260)
         feats = torch.empty((S, D), dtype=torch.float32, device=x.device)
         if S > 0:
-            _hip.check(self.lib.rgrg_gather_rows_f32(_hip.ptr(x), _hip.ptr(rows), _hip.ptr(feats), S, D, _stream()),
+            _hip.check(self.lib.rgrg_gather_rows_f32(_hip.ptr(x), _hip.ptr(rows), _hip.ptr(feats), S, D, self._s()),
                        "rgrg_gather_rows_f32")
         if taps is not None:
             taps.update(selection_logits=logits.view(B, Rg))
@@ -467,7 +494,7 @@ class HipEngine:
         out = torch.empty((S, limit), dtype=torch.int64, device=feats.device)
         out_len = C.c_int(0)
         _hip.check(self.lib.rgrg_decoder_generate(dec, _hip.ptr(feats), S, limit, _hip.ptr(out), limit,
-                                                  C.byref(out_len), 1 if use_graph else 0, _stream()),
+                                                  C.byref(out_len), 1 if use_graph else 0, self._s()),
                    "rgrg_decoder_generate")
         return out[:, :out_len.value].contiguous()
 
@@ -483,7 +510,7 @@ class HipEngine:
         out = torch.empty((S, limit), dtype=torch.int64, device=feats.device)
         out_len = C.c_int(0)
         _hip.check(self.lib.rgrg_decoder_beam_search(dec, _hip.ptr(feats), S, int(num_beams), limit, 1 if early_stopping else 0,
-                                                     float(length_penalty), _hip.ptr(out), limit, C.byref(out_len), _stream()),
+                                                     float(length_penalty), _hip.ptr(out), limit, C.byref(out_len), self._s()),
                    "rgrg_decoder_beam_search")
         return out[:, :out_len.value].contiguous()
 
@@ -509,7 +536,7 @@ class HipEngine:
         loss = torch.empty((), dtype=torch.float32, device=feats.device) if want_loss else None
         _hip.check(self.lib.rgrg_decoder_lm_forward(dec, _hip.ptr(feats), _hip.ptr(ids), None if am is None else _hip.ptr(am),
                                                     S, T, None if logits is None else _hip.ptr(logits),
-                                                    None if loss is None else _hip.ptr(loss), _stream()),
+                                                    None if loss is None else _hip.ptr(loss), self._s()),
                    "rgrg_decoder_lm_forward")
         return logits, loss
 
@@ -542,7 +569,7 @@ class HipEngine:
                                                       float(loss_scale), float(dropout_p), int(dropout_seed) & (2 ** 64 - 1), _hip.ptr(loss),
                                                       _hip.ptr(g["ukv_w"]), _hip.ptr(g["ukv_b"]),
                                                       _hip.ptr(g["fst0_w"]), _hip.ptr(g["fst0_b"]), _hip.ptr(g["fst2_w"]),
-                                                      _hip.ptr(g["fst2_b"]), _stream()), "rgrg_decoder_lm_loss_grad")
+                                                      _hip.ptr(g["fst2_b"]), self._s()), "rgrg_decoder_lm_loss_grad")
         return loss, g
 
     def dropout_mask(self, seed: int, layer: int, site: int, p: float, shape) -> Tensor:
@@ -550,7 +577,7 @@ class HipEngine:
         [S,16,T,T+1], 2 attn c_proj output, 3 mlp c_proj output ([S*T,1024])."""
         out = torch.empty(shape, dtype=torch.float32, device=self.device)
         _hip.check(self.lib.rgrg_dropout_mask_f32(int(seed) & (2 ** 64 - 1), layer * 4 + site, float(p), out.numel(), _hip.ptr(out),
-                                                  _stream()), "rgrg_dropout_mask_f32")
+                                                  self._s()), "rgrg_dropout_mask_f32")
         return out
 
     def sync_trainable(self, state_dict: Dict[str, Tensor]) -> None:
@@ -570,11 +597,11 @@ class HipEngine:
                 if t.data_ptr() != state_dict[f + k].data_ptr():
                     t.copy_(state_dict[f + k])
         if self._decoder is not None:
-            _hip.check(self.lib.rgrg_decoder_refresh_trainable(self._decoder, _stream()), "rgrg_decoder_refresh_trainable")
+            _hip.check(self.lib.rgrg_decoder_refresh_trainable(self._decoder, self._s()), "rgrg_decoder_refresh_trainable")
 
     def last_logits(self, S: int) -> Tensor:
         dst = torch.empty((S, self.vocab), dtype=torch.float32, device=self.device)
-        _hip.check(self.lib.rgrg_decoder_copy_last_logits(self._decoder, _hip.ptr(dst), S, _stream()), "copy_last_logits")
+        _hip.check(self.lib.rgrg_decoder_copy_last_logits(self._decoder, _hip.ptr(dst), S, self._s()), "copy_last_logits")
         return dst
 
     def time_decode_gemms(self, S: int, iters: int = 3) -> Tuple[float, float, int]:

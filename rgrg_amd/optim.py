@@ -24,7 +24,6 @@ class AdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        stream = None
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -34,8 +33,6 @@ class AdamW(torch.optim.Optimizer):
                     raise _hip.RgrgHipError("rgrg_amd.optim.AdamW needs contiguous fp32 parameters on the GPU (no CPU fallback)")
                 if self._lib is None:
                     self._lib = _hip.load()
-                if stream is None:
-                    stream = torch.cuda.current_stream().cuda_stream
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 st = self.state[p]
                 if not st:
@@ -43,10 +40,12 @@ class AdamW(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
-                _hip.check(self._lib.rgrg_adamw_step_f32(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
-                                                         st["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]), float(b1),
-                                                         float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                                         int(st["step"]), float(grad_scale), stream), "rgrg_adamw_step_f32")
+                with torch.cuda.device(p.device):  # the kernel launches on the current device: the parameter's
+                    _hip.check(self._lib.rgrg_adamw_step_f32(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                                             st["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]), float(b1),
+                                                             float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                                             int(st["step"]), float(grad_scale),
+                                                             torch.cuda.current_stream(p.device).cuda_stream), "rgrg_adamw_step_f32")
                 # the kernel wrote p behind torch's back: bump the version counter so that engines caching derived
                 # layouts (LanguageModel.sync_trainable_if_stale) and autograd's checks notice
                 torch._C._increment_version(p)

@@ -30,7 +30,7 @@ def test_library_builds_loads_and_exports_the_declared_abi():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/rgrg_hip.h but not exported"
     assert sorted(_hip.SIGNATURES) == names  # the ctypes table covers exactly the header
-    assert lib.rgrg_abi_version() == 1
+    assert lib.rgrg_abi_version() == _hip.ABI_VERSION
 
 
 def test_gfx950_code_object_is_embedded():

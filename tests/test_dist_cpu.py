@@ -118,3 +118,92 @@ def test_allreduce_gradients_averages_over_ranks_in_buckets():
             assert ret["grads"][i] is None
         else:
             assert torch.allclose(ret["grads"][i], base * 1.5, atol=1e-6)   # (1 + 2) / 2
+
+
+# ------------------------------------------------------------------------- unequal shards / unbounded length (gloo, world 2)
+class _FakeModel:
+    """The three stage calls generate_sharded makes, with deterministic per-rank outputs (the HIP stages need a GPU)."""
+
+    def __init__(self, seed, length):
+        self.seed, self.length, self.language_model = seed, length, self
+        self.ids = None
+
+    def object_detector(self, images):
+        self.ids, sel, det, cd = _fake_generate(images.shape[0], self.seed, length=self.length)
+        self.sel = sel
+        return {}, det, torch.zeros((images.shape[0], 29, 1024)), cd
+
+    def binary_classifier_region_selection(self, feats, cd, return_loss=False):
+        return self.sel, torch.zeros((int(self.sel.sum()), 1024))
+
+    def generate(self, feats, max_length):
+        return self.ids if max_length is None else self.ids[:, :max_length]
+
+
+def _sharded_worker(rank, world, port, ret):
+    from rgrg_amd.dist import generate_sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_bounds(5, rank, world)                 # 3 + 2 images: unequal shards
+        model = _FakeModel(200 + rank, 13 if rank == 0 else 19)
+        out = generate_sharded(model, torch.zeros((hi - lo, 1, 8, 8)), None, equal_shards=False)  # and no max_length
+        if rank == 0:
+            ret["out"] = (out[0], out[1], out[2]["top_scores"], out[2]["top_region_boxes"], out[3])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_generate_sharded_pads_unequal_shards_and_resolves_unbounded_length():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sharded_worker, args=(2, port, ret), nprocs=2, join=True)
+    ids, sel, scores, boxes, cd = ret["out"]
+    i0, s0, d0, c0 = _fake_generate(3, 200, length=13)
+    i1, s1, d1, c1 = _fake_generate(2, 201, length=19)
+    assert sel.shape == (5, 29) and torch.equal(sel, torch.cat([s0, s1])) and torch.equal(cd, torch.cat([c0, c1]))
+    assert torch.equal(boxes, torch.cat([d0["top_region_boxes"], d1["top_region_boxes"]]))
+    assert torch.equal(scores, torch.cat([d0["top_scores"], d1["top_scores"]]))
+    assert ids.shape == (int(sel.sum()), 19)                                         # L' agreed by the all_reduce(MAX)
+    assert torch.equal(ids, torch.cat([torch.nn.functional.pad(i0, (0, 6), value=50256), i1]))
+
+
+def _bucket_worker(rank, world, port, ret):
+    from rgrg_amd.dist import GradBuckets
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(11)
+        params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in [(300, 40), (40,), (1000, 64), (5,)]]
+        frozen = torch.nn.Parameter(torch.zeros(7), requires_grad=False)
+        gb = GradBuckets(params + [frozen], bucket_bytes=100_000)
+        ptrs = [p.grad.data_ptr() for p in params]
+        for step in range(2):                                  # autograd accumulates INTO the views, twice
+            loss = sum(((rank + 1.0) * (i + 1) * p).sum() for i, p in enumerate(params))
+            loss.backward()
+        assert [p.grad.data_ptr() for p in params] == ptrs and gb.owns_all_grads()
+        n = gb.allreduce()
+        if rank == 0:
+            ret["n"] = n
+            ret["grads"] = [p.grad.clone() for p in params]
+            gb.zero()
+            ret["zeroed"] = all(float(p.grad.abs().max()) == 0.0 for p in params) and frozen.grad is None
+            params[0].grad = None
+            ret["detects_lost_view"] = not gb.owns_all_grads()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_buckets_allreduce_in_place_on_flat_views():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bucket_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["n"] >= 2 and ret["zeroed"] and ret["detects_lost_view"]
+    for i, gr in enumerate(ret["grads"]):                      # 2 backward passes x mean over ranks of (rank + 1)(i + 1)
+        assert torch.allclose(gr, torch.full_like(gr, 2 * 1.5 * (i + 1)), atol=1e-5)
