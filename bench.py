@@ -27,41 +27,99 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def pmc_traffic_per_launch():
-    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (profiles/): PMC counters
-    cannot be collected from inside the timed process, so the last committed measurement is quoted."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+MFMA_PEAK_TFS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md dense peaks (no sparsity)
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json,
+    written by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as the gfx950
+    note of MI355X_MICROARCH.md prescribes): counters cannot be collected from inside the timed process, so the last
+    committed measurement of the same command is quoted; None when there is none for this configuration."""
+    path = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
     try:
         with open(path) as f:
-            return float(json.load(f)["avg_hbm_bytes_per_gemm_launch"])
+            v = json.load(f).get(key)
+        return None if v is None else float(v)
     except Exception:  # noqa: BLE001
         return None
 
 
-def cpu_baseline(sd, images, max_length, sample_steps=16):
-    """The CPU oracle (port of the reference's algorithm; oracle/) timed on this host on a BOUNDED sample of
-    the same workload: ONE image through detector + selection (full), then `sample_steps` greedy decode steps;
-    the decode time is scaled to the max_length-1 steps of the workload (the per-step cost of the reference's
-    concat-KV decoder grows slowly with length, so this slightly flatters the CPU)."""
+def rooflines(eng, S_dec, dtype, max_length):
+    """Rooflines of the two kernel families of a decode step (>= 90 % of a generate() call), both timed live with HIP
+    events on the decoder's stream (engine.time_step_parts): the projection GEMMs of one step and its 24 single-query
+    attention launches at the mid-sequence key count.  <= 128 token rows: the GEMMs are weight-streaming (HBM bound,
+    algorithmic bytes = the fp32 weights of the step, each read once); above: MFMA bound (2 M N K flops against the
+    dense peak of the compute dtype).  Attention is HBM bound on the K/V cache bytes it must read."""
+    nkeys = (2 + (max_length + 1)) // 2
+    p = eng.time_step_parts(S_dec, nkeys, iters=3)
+    n = max(p["gemm_launches"], 1)
+    cfg = f"S{S_dec}_{dtype}"
+    if S_dec <= 128:
+        ach = p["gemm_weight_bytes"] / (p["ms_gemm"] * 1e-3) / 1e9
+        gemm = {"bound": "hbm", "kernel": "rgrg_skinny_direct_f32 (+ _wide)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(f"gemm_{cfg}"), "launches_per_decode_step": n,
+                "avg_launch_us": 1e3 * p["ms_gemm"] / n, "algorithmic_bytes_per_launch": p["gemm_weight_bytes"] / n,
+                "note": "achieved = fp32 weight bytes of the GEMM launches of one decode step (each weight read once) / their duration "
+                        "between two HIP events on the decoder stream, launched back to back in step order"}
+    else:
+        peak = MFMA_PEAK_TFS[dtype]
+        ach = p["gemm_flops"] / (p["ms_gemm"] * 1e-3) / 1e12
+        gemm = {"bound": "mfma", "kernel": "gemm_bf16w_kernel" if dtype == "bf16" else "gemm_f32_kernel", "achieved": ach, "peak": peak,
+                "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic(f"gemm_{cfg}"), "launches_per_decode_step": n,
+                "avg_launch_us": 1e3 * p["ms_gemm"] / n, "algorithmic_flops_per_launch": p["gemm_flops"] / n,
+                "note": "achieved = 2 M N K of the GEMM launches of one decode step / their duration between two HIP events on the decoder stream"}
+    ach = p["kv_bytes"] / (p["ms_attn"] * 1e-3) / 1e9
+    attn = {"bound": "hbm", "kernel": "attn_decode_kv16_kernel" if (dtype == "bf16" and S_dec > 128) else "attn_decode_kernel",
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(f"attn_{cfg}"),
+            "launches_per_decode_step": 24, "avg_launch_us": 1e3 * p["ms_attn"] / 24, "algorithmic_bytes_per_launch": p["kv_bytes"] / 24,
+            "keys_per_sequence": nkeys,
+            "note": "achieved = K/V cache bytes of the 24 attention launches of one step at the mid-sequence key count / their duration "
+                    "between two HIP events on the decoder stream"}
+    gemm["ms_per_decode_step"], attn["ms_per_decode_step"] = p["ms_gemm"], p["ms_attn"]
+    return (gemm, attn) if p["ms_gemm"] >= p["ms_attn"] else (attn, gemm)
+
+
+def cpu_baseline(sd, images, max_length, sample_steps=4):
+    """The CPU oracle (port of the reference's algorithm; oracle/) timed on this host on a BOUNDED sample of the same
+    workload: ONE image through detector + selection (full), then `sample_steps` greedy decode steps; the decode time
+    is scaled to the max_length-1 steps of the workload (the per-step cost of the reference's concat-KV decoder grows
+    slowly with length, so this slightly flatters the CPU).  As BASELINE.md section 3 prescribes: 1 warm-up + 3 timed
+    runs, median, on all PHYSICAL cores (count stated), and 3 more runs with 8 threads (comparable with the survey's
+    probe; small fp32 GEMVs do not scale with cores, so this is usually the faster one)."""
     from oracle import detector as o_det
     from oracle import full_model as o_full
     from oracle import language_model as o_lm
-    threads = min(32, os.cpu_count() or 1)  # small fp32 GEMVs do not scale past a few dozen threads
-    torch.set_num_threads(threads)
-    t0 = time.perf_counter()
-    _, _, top, cd = o_det.object_detector_forward(sd, images[:1])
-    sel, feats, _ = o_full.region_selection(sd, top, cd)
-    t_det = time.perf_counter() - t0
-    S = int(feats.shape[0])
-    t_dec = 0.0
-    if S:
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:  # noqa: BLE001
+        phys = os.cpu_count() or 1
+
+    def one_run():
         t0 = time.perf_counter()
-        o_lm.greedy_generate(sd, feats, sample_steps + 1)
-        t_dec = (time.perf_counter() - t0) * (max_length - 1) / sample_steps
-    total = t_det + t_dec
-    return {"value": 1.0 / total, "unit": "images/sec", "cores": threads, "kind": "port",
+        _, _, top, cd = o_det.object_detector_forward(sd, images[:1])
+        sel, feats, _ = o_full.region_selection(sd, top, cd)
+        t_det = time.perf_counter() - t0
+        S, t_dec = int(feats.shape[0]), 0.0
+        if S:
+            t0 = time.perf_counter()
+            o_lm.greedy_generate(sd, feats, sample_steps + 1)
+            t_dec = (time.perf_counter() - t0) * (max_length - 1) / sample_steps
+        return t_det + t_dec, t_det, t_dec, S
+
+    def median_of(threads, warmup):
+        torch.set_num_threads(threads)
+        for _ in range(warmup):
+            one_run()
+        runs = sorted(one_run() for _ in range(3))
+        return runs[1]
+
+    tot, t_det, t_dec, S = median_of(phys, 1)
+    tot8, _, _, _ = median_of(min(8, phys), 0)
+    return {"value": 1.0 / tot, "unit": "images/sec", "cores": phys, "kind": "port", "value_8_threads": 1.0 / tot8, "runs": "1 warm-up + 3 timed, median",
             "sample": f"1 image: detector+selection in full ({t_det:.1f} s) + {sample_steps} of {max_length - 1} greedy decode steps "
-                      f"for {S} regions scaled to {max_length - 1} ({t_dec:.1f} s); torch-CPU fp32 oracle, {threads} threads"}
+                      f"for {S} regions scaled to {max_length - 1} ({t_dec:.1f} s); torch-CPU fp32 oracle, {phys} threads "
+                      f"(= physical cores); value_8_threads = the same with 8 threads"}
 
 
 def main():
@@ -156,18 +214,10 @@ def main():
                        "parallelism": f"dp{world} (image shards, one RCCL all_gather of token ids)" if use_dist else "single GPU",
                        "weights": "seeded random init (rgrg_amd.synth, profile bench)", "hipGraph_decode": True},
         }
-        # roofline of the dominant kernel: the weight-streaming decode GEMM (HBM-bound at <=32 sequences)
+        # rooflines of the two kernel families of the decode loop, dominant one first (timed live, HIP events)
         try:
-            eng = model.engine()
-            S_dec = min(max(S // max(world, 1), 1), 32) if world > 1 else min(max(S, 1), 32)
-            ms_step, bytes_step, launches = eng.time_decode_gemms(S_dec, iters=3)
-            achieved = bytes_step / (ms_step * 1e-3) / 1e9
-            res["roofline"] = {"bound": "hbm", "kernel": "rgrg_skinny_gemm_f32", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(),
-                               "launches_per_decode_step": launches, "avg_launch_us": 1e3 * ms_step / max(launches, 1),
-                               "algorithmic_bytes_per_launch": bytes_step / max(launches, 1),
-                               "note": "achieved = fp32 weight bytes of the 97 GEMM launches of one decode step / their duration between "
-                                       "two HIP events on the decoder stream; traffic = FETCH_SIZE*2+WRITE_SIZE per launch from profiles/r01_pmc_traffic.json"}
+            S_dec = max(S // max(world, 1), 1)
+            res["roofline"], res["roofline_secondary"] = rooflines(model.engine(), S_dec, args.dtype, args.max_length)
         except Exception as e:  # noqa: BLE001
             res["roofline"] = {"bound": "hbm", "error": str(e)}
         if world == 1 and not args.no_cpu_baseline:

@@ -252,6 +252,14 @@ int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S, void* stre
  * of those launches (bench.py roofline). */
 int rgrg_decoder_time_gemms(rgrg_decoder* d, int S, int iters, float* ms_total, double* bytes_per_iter,
                             int* launches_per_iter);
+/* bench.py roofline, any sequence count / precision mode: `iters` replays of (a) the projection GEMM launches of one
+ * decode step for S token rows as the step would launch them, (b) its 24 single-query attention launches at `nkeys`
+ * keys per sequence, each family between one pair of HIP events on the decoder's stream.  Returns total ms of each,
+ * the algorithmic flops and weight bytes of the GEMMs of ONE step, the K/V cache bytes ONE step reads at `nkeys`
+ * keys (24 x 2 x S x 1024 x nkeys x element size), and the GEMM launches per step.  Call after a generate() so that
+ * the decoder exists in the wanted precision mode. */
+int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, int iters, float* ms_gemm, float* ms_attn,
+                                 double* gemm_flops, double* gemm_weight_bytes, double* kv_bytes, int* gemm_launches);
 
 /* Measurement helper (tools/microbench.py; not on the product path): host wall
  * microseconds per kernel of a dependent chain of n trivial kernels; mode 0 = eager on a

@@ -68,6 +68,8 @@ SIGNATURES = {
     "rgrg_linear_bf16w_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rgrg_decoder_copy_last_logits": (_i, [_p, _p, _i, _p]),
     "rgrg_decoder_time_gemms": (_i, [_p, _i, _i, C.POINTER(_f), C.POINTER(C.c_double), C.POINTER(_i)]),
+    "rgrg_decoder_time_step_parts": (_i, [_p, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "rgrg_debug_chain": (_i, [_i, _i, _i, C.POINTER(_f)]),
 }
 

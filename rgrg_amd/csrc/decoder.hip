@@ -500,7 +500,6 @@ __global__ __launch_bounds__(256) void resid_ln_kernel(float* __restrict__ x, co
 // serialises the latencies (the round-1 kernel: 9.7 us).  Each group keeps its own running softmax
 // statistics (max, sum, weighted V sum over ITS keys) - no cross-lane traffic besides the 4-step DPP dot product -
 // and the 16 partial results are merged once through LDS (flash-decoding inside the workgroup, one barrier).
-constexpr int ATT_NI = 9;
 
 __device__ __forceinline__ float group16_sum_dpp(float v) {  // sum over the 16 lanes of a DPP row, result in every lane
     v += dpp_get<0xB1, 0xf>(v);
@@ -510,7 +509,10 @@ __device__ __forceinline__ float group16_sum_dpp(float v) {  // sum over the 16 
     return v;
 }
 
-template <bool HAS_SRC>  // beam search: per-slot ancestor table (one more dependent load per key, requested first)
+// ATT_NI = keys per group per chunk: 9 (one chunk up to 144 keys, everything in flight at once) when the grid is a
+// fraction of a wave of workgroups per CU and the kernel is latency bound; 2 when thousands of workgroups queue up
+// (throughput bound: fewer registers -> more resident workgroups, no loads wasted on keys beyond nkeys)
+template <bool HAS_SRC, int ATT_NI>  // HAS_SRC (beam search): per-slot ancestor table (one more dependent load per key, requested first)
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                           float* __restrict__ kc, float* __restrict__ vc,
                                                           const int* __restrict__ step, float* __restrict__ out,
@@ -805,27 +807,45 @@ __global__ __launch_bounds__(256) void argmax_update_kernel(const float* __restr
     }
 }
 
-// tiled-GEMM path (> 128 sequences): reduce the logits row to per-32-column candidates first.  A wave covers two
-// adjacent tiles (64 consecutive logits, one coalesced 256-B load); each 32-lane half reduces with shuffles.
+// tiled-GEMM path (> 128 sequences): reduce the logits row to per-32-column candidates first.  HBM bound (the logits
+// are 186 MB at 928 rows): a lane reads 16 bytes (4 columns), 8 lanes cover a 32-column tile, a wave 8 tiles per load
+// with 4 loads in flight; the 8 lanes of a tile reduce with three DPP steps (first maximum wins: lower column on ties).
 __global__ __launch_bounds__(256) void logits_candidates_kernel(const float* __restrict__ logits, int ld, int V, int NT,
                                                                 float* __restrict__ cand_val, int* __restrict__ cand_idx) {
     const int row = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int npair = (NT + 1) / 2;
     const float* x = logits + (size_t)row * ld;
-    for (int pair = blockIdx.x * 4 + wave; pair < npair; pair += gridDim.x * 4) {
-        const int nt = pair * 2 + (lane >> 5);
-        const int col = nt * 32 + (lane & 31);
-        float bv = (nt < NT && col < V) ? x[col] : -INFINITY;
-        int bi = col;
+    const int sub = lane & 7, tw = lane >> 3;     // lane -> (16-byte piece of the tile, tile within the wave's 8)
+    constexpr int UN = 4;
+    for (int t0 = (blockIdx.x * 4 + wave) * 8 * UN; t0 < NT; t0 += gridDim.x * 4 * 8 * UN) {
+        f32x4 v[UN];
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        for (int u = 0; u < UN; ++u) {
+            const int nt = min(t0 + u * 8 + tw, NT - 1);   // clamped: the tail re-reads the last tile, results unused
+            v[u] = *reinterpret_cast<const f32x4*>(x + nt * 32 + sub * 4);   // ld >= NT * 32: always inside the row
         }
-        if ((lane & 31) == 0 && nt < NT) {
-            cand_val[(size_t)row * NT + nt] = bv;
-            cand_idx[(size_t)row * NT + nt] = bi;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int nt = t0 + u * 8 + tw;
+            const int c0 = min(nt, NT - 1) * 32 + sub * 4;
+            float bv = -INFINITY;
+            int bi = c0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float val = (c0 + e < V) ? v[u][e] : -INFINITY;
+                if (val > bv) { bv = val; bi = c0 + e; }
+            }
+#define CAND_STEP(CTRL)                                                                                     \
+    {                                                                                                       \
+        const float ov = dpp_get<CTRL, 0xf>(bv);                                                            \
+        const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, false);                           \
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }                                         \
+    }
+            CAND_STEP(0xB1) CAND_STEP(0x4E) CAND_STEP(0x141)   // lanes ^1, ^2, then 7 - i: all 8 lanes of the tile
+#undef CAND_STEP
+            if (sub == 0 && nt < NT) {
+                cand_val[(size_t)row * NT + nt] = bv;
+                cand_idx[(size_t)row * NT + nt] = bi;
+            }
         }
     }
 }
@@ -1234,6 +1254,7 @@ struct rgrg_decoder {
     std::vector<GraphEntry> graphs;
     std::vector<void*> allocs;
     size_t gemm_bytes_per_step = 0;
+    double gemm_flops_per_step = 0.0;
     // teacher-forced pass workspace (grown on demand, rgrg_decoder_lm_forward)
     float *tf_x = nullptr, *tf_xn = nullptr, *tf_qkv = nullptr, *tf_att = nullptr, *tf_ff = nullptr, *tf_logits = nullptr,
           *tf_ws = nullptr, *tf_row_loss = nullptr;
@@ -1372,12 +1393,20 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
         }
         if (count) {
             d->gemm_bytes_per_step += (size_t)l.N * l.K * sizeof(float);
+            d->gemm_flops_per_step += 2.0 * M * l.N * l.K;
             d->gemm_launches_per_step += 1;
         }
         return RGRG_OK;
     }
-    if (d->bf16_gemms && l.wb && l.K % 256 == 0)
+    if (count) {
+        d->gemm_flops_per_step += 2.0 * M * l.N * l.K;
+        d->gemm_launches_per_step += 1;
+    }
+    if (d->bf16_gemms && l.wb && l.K % 256 == 0) {
+        if (count) d->gemm_bytes_per_step += (size_t)l.N * l.K * 2;
         return launch_gemm_bf16w_ex(X16 ? nullptr : X, X16, l.wb, l.b, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream);
+    }
+    if (count) d->gemm_bytes_per_step += (size_t)l.N * l.K * sizeof(float);
     return launch_gemm_dense(X, l.w, l.b, R, Y, M, l.N, l.K, ldy, act, d->gemm_ws, d->gemm_ws_floats, d->stream);
 }
 
@@ -1389,18 +1418,20 @@ static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsig
     float* vc = kc + d->kv_kv_stride;
     if (kv_is_bf16(d, S)) {
         u16* kc16 = reinterpret_cast<u16*>(d->kv) + (size_t)l * d->kv_layer_stride;
-        if (src)
-            hipLaunchKernelGGL((attn_decode_kv16_kernel<5, true>), dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc16,
-                               kc16 + d->kv_kv_stride, d->step, d->att, S, d->H, d->T, src, att16);
-        else
-            hipLaunchKernelGGL((attn_decode_kv16_kernel<5, false>), dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc16,
-                               kc16 + d->kv_kv_stride, d->step, d->att, S, d->H, d->T, src, att16);
-    } else if (src)
-        hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc, vc, d->step,
-                           d->att, S, d->H, d->T, src, frag_out);
-    else
-        hipLaunchKernelGGL(attn_decode_kernel<false>, dim3(S * d->H), dim3(256), 0, st, d->qkv, 3 * D, kc, vc, d->step,
-                           d->att, S, d->H, d->T, src, frag_out);
+        static const int kv_ni = [] { const char* e = getenv("RGRG_KV16_NI"); return e ? atoi(e) : 1; }();  // measured at 928 sequences: 1 -> 59.7 us, 2 -> 62.9, 3 -> 60.0, 5 -> 81.2 per launch
+        const dim3 grid(S * d->H), blk(256);
+#define KV_LAUNCH(NI_, SRC_) hipLaunchKernelGGL((attn_decode_kv16_kernel<NI_, SRC_>), grid, blk, 0, st, d->qkv, 3 * D, kc16, kc16 + d->kv_kv_stride, d->step, d->att, S, d->H, d->T, src, att16)
+#define KV_NI_SWITCH(SRC_) do { if (kv_ni == 2) KV_LAUNCH(2, SRC_); else if (kv_ni == 3) KV_LAUNCH(3, SRC_); else if (kv_ni == 5) KV_LAUNCH(5, SRC_); else KV_LAUNCH(1, SRC_); } while (0)
+        if (src) KV_NI_SWITCH(true); else KV_NI_SWITCH(false);
+#undef KV_NI_SWITCH
+#undef KV_LAUNCH
+    } else {
+        const dim3 grid(S * d->H), blk(256);
+#define ATT_LAUNCH(SRC_, NI_) hipLaunchKernelGGL((attn_decode_kernel<SRC_, NI_>), grid, blk, 0, st, d->qkv, 3 * D, kc, vc, d->step, d->att, S, d->H, d->T, src, frag_out)
+        if (S * d->H <= 4096) { if (src) ATT_LAUNCH(true, 9); else ATT_LAUNCH(false, 9); }
+        else { if (src) ATT_LAUNCH(true, 2); else ATT_LAUNCH(false, 2); }
+#undef ATT_LAUNCH
+    }
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
@@ -1440,6 +1471,7 @@ static int direct_linear(rgrg_decoder* d, const Lin& l, DirectArgs a, int mode, 
     RGRG_LAUNCH_CHECK();
     if (count) {
         d->gemm_bytes_per_step += (size_t)l.N * l.K * sizeof(float);
+        d->gemm_flops_per_step += 2.0 * M * l.N * l.K;
         d->gemm_launches_per_step += 1;
     }
     return RGRG_OK;
@@ -1483,7 +1515,7 @@ static int enqueue_layer_gemms(rgrg_decoder* d, int l, int S, bool count, const 
 //   lm_head' [combine; ln_f folded; arg-max candidates] -> argmax + bookkeeping.
 // The residual stream ping-pongs between d->x and d->x2; x, att, ff and the partial sums are fragment-major.
 static int enqueue_step_fused(rgrg_decoder* d, int S, bool count, const int* tok_override, const int* src, bool beam) {
-    if (count) { d->gemm_bytes_per_step = 0; d->gemm_launches_per_step = 0; }
+    if (count) { d->gemm_bytes_per_step = 0; d->gemm_flops_per_step = 0.0; d->gemm_launches_per_step = 0; }
     hipStream_t st = d->stream;
     int rc;
     float* cur = d->x;
@@ -1510,7 +1542,7 @@ static int enqueue_step_fused(rgrg_decoder* d, int S, bool count, const int* tok
 static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_override = nullptr, const int* src = nullptr,
                         bool beam = false) {
     if (d->lm_head.direct && S <= skinny_max_rows()) return enqueue_step_fused(d, S, count, tok_override, src, beam);
-    if (count) { d->gemm_bytes_per_step = 0; d->gemm_launches_per_step = 0; }
+    if (count) { d->gemm_bytes_per_step = 0; d->gemm_flops_per_step = 0.0; d->gemm_launches_per_step = 0; }
     hipStream_t st = d->stream;
     const int D = d->D;
     const bool skinny = S <= skinny_max_rows();
@@ -1543,12 +1575,14 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
     }
     if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, false, !beam, xn16))) return rc;
     if (beam) return RGRG_OK;  // the caller ranks the logits (beam_row_topk / beam_merge)
-    if (!(skinny && d->lm_head.KS == 1 && d->lm_head.ntile == 32)) {
-        hipLaunchKernelGGL(logits_candidates_kernel, dim3(16, S), dim3(256), 0, st, d->logits, d->ld_logits, d->V,
-                           d->lm_head.NT, d->cand_val, d->cand_idx);
+    int cand_nt = d->lm_head.NT;  // candidates per row: the lm_head kernel's column tiles, or 32-column tiles of the logits
+    if (!(skinny && !d->lm_head.direct && d->lm_head.KS == 1 && d->lm_head.ntile == 32)) {
+        cand_nt = (d->V + 31) / 32;  // ld_logits >= 32 * cand_nt, and the candidate buffers hold lm_head.NT >= cand_nt per row
+        hipLaunchKernelGGL(logits_candidates_kernel, dim3(4, S), dim3(256), 0, st, d->logits, d->ld_logits, d->V,
+                           cand_nt, d->cand_val, d->cand_idx);
         RGRG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(argmax_update_kernel, dim3(S), dim3(256), 0, st, d->cand_val, d->cand_idx, d->lm_head.NT, d->ids,
+    hipLaunchKernelGGL(argmax_update_kernel, dim3(S), dim3(256), 0, st, d->cand_val, d->cand_idx, cand_nt, d->ids,
                        d->max_len, d->finished, d->step, d->done_len, d->sync, S);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
@@ -2358,5 +2392,89 @@ extern "C" int rgrg_decoder_time_gemms(rgrg_decoder* d, int S, int iters, float*
     *ms_total = total;
     *bytes_per_iter = (double)d->gemm_bytes_per_step;
     if (launches_per_iter) *launches_per_iter = d->gemm_launches_per_step;
+    return RGRG_OK;
+}
+
+namespace rgrg {
+__global__ void set_int_kernel(int* p, int v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *p = v;
+}
+}  // namespace rgrg
+
+// Live timing of the two kernel families of one decode step, each as `iters` back-to-back replays of ITS launches of
+// one step (24 layers [+ lm_head]) between one pair of HIP events on the decoder's stream:
+//   * the projection GEMMs exactly as the step would launch them for S token rows in the current precision mode
+//     (fused fragment-direct kernels <= 128 rows, tiled fp32 / bf16-weight MFMA GEMMs above);
+//   * the single-query attention at `nkeys` keys per sequence (the step counter is set to nkeys - 2 for the timing).
+// Token / cache contents are whatever the last generate() left: timing only.
+extern "C" int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, int iters, float* ms_gemm, float* ms_attn,
+                                            double* gemm_flops, double* gemm_weight_bytes, double* kv_bytes,
+                                            int* gemm_launches) {
+    RGRG_CHECK_ARG(d && S > 0 && S <= d->max_seqs && nkeys >= 2 && nkeys <= d->T && iters > 0 && ms_gemm && ms_attn);
+    hipEvent_t e0, e1;
+    RGRG_HIP(hipEventCreate(&e0));
+    RGRG_HIP(hipEventCreate(&e1));
+    const int D = d->D;
+    const bool fused = d->lm_head.direct && S <= skinny_max_rows();
+    const bool bf = kv_is_bf16(d, S);
+    unsigned short* xn16 = (bf && d->xn16) ? d->xn16 : nullptr;
+    unsigned short* att16 = xn16 ? d->att16 : nullptr;
+    unsigned short* ff16 = xn16 ? d->ff16 : nullptr;
+    int rc = RGRG_OK;
+    float tg = 0.f, ta = 0.f;
+    d->gemm_bytes_per_step = 0; d->gemm_flops_per_step = 0.0; d->gemm_launches_per_step = 0;
+    for (int it = 0; it < iters && !rc; ++it) {
+        const bool c = it == 0;
+        RGRG_HIP(hipEventRecord(e0, d->stream));
+        for (int l = 0; l < d->n_layer && !rc; ++l) {
+            const LayerW& w = d->layers[l];
+            if (fused) {
+                if ((rc = enqueue_layer_gemms(d, l ? l : 1, S, c, nullptr, d->x, d->x2, 0))) break;
+                if ((rc = enqueue_layer_gemms(d, l, S, c, nullptr, d->x, d->x2, 1))) break;
+                continue;
+            }
+            if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, c, true, false, xn16))) break;
+            if ((rc = linear(d, w.attn_proj, d->att, d->x, d->h1, S, D, RGRG_ACT_NONE, c, true, false, att16))) break;
+            if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, c, true, false, xn16, ff16))) break;
+            if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->h1, S, D, RGRG_ACT_NONE, c, true, false, ff16))) break;
+        }
+        if (!rc && fused) {
+            DirectArgs h{};
+            h.Xf = d->x; h.part = d->part; h.Y = d->logits; h.ldy = d->ld_logits; h.act = RGRG_ACT_NONE;
+            rc = direct_linear(d, d->lm_head, h, DX_COMBINE4, S, c, true);
+        } else if (!rc) {
+            rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, c, true, true, xn16);
+        }
+        if (rc) break;
+        RGRG_HIP(hipEventRecord(e1, d->stream));
+        RGRG_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        RGRG_HIP(hipEventElapsedTime(&ms, e0, e1));
+        tg += ms;
+    }
+    if (!rc) {
+        hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, d->stream, d->step, nkeys - 2);
+        for (int it = 0; it < iters && !rc; ++it) {
+            RGRG_HIP(hipEventRecord(e0, d->stream));
+            for (int l = 0; l < d->n_layer && !rc; ++l) rc = launch_attention(d, l, S, nullptr, att16, fused ? 1 : 0);
+            if (rc) break;
+            RGRG_HIP(hipEventRecord(e1, d->stream));
+            RGRG_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            RGRG_HIP(hipEventElapsedTime(&ms, e0, e1));
+            ta += ms;
+        }
+        hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, d->stream, d->step, 0);
+        (void)hipStreamSynchronize(d->stream);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    *ms_gemm = tg;
+    *ms_attn = ta;
+    if (gemm_flops) *gemm_flops = d->gemm_flops_per_step;
+    if (gemm_weight_bytes) *gemm_weight_bytes = (double)d->gemm_bytes_per_step;
+    if (kv_bytes) *kv_bytes = (double)d->n_layer * 2.0 * S * D * nkeys * (bf ? 2.0 : 4.0);
+    if (gemm_launches) *gemm_launches = d->gemm_launches_per_step;
     return RGRG_OK;
 }

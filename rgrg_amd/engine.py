@@ -604,6 +604,16 @@ class HipEngine:
         _hip.check(self.lib.rgrg_decoder_copy_last_logits(self._decoder, _hip.ptr(dst), S, self._s()), "copy_last_logits")
         return dst
 
+    def time_step_parts(self, S: int, nkeys: int, iters: int = 3) -> Dict[str, float]:
+        """Per decode step, measured with HIP events on the decoder's stream (bench.py roofline): ms spent in the
+        projection GEMM launches and in the 24 attention launches (at ``nkeys`` keys), with the algorithmic flops /
+        weight bytes / K/V bytes of one step.  Uses the decoder of the last generate() (its precision mode)."""
+        mg, ma, fl, wb, kv, n = C.c_float(0), C.c_float(0), C.c_double(0), C.c_double(0), C.c_double(0), C.c_int(0)
+        _hip.check(self.lib.rgrg_decoder_time_step_parts(self._decoder, S, nkeys, iters, C.byref(mg), C.byref(ma), C.byref(fl),
+                                                         C.byref(wb), C.byref(kv), C.byref(n)), "rgrg_decoder_time_step_parts")
+        return {"ms_gemm": mg.value / iters, "ms_attn": ma.value / iters, "gemm_flops": fl.value, "gemm_weight_bytes": wb.value,
+                "kv_bytes": kv.value, "gemm_launches": n.value}
+
     def time_decode_gemms(self, S: int, iters: int = 3) -> Tuple[float, float, int]:
         """(avg ms per decode step spent in the weight-streaming GEMM launches, algorithmic
         weight bytes per step, launches per step) measured with HIP events on the decoder's stream."""
