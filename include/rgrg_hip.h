@@ -245,6 +245,31 @@ int rgrg_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* 
 int rgrg_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 int rgrg_linear_bf16w_f32(const float* A, const uint16_t* Wb, const float* shift, const float* R, float* Y, int M,
                           int N, int K, int ldy, int act, void* stream);
+/* ---- detector targets and losses: ObjectDetector.forward(images, targets), the detector half of
+ * ReportGenerationModel.forward(images, image_targets, ...) (src/full_model/report_generation_model.py:55,91 ->
+ * src/object_detector/object_detector.py:216-224 -> custom_rpn.py:74-83, custom_roi_heads.py:225-242, and underneath
+ * torchvision 0.13.1 det_utils.Matcher / BoxCoder.encode / RegionProposalNetwork.compute_loss / fastrcnn_loss).
+ * The random sub-sampling (BalancedPositiveNegativeSampler) and the index gathers stay with the caller. */
+/* Matcher: gt [B][G][4] (gt_count[b] valid rows), boxes [N][4] per image at boxes + b * box_image_stride floats
+ * (stride 0: one shared set, the anchors), box_count[b] valid boxes (NULL: N).  matched [B][N] = index of the best gt
+ * (first maximum), -1 below `low`, -2 between; allow_low_quality restores the arg-max of every box that ties a gt's
+ * best IoU.  ws_best_per_gt: B * G ints of work space. */
+int rgrg_box_match_f32(const float* gt, const int* gt_count, int G, const float* boxes, int64_t box_image_stride,
+                       const int* box_count, int B, int N, float high, float low, int allow_low_quality, int* matched,
+                       int* ws_best_per_gt, void* stream);
+/* BoxCoder.encode: deltas [n][4] of ref_boxes [n][4] relative to proposals [n][4], weights (wx, wy, ww, wh). */
+int rgrg_box_encode_f32(const float* ref_boxes, const float* proposals, int n, float wx, float wy, float ww, float wh,
+                        float* out, void* stream);
+/* RPN losses on the fused head output rpn_out [B * cells][ld] (anchors_per_cell objectness columns, then 4 deltas per
+ * anchor); labels / reg_targets are per flat anchor index (image-major), pos_idx / sampled_idx the sampled flat
+ * indices.  out2[0] = loss_objectness, out2[1] = loss_rpn_box_reg. */
+int rgrg_rpn_loss_f32(const float* rpn_out, int ld, int anchors_per_cell, const float* labels, const float* reg_targets,
+                      const int64_t* pos_idx, int n_pos, const int64_t* sampled_idx, int n_sampled, float* out2, void* stream);
+/* fastrcnn_loss on pred [N][ld] = num_classes logits | num_classes x 4 deltas.  out2[0] = loss_classifier,
+ * out2[1] = loss_box_reg. */
+int rgrg_fastrcnn_loss_f32(const float* pred, int ld, int num_classes, const int64_t* labels, const float* reg_targets, int N,
+                           float* out2, void* stream);
+
 /* Debug/parity taps: logits of the LAST executed step [S, vocab] -> dst (device). */
 int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S, void* stream);
 /* Times `iters` replays of one decode step's weight-streaming GEMM launches with HIP

@@ -85,18 +85,39 @@ def roi_heads_forward(sd: SD, p: str, feat: Tensor, proposals: List[Tensor], ima
     return out
 
 
-def object_detector_forward(sd: SD, images: Tensor, p: str = "object_detector.", return_intermediates: bool = False):
-    """ObjectDetector.forward(images, targets=None) in eval mode with
-    return_feature_vectors=True (object_detector.py:184-261) ->
-    (losses={}, detections, top_region_features [B,29,1024], class_detected [B,29])."""
+def object_detector_forward(sd: SD, images: Tensor, p: str = "object_detector.", return_intermediates: bool = False,
+                            targets=None, perm_fn=tv013.default_perm):
+    """ObjectDetector.forward(images, targets) in eval mode with return_feature_vectors=True
+    (object_detector.py:184-261) -> (losses, detections, top_region_features [B,29,1024], class_detected [B,29]).
+    targets=None: inference, losses = {}.  With targets (the reference's validation loop, evaluate_model.py:413) the
+    four detector losses are computed AND - exactly like the reference - the RoI heads run on the SAMPLED training
+    proposals (custom_roi_heads.py:225-226), so detections / region features depend on the sampler's draws
+    (``perm_fn``, see tv013.balanced_sample)."""
     feat = tv013.resnet50_trunk(sd, p + "backbone.", images)
     image_sizes = [tuple(images.shape[-2:])] * images.shape[0]  # image_list.py:15-20
-    proposals = rpn_forward(sd, p + "rpn.", feat, image_sizes[0])
-    out = roi_heads_forward(sd, p + "roi_heads.", feat, proposals, image_sizes, return_intermediates)
+    losses = {}
+    if targets is None:
+        proposals = rpn_forward(sd, p + "rpn.", feat, image_sizes[0])
+        labels = reg_targets = None
+    else:
+        B = feat.shape[0]
+        obj, reg = tv013.rpn_head(sd, p + "rpn.head.", feat)
+        anchors = tv013.grid_anchors(image_sizes[0], tuple(feat.shape[-2:]))
+        objectness = tv013.permute_and_flatten(obj, 1).reshape(-1, 1)
+        deltas = tv013.permute_and_flatten(reg, 4).reshape(-1, 4)
+        boxes = tv013.box_decode(deltas, anchors.repeat(B, 1), (1.0, 1.0, 1.0, 1.0)).view(B, -1, 4)
+        proposals, _ = tv013.filter_proposals(boxes, objectness.reshape(B, -1), image_sizes[0])
+        losses["loss_objectness"], losses["loss_rpn_box_reg"] = tv013.rpn_targets_and_loss(objectness, deltas, anchors, targets, perm_fn)
+        proposals, labels, reg_targets = tv013.select_training_samples(proposals, targets, perm_fn)
+    out = roi_heads_forward(sd, p + "roi_heads.", feat, proposals, image_sizes, return_intermediates or targets is not None)
+    if targets is not None:
+        cls_loss, box_loss = tv013.fastrcnn_loss(out["_class_logits"], out["_box_regression"], labels, reg_targets)
+        # the reference's dict order: roi-head losses first, then the RPN's (object_detector.py:240-242)
+        losses = {"loss_classifier": cls_loss, "loss_box_reg": box_loss, **losses}
     if return_intermediates:
-        out["_features"], out["_proposals"] = feat, proposals
+        out["_features"], out["_proposals"], out["_losses"] = feat, proposals, losses
         return out
-    return {}, out["detections"], out["top_region_features"], out["class_detected"]
+    return losses, out["detections"], out["top_region_features"], out["class_detected"]
 
 
 def bbox_features(sd: SD, images: Tensor, bbox_coordinates: List[Tensor], p: str = "object_detector.") -> Tensor:

@@ -41,13 +41,16 @@ def _classifier_logits(sd: SD, c: str, x: Tensor) -> Tensor:
 
 @torch.no_grad()
 def forward_eval(sd: SD, images: Tensor, input_ids: Tensor, attention_mask: Tensor, region_has_sentence: Tensor,
-                 region_is_abnormal: Tensor):
-    """ReportGenerationModel.forward in eval mode with ``image_targets=None`` (report_generation_model.py:87-168):
-    detector (losses {}), selection classifier loss (BCEWithLogits pos_weight 2.2 on detected regions) and
+                 region_is_abnormal: Tensor, image_targets=None, perm_fn=None):
+    """ReportGenerationModel.forward in eval mode (report_generation_model.py:87-168): detector (losses {} when
+    ``image_targets`` is None; with targets its four losses, computed on the sampled proposals - ``perm_fn`` supplies the
+    sampler's draws, see oracle.tv013), selection classifier loss (BCEWithLogits pos_weight 2.2 on detected regions) and
     ``selected_regions``, abnormal classifier loss (pos_weight 6.0) and ``logits > -1`` predictions, decoder inputs of
     the selected regions (:196-210), teacher-forced LM loss.  Returns the reference's 8-tuple, or -1 (:136)."""
     from .language_model import lm_teacher_forced
-    _, detections, top_region_features, class_detected = object_detector_forward(sd, images)
+    from . import tv013
+    det_losses, detections, top_region_features, class_detected = object_detector_forward(
+        sd, images, targets=image_targets, perm_fn=perm_fn or tv013.default_perm)
     selected_regions, selected_feats, sel_logits = region_selection(sd, top_region_features, class_detected)
     loss_sel = F.binary_cross_entropy_with_logits(sel_logits[class_detected], region_has_sentence[class_detected].float(),
                                                   pos_weight=torch.tensor([2.2]))
@@ -60,7 +63,7 @@ def forward_eval(sd: SD, images: Tensor, input_ids: Tensor, attention_mask: Tens
     if ids.shape[0] == 0:
         return -1
     lm_loss = lm_teacher_forced(sd, ids, mask, selected_feats, return_loss=True)
-    return {}, loss_sel, loss_abn, lm_loss, detections, class_detected, selected_regions, predicted_abnormal
+    return det_losses, loss_sel, loss_abn, lm_loss, detections, class_detected, selected_regions, predicted_abnormal
 
 
 def train_losses_and_grads(sd: SD, images: Tensor, input_ids: Tensor, attention_mask: Tensor, region_has_sentence: Tensor,

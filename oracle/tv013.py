@@ -296,3 +296,145 @@ def fastrcnn_predictor(sd: SD, p: str, x: Tensor) -> Tuple[Tensor, Tensor]:
     x = x.flatten(start_dim=1)
     return (F.linear(x, sd[p + "cls_score.weight"], sd[p + "cls_score.bias"]),
             F.linear(x, sd[p + "bbox_pred.weight"], sd[p + "bbox_pred.bias"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Targets and losses (torchvision 0.13.1 ``models/detection/_utils.py``, ``rpn.py``, ``roi_heads.py``, ``ops/boxes.py``):
+# what RegionProposalNetwork / RoIHeads do when ``targets`` are given - in EVAL mode too, which is how the reference's
+# validation loop calls the model (evaluate_model.py:413; custom_rpn.py:74-83; custom_roi_heads.py:225-242).
+# torchvision samples anchors / proposals with torch.randperm; here the permutations come from ``perm_fn(n, tag)`` so
+# that a test can give the oracle and the HIP path the SAME draws (the default draws with torch.randperm like
+# torchvision).  Third-party semantics, restated from the published source: parity unpinned.
+BELOW_LOW_THRESHOLD, BETWEEN_THRESHOLDS = -1, -2
+
+
+def box_iou(boxes1: Tensor, boxes2: Tensor) -> Tensor:
+    """ops.boxes.box_iou: [N,4] x [M,4] -> [N,M]."""
+    area1 = (boxes1[:, 2] - boxes1[:, 0]) * (boxes1[:, 3] - boxes1[:, 1])
+    area2 = (boxes2[:, 2] - boxes2[:, 0]) * (boxes2[:, 3] - boxes2[:, 1])
+    lt = torch.max(boxes1[:, None, :2], boxes2[:, :2])
+    rb = torch.min(boxes1[:, None, 2:], boxes2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[:, :, 0] * wh[:, :, 1]
+    return inter / (area1[:, None] + area2 - inter)
+
+
+def matcher(mqm: Tensor, high: float, low: float, allow_low_quality_matches: bool) -> Tensor:
+    """det_utils.Matcher.__call__ on a [num_gt, num_boxes] quality matrix -> per box: gt index, -1 (below low) or -2."""
+    matched_vals, matches = mqm.max(dim=0)
+    all_matches = matches.clone()
+    below = matched_vals < low
+    between = (matched_vals >= low) & (matched_vals < high)
+    matches[below] = BELOW_LOW_THRESHOLD
+    matches[between] = BETWEEN_THRESHOLDS
+    if allow_low_quality_matches:  # set_low_quality_matches_: every box that ties a gt's best IoU keeps its arg-max match
+        highest, _ = mqm.max(dim=1)
+        pred_inds = torch.where(mqm == highest[:, None])[1]
+        matches[pred_inds] = all_matches[pred_inds]
+    return matches
+
+
+def box_encode(reference_boxes: Tensor, proposals: Tensor, weights: Tuple[float, float, float, float]) -> Tensor:
+    """det_utils.encode_boxes."""
+    wx, wy, ww, wh = weights
+    px1, py1, px2, py2 = proposals.unbind(1)
+    rx1, ry1, rx2, ry2 = reference_boxes.unbind(1)
+    ex_w, ex_h = px2 - px1, py2 - py1
+    ex_cx, ex_cy = px1 + 0.5 * ex_w, py1 + 0.5 * ex_h
+    gt_w, gt_h = rx2 - rx1, ry2 - ry1
+    gt_cx, gt_cy = rx1 + 0.5 * gt_w, ry1 + 0.5 * gt_h
+    return torch.stack((wx * (gt_cx - ex_cx) / ex_w, wy * (gt_cy - ex_cy) / ex_h,
+                        ww * torch.log(gt_w / ex_w), wh * torch.log(gt_h / ex_h)), dim=1)
+
+
+def default_perm(n: int, tag) -> Tensor:
+    return torch.randperm(n)
+
+
+def balanced_sample(labels: Tensor, batch_size_per_image: int, positive_fraction: float, perm_fn, tag) -> Tuple[Tensor, Tensor]:
+    """det_utils.BalancedPositiveNegativeSampler for one image -> (positive indices, negative indices) as drawn."""
+    positive = torch.where(labels >= 1)[0]
+    negative = torch.where(labels == 0)[0]
+    num_pos = min(positive.numel(), int(batch_size_per_image * positive_fraction))
+    num_neg = min(negative.numel(), batch_size_per_image - num_pos)
+    perm1 = perm_fn(positive.numel(), (tag, "pos"))[:num_pos]
+    perm2 = perm_fn(negative.numel(), (tag, "neg"))[:num_neg]
+    return positive[perm1], negative[perm2]
+
+
+def rpn_targets_and_loss(objectness: Tensor, pred_bbox_deltas: Tensor, anchors: Tensor, targets, perm_fn=default_perm):
+    """RegionProposalNetwork.assign_targets_to_anchors + box_coder.encode + compute_loss (rpn.py), configured as
+    object_detector.py:84-96: fg 0.7 / bg 0.3 with low-quality matches, 256 anchors per image, half positive.
+    objectness [B*A,1], pred_bbox_deltas [B*A,4] (image-major), anchors [A,4] (the same grid for every image)."""
+    labels, reg_targets, pos_all, neg_all = [], [], [], []
+    A = anchors.shape[0]
+    for i, t in enumerate(targets):
+        gt = t["boxes"].to(torch.float32)
+        if gt.numel() == 0:
+            matched_gt = torch.zeros_like(anchors)
+            lab = torch.zeros((A,), dtype=torch.float32)
+        else:
+            m = matcher(box_iou(gt, anchors), 0.7, 0.3, True)
+            matched_gt = gt[m.clamp(min=0)]
+            lab = (m >= 0).to(torch.float32)
+            lab[m == BELOW_LOW_THRESHOLD] = 0.0
+            lab[m == BETWEEN_THRESHOLDS] = -1.0
+        labels.append(lab)
+        reg_targets.append(box_encode(matched_gt, anchors, (1.0, 1.0, 1.0, 1.0)))
+        p, n = balanced_sample(lab, 256, 0.5, perm_fn, ("rpn", i))
+        pos_mask = torch.zeros((A,), dtype=torch.bool)
+        neg_mask = torch.zeros((A,), dtype=torch.bool)
+        pos_mask[p] = True
+        neg_mask[n] = True
+        pos_all.append(pos_mask)
+        neg_all.append(neg_mask)
+    sampled_pos = torch.where(torch.cat(pos_all))[0]
+    sampled_neg = torch.where(torch.cat(neg_all))[0]
+    sampled = torch.cat([sampled_pos, sampled_neg])
+    obj = objectness.flatten()
+    lab = torch.cat(labels)
+    reg = torch.cat(reg_targets)
+    box_loss = F.smooth_l1_loss(pred_bbox_deltas[sampled_pos], reg[sampled_pos], beta=1 / 9, reduction="sum") / sampled.numel()
+    obj_loss = F.binary_cross_entropy_with_logits(obj[sampled], lab[sampled])
+    return obj_loss, box_loss
+
+
+def select_training_samples(proposals: List[Tensor], targets, perm_fn=default_perm):
+    """RoIHeads.select_training_samples (roi_heads.py), configured as object_detector.py:118-123: add the gt boxes to
+    the proposals, match at IoU 0.5 (no low-quality matches), sample 512 per image with a quarter positive, keep the
+    sampled proposals IN INDEX ORDER, encode the matched gt boxes with weights (10, 10, 5, 5)."""
+    out_props, out_labels, out_reg = [], [], []
+    for i, (props, t) in enumerate(zip(proposals, targets)):
+        gt = t["boxes"].to(props.dtype)
+        props = torch.cat((props, gt))
+        if gt.numel() == 0:
+            clamped = torch.zeros((props.shape[0],), dtype=torch.int64)
+            lab = torch.zeros((props.shape[0],), dtype=torch.int64)
+        else:
+            m = matcher(box_iou(gt, props), 0.5, 0.5, False)
+            clamped = m.clamp(min=0)
+            lab = t["labels"][clamped].to(torch.int64)
+            lab[m == BELOW_LOW_THRESHOLD] = 0
+            lab[m == BETWEEN_THRESHOLDS] = -1
+        p, n = balanced_sample(lab, 512, 0.25, perm_fn, ("roi", i))
+        mask = torch.zeros((props.shape[0],), dtype=torch.bool)
+        mask[p] = True
+        mask[n] = True
+        inds = torch.where(mask)[0]
+        gt_in = gt if gt.numel() else torch.zeros((1, 4), dtype=props.dtype)
+        out_props.append(props[inds])
+        out_labels.append(lab[inds])
+        out_reg.append(box_encode(gt_in[clamped[inds]], props[inds], (10.0, 10.0, 5.0, 5.0)))
+    return out_props, out_labels, out_reg
+
+
+def fastrcnn_loss(class_logits: Tensor, box_regression: Tensor, labels: List[Tensor], regression_targets: List[Tensor]):
+    """roi_heads.fastrcnn_loss."""
+    lab = torch.cat(labels)
+    reg = torch.cat(regression_targets)
+    cls_loss = F.cross_entropy(class_logits, lab)
+    pos = torch.where(lab > 0)[0]
+    N = class_logits.shape[0]
+    br = box_regression.reshape(N, box_regression.size(-1) // 4, 4)
+    box_loss = F.smooth_l1_loss(br[pos, lab[pos]], reg[pos], beta=1 / 9, reduction="sum") / lab.numel()
+    return cls_loss, box_loss

@@ -40,6 +40,8 @@ def _on_engine_device(cls):
         return inner
 
     for name, fn in list(vars(cls).items()):
+        if isinstance(fn, (staticmethod, classmethod)):
+            continue
         if callable(fn) and not name.startswith("__") and name != "_s":
             setattr(cls, name, wrap(fn))
     return cls
@@ -282,8 +284,9 @@ class HipEngine:
             x = self.conv(o, blk["c3"], _hip.ACT_RELU, residual=idt)
         return x
 
-    def rpn(self, feat: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
-        """RPN head + proposal filtering -> proposals [B,1000,4], counts [B], offsets [B+1] (device)."""
+    def rpn(self, feat: Tensor, return_head: bool = False):
+        """RPN head + proposal filtering -> proposals [B,1000,4], counts [B], offsets [B+1] (device)
+        (+ the raw head output [B,FH,FW,800] = objectness | deltas when ``return_head``: the RPN losses read it)."""
         B, FH, FW, _ = feat.shape
         t = self.conv(feat, self.rpn_conv, _hip.ACT_RELU)
         head = self.conv(t, self.rpn_head, _hip.ACT_NONE)  # [B,FH,FW,800]
@@ -295,6 +298,8 @@ class HipEngine:
                                                    _hip.ptr(counts), _hip.ptr(offsets), B, FH * FW, self.num_anchors,
                                                    RPN_PRE_NMS_TOP_N, RPN_POST_NMS_TOP_N, RPN_NMS_THRESH, 1e-3, size,
                                                    size, self._s()), "rgrg_rpn_proposals_f32")
+        if return_head:
+            return props, counts, offsets, head
         return props, counts, offsets
 
     def _fc6_bf16(self) -> Tensor:
@@ -362,17 +367,157 @@ class HipEngine:
                                                        _hip.ptr(pooled), B, FH, FW, Cf, maxn, R, scale, self._s()), "rgrg_roi_align")
         return maps, pooled
 
-    def detect(self, images: Tensor, taps: Optional[dict] = None, bf16: bool = False):
-        """ObjectDetector.forward (inference): -> (detections, top_region_features, class_detected).  bf16 (opt-in
-        through torch.autocast): fc6 on the bf16 MFMA; trunk, RPN, RoIAlign and the post-processing stay fp32."""
+    def detect(self, images: Tensor, taps: Optional[dict] = None, bf16: bool = False, targets=None, perm_fn=None):
+        """ObjectDetector.forward in eval mode: -> (detections, top_region_features, class_detected) or, with
+        ``targets`` (list of {"boxes" [n,4], "labels" [n]} per image), (losses, detections, top_region_features,
+        class_detected) where - as in the reference - the RoI heads then run on the SAMPLED training proposals.
+        bf16 (opt-in through torch.autocast): fc6 on the bf16 MFMA; trunk, RPN, RoIAlign, post-processing stay fp32."""
         _require_gpu(images.device)
         images = images.to(torch.float32)
         feat = self.backbone(images)
-        props, counts, offsets = self.rpn(feat)
-        cd, scores, boxes, top = self.roi_heads(feat, props, offsets, taps, bf16)
+        if targets is None:
+            props, counts, offsets = self.rpn(feat)
+            cd, scores, boxes, top = self.roi_heads(feat, props, offsets, taps, bf16)
+            if taps is not None:
+                taps.update(features_nhwc=feat, proposals=props, counts=counts, offsets=offsets)
+            return {"top_region_boxes": boxes, "top_scores": scores}, top, cd
+        perm_fn = perm_fn or (lambda n, tag: torch.randperm(n, device=images.device))
+        props, counts, offsets, head = self.rpn(feat, return_head=True)
+        gt, gt_count, gt_labels = self._pad_targets(targets, images.device)
+        loss_obj, loss_rpn_box = self._rpn_losses(head, gt, gt_count, perm_fn)
+        props_s, offsets_s, labels_s, reg_s = self._select_training_samples(props, counts, gt, gt_count, gt_labels, perm_fn)
+        t2 = {} if taps is None else taps
+        cd, scores, boxes, top = self.roi_heads(feat, props_s, offsets_s, t2, bf16)
+        out2 = torch.empty((2,), dtype=torch.float32, device=images.device)
+        R = int(labels_s.shape[0])
+        pred = t2.get("pred")
+        _hip.check(self.lib.rgrg_fastrcnn_loss_f32(None if pred is None else _hip.ptr(pred), 150 if pred is None else pred.shape[1], 30,
+                                                   _hip.ptr(labels_s), _hip.ptr(reg_s), R if pred is not None else 0, _hip.ptr(out2),
+                                                   self._s()), "rgrg_fastrcnn_loss_f32")
+        # the reference's dict order: RoI-head losses, then the RPN's (object_detector.py:240-242)
+        losses = {"loss_classifier": out2[0], "loss_box_reg": out2[1], "loss_objectness": loss_obj, "loss_rpn_box_reg": loss_rpn_box}
         if taps is not None:
-            taps.update(features_nhwc=feat, proposals=props, counts=counts, offsets=offsets)
-        return {"top_region_boxes": boxes, "top_scores": scores}, top, cd
+            taps.update(features_nhwc=feat, proposals=props_s, offsets=offsets_s, sampled_labels=labels_s, sampled_reg_targets=reg_s)
+        return losses, {"top_region_boxes": boxes, "top_scores": scores}, top, cd
+
+    # ------------------------------------------------------------------ detector targets / losses (eval forward with image_targets)
+    @staticmethod
+    def _pad_targets(targets, dev):
+        """list of {"boxes", "labels"} -> gt [B,G,4] fp32 (zero padded), gt_count int32 [B], labels list (device int64)."""
+        B = len(targets)
+        G = max(1, max(int(t["boxes"].shape[0]) for t in targets))
+        gt = torch.zeros((B, G, 4), dtype=torch.float32, device=dev)
+        cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+        labels = []
+        for i, t in enumerate(targets):
+            n = int(t["boxes"].shape[0])
+            if n:
+                gt[i, :n] = t["boxes"].to(device=dev, dtype=torch.float32)
+            cnt[i] = n
+            labels.append(t["labels"].to(device=dev, dtype=torch.int64))
+        return gt, cnt, labels
+
+    def _match(self, gt, gt_count, boxes, box_image_stride, box_count, N, high, low, allow_low_quality) -> Tensor:
+        B, G = gt.shape[:2]
+        matched = torch.empty((B, N), dtype=torch.int32, device=gt.device)
+        ws = torch.empty((B, G), dtype=torch.int32, device=gt.device)
+        _hip.check(self.lib.rgrg_box_match_f32(_hip.ptr(gt), _hip.ptr(gt_count), G, _hip.ptr(boxes), box_image_stride,
+                                               None if box_count is None else _hip.ptr(box_count), B, N, high, low,
+                                               1 if allow_low_quality else 0, _hip.ptr(matched), _hip.ptr(ws), self._s()),
+                   "rgrg_box_match_f32")
+        return matched
+
+    def _encode(self, ref: Tensor, props: Tensor, weights) -> Tensor:
+        out = torch.empty_like(props)
+        _hip.check(self.lib.rgrg_box_encode_f32(_hip.ptr(ref.contiguous()), _hip.ptr(props.contiguous()), props.shape[0], *map(float, weights),
+                                                _hip.ptr(out), self._s()), "rgrg_box_encode_f32")
+        return out
+
+    @staticmethod
+    def _balanced_sample(labels: Tensor, batch: int, frac: float, perm_fn, tag):
+        """det_utils.BalancedPositiveNegativeSampler for one image (index plumbing; the draws come from perm_fn)."""
+        positive = torch.where(labels >= 1)[0]
+        negative = torch.where(labels == 0)[0]
+        num_pos = min(positive.numel(), int(batch * frac))
+        num_neg = min(negative.numel(), batch - num_pos)
+        p1 = perm_fn(positive.numel(), (tag, "pos")).to(labels.device)[:num_pos]
+        p2 = perm_fn(negative.numel(), (tag, "neg")).to(labels.device)[:num_neg]
+        return positive[p1], negative[p2]
+
+    def _rpn_losses(self, head: Tensor, gt: Tensor, gt_count: Tensor, perm_fn):
+        """RegionProposalNetwork.assign_targets_to_anchors + encode + compute_loss (custom_rpn.py:74-83;
+        object_detector.py:84-96: fg 0.7 / bg 0.3, low-quality matches, 256 anchors per image, half positive)."""
+        B, FH, FW, ld = head.shape
+        A = self.anchors.shape[0]
+        dev = head.device
+        m = self._match(gt, gt_count, self.anchors, 0, None, A, 0.7, 0.3, True)
+        labels = (m >= 0).to(torch.float32)
+        labels[m == -2] = -1.0  # between the thresholds: ignored (BELOW_LOW_THRESHOLD already maps to 0)
+        ref = torch.gather(gt, 1, m.clamp(min=0).to(torch.int64)[:, :, None].expand(B, A, 4))  # images without gt: zeros
+        reg = self._encode(ref.reshape(B * A, 4), self.anchors.repeat(B, 1), (1.0, 1.0, 1.0, 1.0))
+        pos_masks, neg_masks = [], []
+        for i in range(B):
+            p, n = self._balanced_sample(labels[i], 256, 0.5, perm_fn, ("rpn", i))
+            pm = torch.zeros((A,), dtype=torch.bool, device=dev)
+            nm = torch.zeros((A,), dtype=torch.bool, device=dev)
+            pm[p] = True
+            nm[n] = True
+            pos_masks.append(pm)
+            neg_masks.append(nm)
+        pos_idx = torch.where(torch.cat(pos_masks))[0]
+        all_idx = torch.cat([pos_idx, torch.where(torch.cat(neg_masks))[0]]).contiguous()
+        out2 = torch.empty((2,), dtype=torch.float32, device=dev)
+        _hip.check(self.lib.rgrg_rpn_loss_f32(_hip.ptr(head), ld, self.num_anchors, _hip.ptr(labels), _hip.ptr(reg),
+                                              _hip.ptr(pos_idx) if pos_idx.numel() else None, pos_idx.numel(),
+                                              _hip.ptr(all_idx) if all_idx.numel() else None, all_idx.numel(), _hip.ptr(out2), self._s()),
+                   "rgrg_rpn_loss_f32")
+        return out2[0], out2[1]
+
+    def _select_training_samples(self, props: Tensor, counts: Tensor, gt: Tensor, gt_count: Tensor, gt_labels, perm_fn):
+        """RoIHeads.select_training_samples (custom_roi_heads.py:225-226; object_detector.py:118-123: IoU 0.5, 512
+        per image, a quarter positive, BoxCoder weights (10,10,5,5)) -> proposals [B,maxK,4], offsets int32 [B+1],
+        labels int64 [sum K], regression targets [sum K,4]."""
+        B, G = gt.shape[:2]
+        dev = props.device
+        cnt, gcnt = counts.tolist(), gt_count.tolist()
+        N = max(c + g for c, g in zip(cnt, gcnt))
+        boxes = torch.zeros((B, N, 4), dtype=torch.float32, device=dev)
+        for i in range(B):  # add_gt_proposals
+            boxes[i, :cnt[i]] = props[i, :cnt[i]]
+            boxes[i, cnt[i]:cnt[i] + gcnt[i]] = gt[i, :gcnt[i]]
+        box_count = torch.tensor([c + g for c, g in zip(cnt, gcnt)], dtype=torch.int32, device=dev)
+        m = self._match(gt, gt_count, boxes, N * 4, box_count, N, 0.5, 0.5, False)
+        out_props, out_labels, out_ref = [], [], []
+        for i in range(B):
+            n = cnt[i] + gcnt[i]
+            mi = m[i, :n].to(torch.int64)
+            clamped = mi.clamp(min=0)
+            if gcnt[i]:
+                lab = gt_labels[i][clamped]
+                lab = torch.where(mi == -1, torch.zeros_like(lab), lab)
+                lab = torch.where(mi == -2, torch.full_like(lab, -1), lab)
+            else:
+                lab = torch.zeros((n,), dtype=torch.int64, device=dev)
+            p, q = self._balanced_sample(lab, 512, 0.25, perm_fn, ("roi", i))
+            mask = torch.zeros((n,), dtype=torch.bool, device=dev)
+            mask[p] = True
+            mask[q] = True
+            inds = torch.where(mask)[0]
+            out_props.append(boxes[i, inds])
+            out_labels.append(lab[inds])
+            out_ref.append(gt[i][clamped[inds]] if gcnt[i] else torch.zeros((inds.numel(), 4), dtype=torch.float32, device=dev))
+        ks = [int(p.shape[0]) for p in out_props]
+        maxk = max(1, max(ks))
+        props_s = torch.zeros((B, maxk, 4), dtype=torch.float32, device=dev)
+        for i, p in enumerate(out_props):
+            props_s[i, :ks[i]] = p
+        offs = [0]
+        for k in ks:
+            offs.append(offs[-1] + k)
+        offsets_s = torch.tensor(offs, dtype=torch.int32, device=dev)
+        allp = torch.cat(out_props) if sum(ks) else torch.zeros((0, 4), dtype=torch.float32, device=dev)
+        reg = self._encode(torch.cat(out_ref), allp, (10.0, 10.0, 5.0, 5.0)) if sum(ks) else allp
+        return props_s, offsets_s, torch.cat(out_labels).contiguous(), reg
 
     # ------------------------------------------------------------------ selection
     def classifier_logits(self, mlp, x: Tensor) -> Tensor:

@@ -156,8 +156,8 @@ class ImageList:
 
 
 class ObjectDetector(EngineOwner):
-    """Faster R-CNN with a ResNet-50 C5 trunk (object_detector.py:18).  Only the
-    inference branch (``targets=None``, eval) is implemented on the HIP path."""
+    """Faster R-CNN with a ResNet-50 C5 trunk (object_detector.py:18), eval mode: inference (``targets=None``) and
+    the validation forward with targets (detector losses)."""
 
     _engine_prefix = "object_detector."
 
@@ -178,13 +178,34 @@ class ObjectDetector(EngineOwner):
     def _transform_inputs_for_rpn_and_roi(self, images, features):
         return ImageList(images), OrderedDict([("0", features)])
 
+    def _check_targets(self, targets) -> None:
+        """object_detector.py:133-162: every box needs positive width and height."""
+        for t in targets:
+            boxes = t["boxes"]
+            if not isinstance(boxes, torch.Tensor) or boxes.dim() != 2 or boxes.shape[-1] != 4:
+                raise ValueError(f"Expected target boxes to be a tensor of shape [N, 4], got {getattr(boxes, 'shape', type(boxes))}.")
+            degenerate = boxes[:, 2:] <= boxes[:, :2]
+            if degenerate.any():
+                bb_idx = torch.where(degenerate.any(dim=1))[0][0]
+                raise ValueError("All bounding boxes should have positive height and width."
+                                 f" Found invalid box {boxes[bb_idx].tolist()}.")
+
     def forward(self, images: Tensor, targets: Optional[List[Dict[str, Tensor]]] = None):
-        if targets is not None or self.training:
-            raise NotImplementedError("rgrg_amd implements the inference branch of ObjectDetector.forward "
-                                      "(targets=None, eval mode); training is a later row of SURVEY.md 8(f)")
+        """Eval-mode ``ObjectDetector.forward`` (object_detector.py:184-261).  ``targets=None``: inference, losses = {}.
+        With targets (the reference's validation loop) the four detector losses are returned and - exactly as in the
+        reference - detections / region features come from the SAMPLED training proposals.  ``self.sampler_perm`` (a
+        callable ``(n, tag) -> permutation``) replaces torch.randperm in the two samplers when set (tests)."""
+        if self.training:
+            raise NotImplementedError("rgrg_amd runs the detector in eval mode (BatchNorm running statistics, test-time "
+                                      "proposal counts); training the detector is not implemented")
         low = images.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
-        detections, top_region_features, class_detected = self.engine().detect(images, bf16=bool(low))
         losses: Dict[str, Tensor] = {}
+        if targets is not None:
+            self._check_targets(targets)
+            losses, detections, top_region_features, class_detected = self.engine().detect(
+                images, bf16=bool(low), targets=targets, perm_fn=getattr(self, "sampler_perm", None))
+        else:
+            detections, top_region_features, class_detected = self.engine().detect(images, bf16=bool(low))
         if not self.return_feature_vectors:
             return losses, detections, class_detected
         return losses, detections, top_region_features, class_detected

@@ -101,16 +101,15 @@ class ReportGenerationModel(EngineOwner):
         language_model_loss, detections, class_detected, selected_regions, predicted_abnormal_regions)``, the
         7-tuple without the LM loss when ``pretrain_without_lm_model``, or ``-1`` when no region is selected (:136).
 
-        Not implemented: ``image_targets`` in eval mode (the detector's validation losses draw random anchor/proposal
-        samples, torchvision ``BalancedPositiveNegativeSampler``): pass ``image_targets=None`` and
-        ``obj_detector_loss_dict`` is ``{}`` as in the reference's ``targets is None`` path (object_detector.py:195-197).
+        ``image_targets`` (list of {"boxes", "labels"} per image, as evaluate_model.py:413 passes them): the detector
+        returns its four validation losses and - as in the reference - runs its RoI heads on the randomly SAMPLED
+        training proposals (custom_roi_heads.py:225-226), so the detections / region features of this call depend on the
+        sampler's draws.  ``image_targets=None``: ``obj_detector_loss_dict`` is ``{}`` (object_detector.py:195-197).
         In ``train()`` mode see ``_forward_train`` (frozen detector)."""
         if self.training:
             return self._forward_train(images, input_ids, attention_mask, region_has_sentence, region_is_abnormal, return_loss,
                                        past_key_values, position_ids, use_cache)
-        if image_targets is not None:
-            raise NotImplementedError("detector validation losses (image_targets) are not implemented: pass image_targets=None")
-        obj_detector_loss_dict, detections, top_region_features, class_detected = self.object_detector(images, None)
+        obj_detector_loss_dict, detections, top_region_features, class_detected = self.object_detector(images, image_targets)
         del images
         classifier_loss_region_selection, selected_regions, selected_region_features = self.binary_classifier_region_selection(
             top_region_features, class_detected, return_loss=True, region_has_sentence=region_has_sentence)

@@ -152,3 +152,63 @@ def test_bpe_decoder_matches_transformers_on_a_synthetic_vocabulary(tmp_path):
     raw = dec.decode(ids, skip_special_tokens=True, clean_up_tokenization_spaces=False)
     assert hf.decode(ids, skip_special_tokens=True, clean_up_tokenization_spaces=False) == raw
     assert raw == " the heart is normal . there is no pleural effusion , 's"
+
+
+# ------------------------------------------------------------------------- detector targets / losses (torchvision 0.13.1 semantics)
+def test_matcher_thresholds_ties_and_low_quality_hand_case():
+    gt = torch.tensor([[0., 0., 10., 10.], [20., 20., 40., 40.]])
+    bx = torch.tensor([[0., 0., 10., 10.], [0., 0., 10., 5.], [21., 21., 39., 39.], [100., 100., 110., 110.], [0., 0., 7., 10.]])
+    iou = tv013.box_iou(gt, bx)
+    assert torch.allclose(iou[0], torch.tensor([1.0, 0.5, 0.0, 0.0, 0.7])) and abs(float(iou[1, 2]) - 0.81) < 1e-6
+    # fg 0.7 / bg 0.3: box 1 (IoU 0.5) falls between the thresholds, box 3 below; 0.7 itself is foreground (>=)
+    assert tv013.matcher(iou.clone(), 0.7, 0.3, False).tolist() == [0, -2, 1, -1, 0]
+    # RoI heads: both thresholds 0.5 -> nothing "between", IoU 0.5 is foreground
+    assert tv013.matcher(iou.clone(), 0.5, 0.5, False).tolist() == [0, 0, 1, -1, 0]
+    # low-quality matches: gt 1's best box has IoU 0.4 (< 0.7) and is restored; so is every box TYING that maximum
+    gt2 = torch.tensor([[0., 0., 10., 10.]])
+    bx2 = torch.tensor([[0., 0., 10., 4.], [0., 6., 10., 10.], [0., 0., 1., 1.]])
+    q = tv013.box_iou(gt2, bx2)
+    assert tv013.matcher(q.clone(), 0.7, 0.3, False).tolist() == [-2, -2, -1]
+    assert tv013.matcher(q.clone(), 0.7, 0.3, True).tolist() == [0, 0, -1]
+
+
+def test_box_encode_inverts_box_decode_and_hand_values():
+    props = torch.tensor([[10., 20., 50., 100.], [0., 0., 8., 8.]])
+    ref = torch.tensor([[12., 25., 60., 90.], [0., 0., 8., 8.]])
+    for w in ((1.0, 1.0, 1.0, 1.0), (10.0, 10.0, 5.0, 5.0)):
+        d = tv013.box_encode(ref, props, w)
+        assert torch.allclose(tv013.box_decode(d, props, w).reshape(-1, 4), ref, atol=1e-4)
+    d = tv013.box_encode(ref, props, (10.0, 10.0, 5.0, 5.0))
+    assert torch.allclose(d[0], torch.tensor([10 * (36 - 30) / 40, 10 * (57.5 - 60) / 80, 5 * math.log(48 / 40), 5 * math.log(65 / 80)]), atol=1e-5)
+    assert float(d[1].abs().max()) == 0.0
+
+
+def test_balanced_sampler_counts_and_injected_draws():
+    labels = torch.tensor([1, 0, 0, -1, 3, 0, 0, 0, 2, 0])
+    ident = lambda n, tag: torch.arange(n)  # noqa: E731
+    p, n = tv013.balanced_sample(labels, 4, 0.5, ident, "t")
+    assert p.tolist() == [0, 4] and n.tolist() == [1, 2]                 # 2 of 3 positives, 4 - 2 negatives, ignored (-1) never
+    p, n = tv013.balanced_sample(labels, 512, 0.25, ident, "t")
+    assert p.tolist() == [0, 4, 8] and n.tolist() == [1, 2, 5, 6, 7, 9]  # fewer candidates than the quota: all of them
+    rev = lambda n, tag: torch.arange(n - 1, -1, -1)  # noqa: E731
+    p, n = tv013.balanced_sample(labels, 4, 0.5, rev, "t")
+    assert p.tolist() == [8, 4] and n.tolist() == [9, 7]
+
+
+def test_fastrcnn_and_rpn_loss_hand_values():
+    logits = torch.tensor([[2.0, 0.0, 0.0], [0.0, 3.0, 0.0]])
+    boxreg = torch.zeros((2, 12))
+    boxreg[1, 4:8] = torch.tensor([0.05, -0.05, 1.0, 0.0])
+    cls, box = tv013.fastrcnn_loss(logits, boxreg, [torch.tensor([0, 1])], [torch.zeros((2, 4))])
+    want = 0.5 * (math.log(math.exp(2) + 2) - 2 + math.log(math.exp(3) + 2) - 3)
+    assert abs(float(cls) - want) < 1e-6
+    beta = 1 / 9   # smooth L1: 0.5 d^2 / beta below beta, |d| - beta / 2 above; only the positive row's OWN class counts; / N
+    assert abs(float(box) - (2 * 0.5 * 0.05 ** 2 / beta + (1.0 - beta / 2)) / 2) < 1e-6
+    anchors = torch.tensor([[0., 0., 10., 10.], [0., 0., 10., 4.], [50., 50., 60., 60.]])
+    obj = torch.tensor([[2.0], [0.5], [-1.0]])
+    deltas = torch.zeros((3, 4))
+    t = [{"boxes": torch.tensor([[0., 0., 10., 10.]]), "labels": torch.tensor([1])}]
+    lo, lb = tv013.rpn_targets_and_loss(obj, deltas, anchors, t, lambda n, tag: torch.arange(n))
+    # anchor 0 positive (IoU 1), anchor 1 between (0.4: ignored), anchor 2 negative; exact match -> zero box loss
+    want = 0.5 * (math.log1p(math.exp(-2.0)) + math.log1p(math.exp(-1.0)))
+    assert abs(float(lo) - want) < 1e-6 and float(lb) == 0.0
