@@ -362,28 +362,32 @@ def balanced_sample(labels: Tensor, batch_size_per_image: int, positive_fraction
     return positive[perm1], negative[perm2]
 
 
-def rpn_targets_and_loss(objectness: Tensor, pred_bbox_deltas: Tensor, anchors: Tensor, targets, perm_fn=default_perm):
-    """RegionProposalNetwork.assign_targets_to_anchors + box_coder.encode + compute_loss (rpn.py), configured as
-    object_detector.py:84-96: fg 0.7 / bg 0.3 with low-quality matches, 256 anchors per image, half positive.
-    objectness [B*A,1], pred_bbox_deltas [B*A,4] (image-major), anchors [A,4] (the same grid for every image)."""
-    labels, reg_targets, pos_all, neg_all = [], [], [], []
-    A = anchors.shape[0]
-    for i, t in enumerate(targets):
+def assign_targets_to_anchors(anchors: List[Tensor], targets) -> Tuple[List[Tensor], List[Tensor]]:
+    """RegionProposalNetwork.assign_targets_to_anchors, fg 0.7 / bg 0.3 with low-quality matches (object_detector.py:87-88)."""
+    labels, matched_gt_boxes = [], []
+    for anc, t in zip(anchors, targets):
         gt = t["boxes"].to(torch.float32)
         if gt.numel() == 0:
-            matched_gt = torch.zeros_like(anchors)
-            lab = torch.zeros((A,), dtype=torch.float32)
-        else:
-            m = matcher(box_iou(gt, anchors), 0.7, 0.3, True)
-            matched_gt = gt[m.clamp(min=0)]
-            lab = (m >= 0).to(torch.float32)
-            lab[m == BELOW_LOW_THRESHOLD] = 0.0
-            lab[m == BETWEEN_THRESHOLDS] = -1.0
+            matched_gt_boxes.append(torch.zeros_like(anc))
+            labels.append(torch.zeros((anc.shape[0],), dtype=torch.float32))
+            continue
+        m = matcher(box_iou(gt, anc), 0.7, 0.3, True)
+        matched_gt_boxes.append(gt[m.clamp(min=0)])
+        lab = (m >= 0).to(torch.float32)
+        lab[m == BELOW_LOW_THRESHOLD] = 0.0
+        lab[m == BETWEEN_THRESHOLDS] = -1.0
         labels.append(lab)
-        reg_targets.append(box_encode(matched_gt, anchors, (1.0, 1.0, 1.0, 1.0)))
+    return labels, matched_gt_boxes
+
+
+def rpn_compute_loss(objectness: Tensor, pred_bbox_deltas: Tensor, labels: List[Tensor], regression_targets: List[Tensor],
+                     perm_fn=default_perm):
+    """RegionProposalNetwork.compute_loss: 256 anchors per image, half positive (object_detector.py:89-90)."""
+    pos_all, neg_all = [], []
+    for i, lab in enumerate(labels):
         p, n = balanced_sample(lab, 256, 0.5, perm_fn, ("rpn", i))
-        pos_mask = torch.zeros((A,), dtype=torch.bool)
-        neg_mask = torch.zeros((A,), dtype=torch.bool)
+        pos_mask = torch.zeros_like(lab, dtype=torch.bool)
+        neg_mask = torch.zeros_like(lab, dtype=torch.bool)
         pos_mask[p] = True
         neg_mask[n] = True
         pos_all.append(pos_mask)
@@ -393,10 +397,18 @@ def rpn_targets_and_loss(objectness: Tensor, pred_bbox_deltas: Tensor, anchors: 
     sampled = torch.cat([sampled_pos, sampled_neg])
     obj = objectness.flatten()
     lab = torch.cat(labels)
-    reg = torch.cat(reg_targets)
+    reg = torch.cat(regression_targets)
     box_loss = F.smooth_l1_loss(pred_bbox_deltas[sampled_pos], reg[sampled_pos], beta=1 / 9, reduction="sum") / sampled.numel()
     obj_loss = F.binary_cross_entropy_with_logits(obj[sampled], lab[sampled])
     return obj_loss, box_loss
+
+
+def rpn_targets_and_loss(objectness: Tensor, pred_bbox_deltas: Tensor, anchors: Tensor, targets, perm_fn=default_perm):
+    """assign_targets_to_anchors + box_coder.encode (weights 1,1,1,1) + compute_loss, as custom_rpn.py:74-83 chains them.
+    objectness [B*A,1], pred_bbox_deltas [B*A,4] (image-major), anchors [A,4] (the same grid for every image)."""
+    labels, matched = assign_targets_to_anchors([anchors] * len(targets), targets)
+    reg_targets = [box_encode(m, anchors, (1.0, 1.0, 1.0, 1.0)) for m in matched]
+    return rpn_compute_loss(objectness, pred_bbox_deltas, labels, reg_targets, perm_fn)
 
 
 def select_training_samples(proposals: List[Tensor], targets, perm_fn=default_perm):

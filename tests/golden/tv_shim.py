@@ -112,9 +112,15 @@ def concat_box_prediction_layers(box_cls, box_regression):
     return torch.cat(cls, dim=1).flatten(0, -2), torch.cat(reg, dim=1).reshape(-1, 4)
 
 
+PERM_FN = tv013.default_perm  # the samplers' draws (torch.randperm in torchvision); fixture scripts inject a seeded one
+
+
 class _BoxCoder:
     def __init__(self, weights):
         self.weights = weights
+
+    def encode(self, reference_boxes, proposals):
+        return tuple(tv013.box_encode(r, p, self.weights) for r, p in zip(reference_boxes, proposals))
 
     def decode(self, rel_codes, boxes):
         concat = torch.cat(list(boxes), dim=0)
@@ -131,6 +137,12 @@ class RegionProposalNetwork(nn.Module):
         self.box_coder = _BoxCoder((1.0, 1.0, 1.0, 1.0))
         self._pre, self._post = pre_nms_top_n, post_nms_top_n
         self.nms_thresh, self.score_thresh, self.min_size = nms_thresh, score_thresh, 1e-3
+
+    def assign_targets_to_anchors(self, anchors, targets):
+        return tv013.assign_targets_to_anchors(anchors, targets)
+
+    def compute_loss(self, objectness, pred_bbox_deltas, labels, regression_targets):
+        return tv013.rpn_compute_loss(objectness, pred_bbox_deltas, labels, list(regression_targets), PERM_FN)
 
     def filter_proposals(self, proposals, objectness, image_shapes, num_anchors_per_level):
         assert not self.training
@@ -187,9 +199,13 @@ class RoIHeads(nn.Module):
         self.box_coder = _BoxCoder(bbox_reg_weights)
         self.box_roi_pool, self.box_head, self.box_predictor = box_roi_pool, box_head, box_predictor
 
+    def select_training_samples(self, proposals, targets):
+        props, labels, reg = tv013.select_training_samples(proposals, targets, PERM_FN)
+        return props, None, labels, reg
 
-def fastrcnn_loss(*a, **k):
-    raise NotImplementedError("training path is out of scope for the golden fixtures")
+
+def fastrcnn_loss(class_logits, box_regression, labels, regression_targets):
+    return tv013.fastrcnn_loss(class_logits, box_regression, labels, regression_targets)
 
 
 def install():

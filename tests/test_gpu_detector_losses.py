@@ -7,7 +7,7 @@ import ctypes as C
 import pytest
 import torch
 
-from conftest import gpu_model, synth_sd
+from conftest import gpu_model, load_golden, synth_sd
 from oracle import detector as o_det
 from oracle import full_model as o_full
 from oracle import tv013
@@ -136,3 +136,29 @@ def test_full_model_eval_forward_accepts_image_targets_like_the_validation_loop(
     assert torch.equal(cd.cpu(), ref[5]) and torch.equal(sel.cpu(), ref[6]) and torch.equal(pred_abn.cpu(), ref[7])
     assert abs(float(l_sel) - float(ref[1])) <= 1e-4 and abs(float(l_abn) - float(ref[2])) <= 1e-4
     assert abs(float(l_lm) - float(ref[3])) <= 5e-4 * max(1.0, abs(float(ref[3])))
+
+
+def test_full_model_eval_forward_with_targets_matches_reference_fixture():
+    """The same call against the fixture generated by the REAL reference (tests/golden/make_golden_forward_targets.py)."""
+    fx = load_golden("forward_eval_targets_b2.pt")
+    m = gpu_model(fx["meta"]["profile"])
+    images = torch.cat([synth.make_images(1, s) for s in fx["meta"]["image_seeds"]], 0)
+    i, e = fx["inputs"], fx["expected"]
+    m.object_detector.sampler_perm = _perm(fx["meta"]["perm_seed"])
+    was = m.pretrain_without_lm_model
+    m.pretrain_without_lm_model = False
+    try:
+        out = m(images.to(DEV), [{k: v.to(DEV) for k, v in t.items()} for t in i["targets"]], i["input_ids"].to(DEV),
+                i["attention_mask"].to(DEV), i["region_has_sentence"].to(DEV), i["region_is_abnormal"].to(DEV))
+    finally:
+        m.object_detector.sampler_perm = None
+        m.pretrain_without_lm_model = was
+    assert list(out[0]) == list(e["obj_detector_loss_dict"])
+    for k, v in e["obj_detector_loss_dict"].items():
+        assert abs(float(out[0][k]) - float(v)) <= 5e-4 * max(1.0, abs(float(v))), k
+    assert abs(float(out[1]) - float(e["classifier_loss_region_selection"])) <= 1e-4
+    assert abs(float(out[2]) - float(e["classifier_loss_region_abnormal"])) <= 1e-4
+    assert abs(float(out[3]) - float(e["language_model_loss"])) <= 5e-4 * float(e["language_model_loss"])
+    assert torch.equal(out[5].cpu(), e["class_detected"]) and torch.equal(out[6].cpu(), e["selected_regions"])
+    assert torch.equal(out[7].cpu(), e["predicted_abnormal_regions"])
+    assert (out[4]["top_region_boxes"].cpu() - e["top_region_boxes"])[e["class_detected"]].abs().max() <= 5e-2

@@ -129,3 +129,24 @@ def test_eval_forward_oracle_matches_reference(sd_ragged):
     assert torch.equal(out[5], e["class_detected"]) and torch.equal(out[6], e["selected_regions"])
     assert torch.equal(out[7], e["predicted_abnormal_regions"])
     assert torch.equal(out[4]["top_region_boxes"], e["top_region_boxes"])
+
+
+def test_eval_forward_with_image_targets_oracle_matches_reference(sd_bench):
+    """ReportGenerationModel.forward(images, image_targets, ...) in eval mode - the validation loop's call
+    (evaluate_model.py:413) - of the REAL reference vs the restatement, with the samplers' draws injected
+    (tests/golden/make_golden_forward_targets.py)."""
+    fx = load_golden("forward_eval_targets_b2.pt")
+    assert fx["meta"]["oracle_matches_reference"] is True
+    images = torch.cat([synth.make_images(1, s) for s in fx["meta"]["image_seeds"]], 0)
+    i, e = fx["inputs"], fx["expected"]
+    g = torch.Generator().manual_seed(fx["meta"]["perm_seed"])
+    out = o_full.forward_eval(sd_bench, images, i["input_ids"].clone(), i["attention_mask"], i["region_has_sentence"],
+                              i["region_is_abnormal"], image_targets=i["targets"], perm_fn=lambda n, tag: torch.randperm(n, generator=g))
+    assert list(out[0]) == list(e["obj_detector_loss_dict"]) == ["loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg"]
+    for k, v in e["obj_detector_loss_dict"].items():
+        assert abs(out[0][k].item() - v.item()) <= 1e-6, k
+    for got, key in ((out[1], "classifier_loss_region_selection"), (out[2], "classifier_loss_region_abnormal"),
+                     (out[3], "language_model_loss")):
+        assert abs(got.item() - e[key].item()) <= 1e-5, key
+    assert torch.equal(out[5], e["class_detected"]) and torch.equal(out[6], e["selected_regions"])
+    assert torch.equal(out[7], e["predicted_abnormal_regions"]) and torch.equal(out[4]["top_region_boxes"], e["top_region_boxes"])
