@@ -995,12 +995,20 @@ __global__ __launch_bounds__(256) void beam_init_kernel(int* __restrict__ src, i
 // ------------------------------------------------------------------ teacher-forced pass (LanguageModel.forward, no cache)
 // x[s,t] = wte[ids[s,t]] + wte[t] (position_ids default to arange(T) and are embedded with wte, language_model.py:298-307),
 // xn = ln_1 of layer 0.  One workgroup per token row.
+// Token ids are validated HERE (no host round trip before the launch): an id outside [0, V) is clamped, so nothing is
+// read out of bounds, and raises the decoder's device-side error word; the loss of that pass comes out as NaN and the
+// next decoder call reports the error (torch.nn.Embedding raises IndexError synchronously on the CPU / asserts on the GPU).
 __global__ __launch_bounds__(256) void embed_seq_ln_kernel(const float* __restrict__ wte, const long long* __restrict__ ids,
                                                            int T, const float* __restrict__ g, const float* __restrict__ b,
-                                                           float* __restrict__ x, float* __restrict__ xn, int D) {
+                                                           float* __restrict__ x, float* __restrict__ xn, int D, int V,
+                                                           int* __restrict__ id_error) {
     __shared__ float sh[4];
     const int row = blockIdx.x, tid = threadIdx.x;
-    const long long tok = ids[row];
+    long long tok = ids[row];
+    if (tok < 0 || tok >= V) {
+        if (tid == 0) atomicOr(id_error, 1);
+        tok = tok < 0 ? 0 : V - 1;
+    }
     const int pos = row % T;
     const f32x4 v = reinterpret_cast<const f32x4*>(wte + (size_t)tok * D)[tid] + reinterpret_cast<const f32x4*>(wte + (size_t)pos * D)[tid];
     reinterpret_cast<f32x4*>(x + (size_t)row * D)[tid] = v;
@@ -1172,7 +1180,8 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
 
 // mean over the scored rows in a fixed order (double accumulation); no scored row -> nan, like torch
 __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restrict__ row_loss, const int* __restrict__ row_valid,
-                                                          int n, float* __restrict__ loss, int* __restrict__ n_scored = nullptr) {
+                                                          int n, float* __restrict__ loss, int* __restrict__ n_scored = nullptr,
+                                                          const int* __restrict__ id_error = nullptr) {
     __shared__ double ssum[256];
     __shared__ int scnt[256];
     double a = 0.0;
@@ -1186,7 +1195,7 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restric
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        if (loss) *loss = (float)(ssum[0] / (double)scnt[0]);
+        if (loss) *loss = (id_error && *id_error) ? nanf("") : (float)(ssum[0] / (double)scnt[0]);  // invalid token id: poisoned
         if (n_scored) *n_scored = scnt[0];
     }
 }
@@ -1249,6 +1258,8 @@ struct rgrg_decoder {
     int *src_a, *src_b, *beam_tok, *beam_parent, *cand_tok, *cand_beam, *top_tok;
     float *beam_scores, *row_max, *row_logsum, *top_val, *cand_score;
     int* h_done;  // pinned
+    int* id_error = nullptr;    // device: set by the teacher-forced embedding when a token id is outside [0, vocab)
+    int* h_id_error = nullptr;  // pinned mirror, copied back asynchronously at the end of a pass, checked by the next call
     hipStream_t stream;
     hipEvent_t ev_in;
     std::vector<GraphEntry> graphs;
@@ -1633,6 +1644,7 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
         delete d;
         return RGRG_EHIP;
     }
+    if (hipHostMalloc((void**)&d->h_id_error, sizeof(int), 0) == hipSuccess) *d->h_id_error = 0;
     if (hipHostMalloc((void**)&d->h_done, sizeof(int), 0) != hipSuccess) {
         set_error("decoder: hipHostMalloc failed");
         delete d;
@@ -1676,6 +1688,7 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     TRY(dmalloc(d, (void**)&d->step, 4, true));
     TRY(dmalloc(d, (void**)&d->done_len, 4, true));
     TRY(dmalloc(d, (void**)&d->sync, 64, true));
+    TRY(dmalloc(d, (void**)&d->id_error, 4, true));
     TRY(dmalloc(d, (void**)&d->cand_val, R * d->lm_head.NT * 4, true));
     TRY(dmalloc(d, (void**)&d->cand_idx, R * d->lm_head.NT * 4, true));
     TRY(dmalloc(d, (void**)&d->src_a, R * d->T * 4, true));
@@ -1715,6 +1728,7 @@ extern "C" void rgrg_decoder_destroy(rgrg_decoder* d) {
     tf_free(d);
     tr_free(d);
     if (d->h_done) (void)hipHostFree(d->h_done);
+    if (d->h_id_error) (void)hipHostFree(d->h_id_error);
     if (d->ev_in) (void)hipEventDestroy(d->ev_in);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
@@ -1936,6 +1950,16 @@ extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int
 
 // ------------------------------------------------------------------ teacher-forced pass (host side)
 namespace rgrg {
+// A previous teacher-forced pass saw a token id outside [0, vocab): report it now (its loss was NaN), clear the flag
+static int check_id_error(rgrg_decoder* d) {
+    if (d->h_id_error && *d->h_id_error) {
+        *d->h_id_error = 0;
+        (void)hipMemsetAsync(d->id_error, 0, sizeof(int), d->stream);
+        set_error("index out of range in self: a token id of the previous teacher-forced pass was outside [0, %d)", d->V);
+        return RGRG_EINVAL;
+    }
+    return RGRG_OK;
+}
 constexpr int TF_LOGIT_ROWS = 2048;  // lm_head + cross entropy run over chunks of this many token rows (412 MB of logits)
 
 static void tf_free(rgrg_decoder* d) {
@@ -1980,8 +2004,9 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
     RGRG_CHECK_ARG(d && feats && input_ids && S > 0 && S <= d->max_seqs && T >= 1 && T <= TF_MAX_T && (logits_out || loss_out));
     RGRG_CHECK_ARG(!loss_out || T >= 2);
     const int D = d->D, M = S * T;
-    int rc = tf_reserve(d, (size_t)M);
+    int rc = check_id_error(d);
     if (rc) return rc;
+    if ((rc = tf_reserve(d, (size_t)M))) return rc;
     hipStream_t caller = as_stream(stream), st = d->stream;
     RGRG_HIP(hipEventRecord(d->ev_in, caller));
     RGRG_HIP(hipStreamWaitEvent(st, d->ev_in, 0));
@@ -1992,7 +2017,7 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
     if ((rc = linear(d, d->ukv, d->img, nullptr, d->ukv_out, S, d->ld_ukv, RGRG_ACT_NONE, false))) return rc;
     const long long* ids = reinterpret_cast<const long long*>(input_ids);
     hipLaunchKernelGGL(embed_seq_ln_kernel, dim3(M), dim3(256), 0, st, d->wte, ids, T, d->layers[0].ln1_g, d->layers[0].ln1_b,
-                       d->tf_x, d->tf_xn, D);
+                       d->tf_x, d->tf_xn, D, d->V, d->id_error);
     RGRG_LAUNCH_CHECK();
     for (int l = 0; l < d->n_layer; ++l) {
         const LayerW& w = d->layers[l];
@@ -2029,9 +2054,11 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
         }
     }
     if (loss_out) {
-        hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, d->tf_row_loss, d->tf_row_valid, M, loss_out);
+        hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, d->tf_row_loss, d->tf_row_valid, M, loss_out, (int*)nullptr,
+                           d->id_error);
         RGRG_LAUNCH_CHECK();
     }
+    RGRG_HIP(hipMemcpyAsync(d->h_id_error, d->id_error, sizeof(int), hipMemcpyDeviceToHost, st));
     // the caller's stream continues after this pass (no host synchronisation)
     RGRG_HIP(hipEventRecord(d->ev_in, st));
     RGRG_HIP(hipStreamWaitEvent(caller, d->ev_in, 0));
@@ -2153,6 +2180,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
     RGRG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || T + 1 <= 160));  // dropout: matrix-core attention only
     const int D = d->D, M = S * T, L = d->n_layer, V = d->V, VP = pad256(V), Sp = pad32(S), LD = d->ld_ukv;
     int rc;
+    if ((rc = check_id_error(d))) return rc;
     if ((rc = tf_reserve(d, (size_t)M)) || (rc = tr_reserve(d, (size_t)M, (size_t)S))) return rc;
     hipStream_t caller = as_stream(stream), st = d->stream;
     RGRG_HIP(hipEventRecord(d->ev_in, caller));
@@ -2168,7 +2196,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
     if ((rc = linear(d, d->fst2, d->h1, nullptr, d->img, S, D, RGRG_ACT_NONE, false))) return rc;
     if ((rc = linear(d, d->ukv, d->img, nullptr, d->ukv_out, S, LD, RGRG_ACT_NONE, false))) return rc;
     hipLaunchKernelGGL(embed_seq_ln_kernel, dim3(M), dim3(256), 0, st, d->wte, ids, T, d->layers[0].ln1_g, d->layers[0].ln1_b,
-                       xs(0), d->tf_xn, D);
+                       xs(0), d->tf_xn, D, d->V, d->id_error);
     RGRG_LAUNCH_CHECK();
     if (dropout_p > 0.f) {  // self.drop on the embeddings (language_model.py:311), then ln_1 of layer 0 again
         if ((rc = launch_dropout_add(xs(0), nullptr, xs(0), MD, DropoutParams{dropout_seed, 0u, dropout_p}, st))) return rc;
@@ -2226,7 +2254,9 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
             return rc;
         if ((rc = tr_lin(d, d->lm_head, true, d->tr_logits, nullptr, d->tr_dxn + (size_t)r0 * D, rows, D))) return rc;
     }
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, d->tf_row_loss, d->tf_row_valid, M, loss_out, (int*)nullptr);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, d->tf_row_loss, d->tf_row_valid, M, loss_out, (int*)nullptr,
+                       d->id_error);
+    RGRG_HIP(hipMemcpyAsync(d->h_id_error, d->id_error, sizeof(int), hipMemcpyDeviceToHost, st));
     RGRG_LAUNCH_CHECK();
     // ---------------- backward through ln_f and the 24 frozen blocks (activation gradients only)
     if ((rc = launch_ln_backward(d->tr_dxn, xs(2 * L), d->lnf_g, d->tr_dx, M, D, 0, st))) return rc;

@@ -659,6 +659,18 @@ class HipEngine:
                    "rgrg_decoder_beam_search")
         return out[:, :out_len.value].contiguous()
 
+    @staticmethod
+    def _check_ids(rc: int, what: str) -> None:
+        """Token ids are validated on the device: an out-of-range id poisons that pass's loss (NaN) and is reported by
+        the NEXT decoder call as torch.nn.Embedding's IndexError (the reference fails in the same call; checking there
+        would cost a device-to-host round trip per call)."""
+        try:
+            _hip.check(rc, what)
+        except _hip.RgrgHipError as e:
+            if "index out of range in self" in str(e):
+                raise IndexError(str(e)) from None
+            raise
+
     def lm_forward(self, feats: Tensor, input_ids: Tensor, attention_mask: Optional[Tensor], want_logits: bool = False,
                    want_loss: bool = True, bf16: bool = False) -> Tuple[Optional[Tensor], Optional[Tensor]]:
         """LanguageModel.forward without cache (teacher forcing): feats [S,1024], input_ids int64 [S,T],
@@ -669,9 +681,7 @@ class HipEngine:
             raise ValueError(f"image_hidden_states has {feats.shape[0]} rows, input_ids {S}")
         if T > 255:
             raise NotImplementedError("the HIP teacher-forced pass supports sequences of up to 255 tokens")
-        lo, hi = int(input_ids.min().item()), int(input_ids.max().item())
-        if lo < 0 or hi >= self.vocab:
-            raise IndexError("index out of range in self")  # torch.nn.Embedding's error
+        # token ids are range-checked on the device (no host sync here): see embed_seq_ln_kernel
         dec = self._get_decoder(S, 2)
         _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")
         feats = feats.to(torch.float32).contiguous()
@@ -679,10 +689,10 @@ class HipEngine:
         am = None if attention_mask is None else attention_mask.to(torch.float32).contiguous()
         logits = torch.empty((S, T, self.vocab), dtype=torch.float32, device=feats.device) if want_logits else None
         loss = torch.empty((), dtype=torch.float32, device=feats.device) if want_loss else None
-        _hip.check(self.lib.rgrg_decoder_lm_forward(dec, _hip.ptr(feats), _hip.ptr(ids), None if am is None else _hip.ptr(am),
-                                                    S, T, None if logits is None else _hip.ptr(logits),
-                                                    None if loss is None else _hip.ptr(loss), self._s()),
-                   "rgrg_decoder_lm_forward")
+        self._check_ids(self.lib.rgrg_decoder_lm_forward(dec, _hip.ptr(feats), _hip.ptr(ids), None if am is None else _hip.ptr(am),
+                                                         S, T, None if logits is None else _hip.ptr(logits),
+                                                         None if loss is None else _hip.ptr(loss), self._s()),
+                        "rgrg_decoder_lm_forward")
         return logits, loss
 
     def lm_loss_grad(self, feats: Tensor, input_ids: Tensor, attention_mask: Optional[Tensor], loss_scale: float = 1.0,
@@ -697,9 +707,7 @@ class HipEngine:
             raise ValueError(f"image_hidden_states has {feats.shape[0]} rows, input_ids {S}")
         if T > 160 or (dropout_p > 0 and T > 159):
             raise NotImplementedError("the HIP training pass supports sequences of up to 160 tokens (159 with dropout)")
-        lo, hi = int(input_ids.min().item()), int(input_ids.max().item())
-        if lo < 0 or hi >= self.vocab:
-            raise IndexError("index out of range in self")
+        # token ids are range-checked on the device (no host sync here): see embed_seq_ln_kernel
         dec = self._get_decoder(S, 2)
         _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")
         feats = feats.detach().to(torch.float32).contiguous()
@@ -710,11 +718,11 @@ class HipEngine:
              "fst0_w": torch.empty((1024, 1024), dtype=torch.float32, device=dev), "fst0_b": torch.empty((1024,), dtype=torch.float32, device=dev),
              "fst2_w": torch.empty((1024, 1024), dtype=torch.float32, device=dev), "fst2_b": torch.empty((1024,), dtype=torch.float32, device=dev)}
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        _hip.check(self.lib.rgrg_decoder_lm_loss_grad(dec, _hip.ptr(feats), _hip.ptr(ids), None if am is None else _hip.ptr(am), S, T,
-                                                      float(loss_scale), float(dropout_p), int(dropout_seed) & (2 ** 64 - 1), _hip.ptr(loss),
-                                                      _hip.ptr(g["ukv_w"]), _hip.ptr(g["ukv_b"]),
-                                                      _hip.ptr(g["fst0_w"]), _hip.ptr(g["fst0_b"]), _hip.ptr(g["fst2_w"]),
-                                                      _hip.ptr(g["fst2_b"]), self._s()), "rgrg_decoder_lm_loss_grad")
+        self._check_ids(self.lib.rgrg_decoder_lm_loss_grad(dec, _hip.ptr(feats), _hip.ptr(ids), None if am is None else _hip.ptr(am), S, T,
+                                                           float(loss_scale), float(dropout_p), int(dropout_seed) & (2 ** 64 - 1), _hip.ptr(loss),
+                                                           _hip.ptr(g["ukv_w"]), _hip.ptr(g["ukv_b"]),
+                                                           _hip.ptr(g["fst0_w"]), _hip.ptr(g["fst0_b"]), _hip.ptr(g["fst2_w"]),
+                                                           _hip.ptr(g["fst2_b"]), self._s()), "rgrg_decoder_lm_loss_grad")
         return loss, g
 
     def dropout_mask(self, seed: int, layer: int, site: int, p: float, shape) -> Tensor:

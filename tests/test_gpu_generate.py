@@ -633,3 +633,23 @@ def test_lm_training_pass_with_dropout_matches_oracle_with_the_same_masks():
     loss2 = lm(ids.clone().to(DEV), am.to(DEV), feats.to(DEV), return_loss=True)
     assert loss2.item() != loss.item()
     m.invalidate_engine()
+
+
+def test_teacher_forced_pass_validates_token_ids_on_the_device():
+    """No host round trip before the launch: an id outside [0, vocab) gives a NaN loss for that call (nothing is read out
+    of bounds) and the next decoder call raises torch.nn.Embedding's IndexError; the call after that works again."""
+    eng = gpu_model("ragged").engine()
+    g = torch.Generator().manual_seed(1)
+    feats = torch.randn((3, 1024), generator=g).to(DEV)
+    ids = torch.randint(0, 50000, (3, 9), generator=g).to(DEV)
+    mask = torch.ones((3, 9), device=DEV)
+    _, good = eng.lm_forward(feats, ids, mask)
+    bad_ids = ids.clone()
+    bad_ids[1, 4] = 60000
+    _, bad = eng.lm_forward(feats, bad_ids, mask)
+    torch.cuda.synchronize()
+    assert torch.isnan(bad) and torch.isfinite(good)
+    with pytest.raises(IndexError):
+        eng.lm_forward(feats, ids, mask)
+    _, again = eng.lm_forward(feats, ids, mask)
+    assert torch.equal(again, good)
