@@ -165,15 +165,16 @@ void rgrg_decoder_destroy(rgrg_decoder* d);
 int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S, int max_length, int64_t* out_ids,
                           int out_ld, int* out_len, int use_graph, void* stream);
 /* Beam search (LanguageModel.generate num_beams > 1 -> beam_search, language_model.py:450-475,
- * :529-607, with transformers 4.19.2 BeamSearchScorer semantics, num_return_sequences = 1).
+ * :529-607, with transformers 4.19.2 BeamSearchScorer semantics; 1 <= num_return_sequences <= num_beams).
  * The decoder must have been created with max_seqs >= S*num_beams; 2*num_beams <= 16.
  * Device side: one decode step over the S*num_beams beam rows (KV cache never re-ordered:
  * per-slot ancestor table), per-row log-sum-exp + top-2*num_beams, per-item merge.  Host
  * side (one small D2H/H2D per step, like the reference's scorer): hypothesis bookkeeping.
- * out_ids int64 [S, out_ld] receives the best hypothesis per item, *out_len its padded length. */
+ * out_ids int64 [S * num_return_sequences, out_ld] receives the best hypotheses of every item (best first),
+ * *out_len their padded length. */
 int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int S, int num_beams, int max_length,
-                             int early_stopping, float length_penalty, int64_t* out_ids, int out_ld, int* out_len,
-                             void* stream);
+                             int early_stopping, float length_penalty, int num_return_sequences, int64_t* out_ids,
+                             int out_ld, int* out_len, void* stream);
 /* Opt-in reduced precision for MANY sequences (BASELINE configs[2], batch 32): bf16_gemms = 1 makes the
  * > 128-row paths run their projections on the bf16 MFMA (bf16 weights, activations rounded to bf16 in LDS,
  * fp32 accumulate / LayerNorm / softmax / residual) and keep the decode K/V cache in bf16 (what the reference's
@@ -186,7 +187,8 @@ int rgrg_decoder_set_precision(rgrg_decoder* d, int bf16_gemms);
  * pseudo self-attention without cache (image key/value first, future columns -1e4, additive padding mask
  * (1 - [1|attention_mask]) * -10000, :84-160,:325-334), final LayerNorm, lm_head.
  *   feats [S,1024] f32, input_ids [S,T] int64 (every id in [0, vocab)), attention_mask [S,T] f32 or NULL (= ones),
- *   S <= max_seqs of the decoder, T <= 255.
+ *   S <= max_seqs of the decoder, T <= 1023 (T + 1 keys <= GPT-2's 1024 positions; beyond 256 keys the attention
+ *   recomputes its score tiles instead of holding them in registers).
  *   logits_out: NULL or f32 [S,T,vocab] (return_loss=False);
  *   loss_out:   NULL or one f32 = CrossEntropyLoss(ignore_index=-100) of logits[:, :-1] against input_ids[:, 1:]
  *               with the labels of attention_mask == 0 positions ignored (:368-396); nan when no label is scored.

@@ -21,6 +21,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -1029,7 +1030,7 @@ __global__ __launch_bounds__(256) void embed_seq_ln_kernel(const float* __restri
 //     the MFMA as is, next to A = V[key(j, lane half)][dim], a coalesced 128-byte row read.  No transpose.
 // Key tiles entirely in the future of the query tile are skipped: their weights are exp(-1e4 - max) = 0 in fp32
 // because the never-masked image column keeps max = O(1).  Keys beyond T (tile padding) get -inf.
-constexpr int TF_MAX_T = 255;
+constexpr int TF_MAX_T = 1023;  // T + 1 keys <= the 1024 positions of GPT-2's causal-mask buffer (the reference's limit)
 template <int NT>  // key tiles held in registers: T + 1 <= 32 * NT
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
                                                            int kcol, const float* __restrict__ am, float* __restrict__ out,
@@ -1140,6 +1141,126 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
             op[32 + dim] = o1[r];
         }
     }
+}
+
+// T + 1 > 256 keys (up to the reference's 1024 positions, language_model.py:60-67): the score tiles no longer fit in
+// registers, so they are RECOMPUTED - pass 1 row max, pass 2 row sum, pass 3 probabilities x V - in the same tile and
+// register order as attn_prefill_kernel, which makes the two kernels bit-identical where both apply (tested).  3x the
+// score MFMAs of the register kernel; only long reports take this path.
+__global__ __launch_bounds__(256) void attn_prefill_stream_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
+                                                                  int kcol, const float* __restrict__ am, float* __restrict__ out,
+                                                                  int S, int H, int T, float* __restrict__ lse, const DropoutParams drop) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int QT = (T + 31) / 32;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= S * H * QT) return;
+    const int qt = item % QT, sh = item / QT, hd = sh % H, s = sh / H;
+    const int NK = T + 1, D = H * 64;
+    const int col = lane & 31, half = lane >> 5;
+    const int iq = qt * 32 + col;
+    const int need = min(NK - 1, qt * 32 + 32) / 32 + 1;
+    auto krow = [&](int c) -> const float* {
+        c = min(c, NK - 1);
+        return c == 0 ? ukv + (size_t)s * ld_ukv + kcol + hd * 64 : qkv + ((size_t)s * T + c - 1) * 3 * D + D + hd * 64;
+    };
+    f32x4 qf[8];
+    {
+        const float* qp = qkv + ((size_t)s * T + min(iq, T - 1)) * 3 * D + hd * 64 + half * 32;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) qf[u] = *reinterpret_cast<const f32x4*>(qp + 4 * u);
+    }
+    // masked, scaled scores of key tile kt for this lane's query (16 keys: rows (r&3) + 8*(r>>2) + 4*half of the tile)
+    auto tile_scores = [&](int kt) -> f32x16 {
+        f32x4 kf[8];
+        const float* kp = krow(kt * 32 + col) + half * 32;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) kf[u] = *reinterpret_cast<const f32x4*>(kp + 4 * u);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u][e], qf[u][e], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float w = -INFINITY;
+            if (c < NK) {
+                const bool allowed = (c == 0) || (c - 1 <= iq);
+                const float addm = (c == 0 || !am) ? 0.f : (1.0f - am[(size_t)s * T + c - 1]) * -10000.0f;
+                w = (allowed ? acc[r] / 8.0f : -1e4f) + addm;
+            }
+            acc[r] = w;
+        }
+        return acc;
+    };
+    float m = -INFINITY;
+    for (int kt = 0; kt < need; ++kt) {
+        const f32x16 w = tile_scores(kt);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, w[r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+    for (int kt = 0; kt < need; ++kt) {
+        const f32x16 w = tile_scores(kt);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += expf(w[r] - m);
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    if (lse && half == 0 && iq < T) lse[((size_t)s * T + iq) * H + hd] = m + logf(sum);
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    for (int kt = 0; kt < need; ++kt) {
+        const f32x16 w = tile_scores(kt);
+        float v0[16], v1[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float* vp = krow(kt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half) + D;
+            v0[j] = vp[col];
+            v1[j] = vp[32 + col];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float pj = expf(w[j] - m) / sum;
+            if (drop.p > 0.f)
+                pj *= dropout_mask(drop, (((unsigned long long)s * H + hd) * T + min(iq, T - 1)) * NK +
+                                             min(kt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half, NK - 1));
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[j], pj, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[j], pj, o1, 0, 0, 0);
+        }
+    }
+    if (iq < T) {
+        float* op = out + ((size_t)s * T + iq) * D + hd * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dim = (r & 3) + 8 * (r >> 2) + 4 * half;
+            op[dim] = o0[r];
+            op[32 + dim] = o1[r];
+        }
+    }
+}
+
+// RGRG_PREFILL_STREAM=1 forces the streaming kernel for every length (tests compare it with the register kernel)
+static bool prefill_stream_forced() {
+    static const bool v = [] { const char* e = getenv("RGRG_PREFILL_STREAM"); return e && atoi(e) != 0; }();
+    return v;
+}
+
+static int launch_attn_prefill(const float* qkv, const float* ukv, int ld_ukv, int kcol, const float* am, float* out, int S, int H,
+                               int T, float* lse, const DropoutParams& drop, hipStream_t st) {
+    const int items = S * H * ((T + 31) / 32);
+    const dim3 grid((items + 3) / 4), block(256);
+    if (T + 1 > 256 || prefill_stream_forced())
+        hipLaunchKernelGGL(attn_prefill_stream_kernel, grid, block, 0, st, qkv, ukv, ld_ukv, kcol, am, out, S, H, T, lse, drop);
+    else if (T + 1 <= 96)
+        hipLaunchKernelGGL(attn_prefill_kernel<3>, grid, block, 0, st, qkv, ukv, ld_ukv, kcol, am, out, S, H, T, lse, drop);
+    else
+        hipLaunchKernelGGL(attn_prefill_kernel<8>, grid, block, 0, st, qkv, ukv, ld_ukv, kcol, am, out, S, H, T, lse, drop);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
 }
 
 // CrossEntropyLoss(ignore_index=-100) on the shifted logits/labels (:368-396): the row of token (s,t), t < T-1, is
@@ -1631,6 +1752,9 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     int rc = init_gemm_attrs();
     if (rc) return rc;
     if ((rc = init_skinny_attrs())) return rc;
+    // The weights are packed below on the decoder's own non-blocking stream, and this entry point has no stream argument:
+    // wait for whatever is still producing them on the caller's streams (creation is rare and allocates GBs anyway).
+    RGRG_HIP(hipDeviceSynchronize());
     rgrg_decoder* d = new rgrg_decoder();
     d->n_layer = w->n_layer; d->D = w->d_model; d->H = w->n_head; d->V = w->vocab;
     d->max_seqs = max_seqs; d->max_len = max_len; d->T = max_len + 1;
@@ -1707,7 +1831,8 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     d->gemm_ws = nullptr;
     if (d->gemm_ws_floats) TRY(dmalloc(d, (void**)&d->gemm_ws, d->gemm_ws_floats * 4, false));
 #undef TRY
-    if (hipStreamSynchronize(d->stream) != hipSuccess) {
+    // packing (decoder stream) and the zero fills (null stream) are complete before the first use
+    if (hipDeviceSynchronize() != hipSuccess) {
         set_error("decoder: weight packing failed");
         rgrg_decoder_destroy(d);
         return RGRG_EHIP;
@@ -1820,9 +1945,10 @@ struct BeamHyps {
 }  // namespace rgrg
 
 extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int S, int num_beams, int max_length,
-                                        int early_stopping, float length_penalty, int64_t* out_ids, int out_ld,
-                                        int* out_len, void* stream) {
+                                        int early_stopping, float length_penalty, int num_return_sequences, int64_t* out_ids,
+                                        int out_ld, int* out_len, void* stream) {
     RGRG_CHECK_ARG(d && feats && out_ids && out_len && S > 0 && num_beams > 1 && 2 * num_beams <= BEAM_K);
+    RGRG_CHECK_ARG(num_return_sequences >= 1 && num_return_sequences <= num_beams);
     const int nb = num_beams, K = 2 * nb, R = S * nb;
     RGRG_CHECK_ARG(R <= d->max_seqs && max_length >= 2 && max_length <= d->max_len && out_ld >= max_length);
     hipStream_t st = d->stream;
@@ -1923,26 +2049,33 @@ extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int
         if (done[b]) continue;
         for (int j = 0; j < nb; ++j) hyps[b].add(ids[b * nb + j], (double)beam_scores[b * nb + j], nb, lp);
     }
-    std::vector<const std::vector<long long>*> best(S);
+    // num_beam_hyps_to_keep best hypotheses per item: sorted(beams, key=score) is stable and pop() takes the last, i.e.
+    // descending score and, among equal scores, the LATER-added hypothesis first
+    const int keep = num_return_sequences, NR = S * keep;
+    std::vector<const std::vector<long long>*> best(NR);
     int max_sent = 0, min_sent = 1 << 30;
     for (int b = 0; b < S; ++b) {
-        int j0 = 0;  // sorted(key=score) is stable and pop() takes the last: the LAST hypothesis among equal maxima
-        for (int j = 1; j < (int)hyps[b].beams.size(); ++j)
-            if (hyps[b].beams[j].score >= hyps[b].beams[j0].score) j0 = j;
-        best[b] = &hyps[b].beams[j0].toks;
-        const int len = (int)best[b]->size();
-        max_sent = len > max_sent ? len : max_sent;
-        min_sent = len < min_sent ? len : min_sent;
+        const int nh = (int)hyps[b].beams.size();
+        if (nh < keep) { set_error("beam search: item %d has %d finished hypotheses, %d requested", b, nh, keep); return RGRG_ESTATE; }
+        std::vector<int> order(nh);
+        for (int j = 0; j < nh; ++j) order[j] = j;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return hyps[b].beams[x].score < hyps[b].beams[y].score; });
+        for (int j = 0; j < keep; ++j) {
+            best[b * keep + j] = &hyps[b].beams[order[nh - 1 - j]].toks;
+            const int len = (int)best[b * keep + j]->size();
+            max_sent = len > max_sent ? len : max_sent;
+            min_sent = len < min_sent ? len : min_sent;
+        }
     }
     const int L = (max_sent + 1 < max_length) ? max_sent + 1 : max_length;
-    std::vector<long long> dec((size_t)S * L, PAD_ID);
-    for (int b = 0; b < S; ++b) {
+    std::vector<long long> dec((size_t)NR * L, PAD_ID);
+    for (int b = 0; b < NR; ++b) {
         const int len = (int)best[b]->size();
         for (int j = 0; j < len && j < L; ++j) dec[(size_t)b * L + j] = (*best[b])[j];
         if (len < max_length) dec[(size_t)b * L + len] = EOS_ID;
     }
     RGRG_HIP(hipMemcpy2DAsync(out_ids, (size_t)out_ld * sizeof(int64_t), dec.data(), (size_t)L * sizeof(long long),
-                              (size_t)L * sizeof(long long), S, hipMemcpyHostToDevice, st));
+                              (size_t)L * sizeof(long long), NR, hipMemcpyHostToDevice, st));
     RGRG_HIP(hipStreamSynchronize(st));
     *out_len = L;
     return RGRG_OK;
@@ -2024,16 +2157,9 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
         const float* ng = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_g : d->lnf_g;
         const float* nb = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_b : d->lnf_b;
         if ((rc = tf_linear(d, w.c_attn, d->tf_xn, nullptr, d->tf_qkv, M, 3 * D, RGRG_ACT_NONE))) return rc;
-        {
-            const int items = S * d->H * ((T + 31) / 32);
-            if (T + 1 <= 96)
-                hipLaunchKernelGGL(attn_prefill_kernel<3>, dim3((items + 3) / 4), dim3(256), 0, st, d->tf_qkv, d->ukv_out, d->ld_ukv,
-                                   l * 2 * D, attention_mask, d->tf_att, S, d->H, T, (float*)nullptr, DropoutParams{0ull, 0u, 0.f});
-            else
-                hipLaunchKernelGGL(attn_prefill_kernel<8>, dim3((items + 3) / 4), dim3(256), 0, st, d->tf_qkv, d->ukv_out, d->ld_ukv,
-                                   l * 2 * D, attention_mask, d->tf_att, S, d->H, T, (float*)nullptr, DropoutParams{0ull, 0u, 0.f});
-            RGRG_LAUNCH_CHECK();
-        }
+        if ((rc = launch_attn_prefill(d->tf_qkv, d->ukv_out, d->ld_ukv, l * 2 * D, attention_mask, d->tf_att, S, d->H, T, nullptr,
+                                      DropoutParams{0ull, 0u, 0.f}, st)))
+            return rc;
         if ((rc = tf_linear(d, w.attn_proj, d->tf_att, d->tf_x, d->tf_x, M, D, RGRG_ACT_NONE))) return rc;
         hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, d->tf_x, nullptr, nullptr, 1, 0, w.ln2_g, w.ln2_b, d->tf_xn, D);
         RGRG_LAUNCH_CHECK();
@@ -2204,7 +2330,6 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
                            d->layers[0].ln1_b, d->tf_xn, D);
         RGRG_LAUNCH_CHECK();
     }
-    const int items = S * d->H * ((T + 31) / 32);
     for (int l = 0; l < L; ++l) {
         const LayerW& w = d->layers[l];
         const float* ng = (l + 1 < L) ? d->layers[l + 1].ln1_g : d->lnf_g;
@@ -2216,13 +2341,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
         float* lse = d->tr_lse + (size_t)l * M * d->H;
         const DropoutParams dp_att{dropout_seed, (unsigned)(l * 4 + 1), dropout_p}, dp_r1{dropout_seed, (unsigned)(l * 4 + 2), dropout_p},
             dp_r2{dropout_seed, (unsigned)(l * 4 + 3), dropout_p};
-        if (T + 1 <= 96)
-            hipLaunchKernelGGL(attn_prefill_kernel<3>, dim3((items + 3) / 4), dim3(256), 0, st, qkv, d->ukv_out, LD, l * 2 * D,
-                               attention_mask, att, S, d->H, T, lse, dp_att);
-        else
-            hipLaunchKernelGGL(attn_prefill_kernel<8>, dim3((items + 3) / 4), dim3(256), 0, st, qkv, d->ukv_out, LD, l * 2 * D,
-                               attention_mask, att, S, d->H, T, lse, dp_att);
-        RGRG_LAUNCH_CHECK();
+        if ((rc = launch_attn_prefill(qkv, d->ukv_out, LD, l * 2 * D, attention_mask, att, S, d->H, T, lse, dp_att, st))) return rc;
         if (dropout_p > 0.f) {  // resid_dropout: x_mid = x_in + dropout(c_proj(att))
             if ((rc = tr_lin(d, w.attn_proj, false, att, nullptr, d->tr_dbig, M, D))) return rc;
             if ((rc = launch_dropout_add(d->tr_dbig, xs(2 * l), xs(2 * l + 1), MD, dp_r1, st))) return rc;

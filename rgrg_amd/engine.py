@@ -644,18 +644,19 @@ class HipEngine:
         return out[:, :out_len.value].contiguous()
 
     def beam_search(self, feats: Tensor, max_length: int, num_beams: int, early_stopping: bool = False,
-                    length_penalty: float = 1.0, bf16: bool = False) -> Tensor:
-        """LanguageModel.generate(num_beams>1, num_return_sequences=1): feats [S,1024] -> int64 [S, L]."""
+                    length_penalty: float = 1.0, bf16: bool = False, num_return_sequences: int = 1) -> Tensor:
+        """LanguageModel.generate(num_beams>1): feats [S,1024] -> int64 [S * num_return_sequences, L]."""
         _require_gpu(feats.device)
         S = feats.shape[0]
         limit = int(max_length)
         dec = self._get_decoder(S * num_beams, limit)
         _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")
         feats = feats.to(torch.float32).contiguous()
-        out = torch.empty((S, limit), dtype=torch.int64, device=feats.device)
+        out = torch.empty((S * int(num_return_sequences), limit), dtype=torch.int64, device=feats.device)
         out_len = C.c_int(0)
         _hip.check(self.lib.rgrg_decoder_beam_search(dec, _hip.ptr(feats), S, int(num_beams), limit, 1 if early_stopping else 0,
-                                                     float(length_penalty), _hip.ptr(out), limit, C.byref(out_len), self._s()),
+                                                     float(length_penalty), int(num_return_sequences), _hip.ptr(out), limit,
+                                                     C.byref(out_len), self._s()),
                    "rgrg_decoder_beam_search")
         return out[:, :out_len.value].contiguous()
 
@@ -679,8 +680,8 @@ class HipEngine:
         S, T = input_ids.shape
         if feats.shape[0] != S:
             raise ValueError(f"image_hidden_states has {feats.shape[0]} rows, input_ids {S}")
-        if T > 255:
-            raise NotImplementedError("the HIP teacher-forced pass supports sequences of up to 255 tokens")
+        if T > 1023:  # T + 1 keys: the 1024 positions of GPT-2's causal-mask buffer bound the reference as well
+            raise NotImplementedError("the teacher-forced pass supports sequences of up to 1023 tokens")
         # token ids are range-checked on the device (no host sync here): see embed_seq_ln_kernel
         dec = self._get_decoder(S, 2)
         _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")

@@ -216,12 +216,10 @@ class LanguageModel(EngineOwner):
                 raise ValueError("'num_return_sequences' has to be smaller or equal to 'num_beams'.")
             if max_length is None:
                 raise ValueError("max_length has to be set for beam generation.")
-            if num_return_sequences != 1:
-                raise NotImplementedError("the HIP beam search returns the best hypothesis per region (num_return_sequences=1), "
-                                          "which is what every caller in the reference uses")
             if 2 * num_beams > 16:
                 raise NotImplementedError("the HIP beam search supports num_beams <= 8")
             # length_penalty = 1.0 as in the reference (language_model.py:461)
             low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
-            return self.engine().beam_search(image_hidden_states, max_length, num_beams, early_stopping, 1.0, bf16=bool(low))
+            return self.engine().beam_search(image_hidden_states, max_length, num_beams, early_stopping, 1.0, bf16=bool(low),
+                                             num_return_sequences=num_return_sequences)
         raise NotImplementedError("Diverse beam-search decoding is not implemented.")

@@ -3,10 +3,12 @@ calls the C ABI) against (a) the golden fixtures produced by the REAL reference 
 (b) the CPU oracle run live on the same seeded inputs; plus size-independent properties
 at BASELINE.json's full size (29 regions x 128 tokens).  Token ids, masks and shapes are
 bit-exact; floating-point outputs carry the tolerance written in the check."""
+import os
+
 import pytest
 import torch
 
-from conftest import gpu_model, load_golden, synth_sd
+from conftest import REPO, gpu_model, load_golden, synth_sd
 from oracle import language_model as o_lm
 from rgrg_amd import synth
 
@@ -39,6 +41,27 @@ def test_decoder_early_exit_when_all_rows_finished():
     ids = m.language_model.generate(_lm_feats().to(DEV), max_length=40)
     assert ids.shape[1] == fx["output_ids"].shape[1] < 40      # L' = first length at which every row has EOS
     assert torch.equal(ids.cpu(), fx["output_ids"])
+
+
+def test_decoder_creation_waits_for_work_pending_on_the_callers_stream():
+    """rgrg_decoder_create packs the weights on the decoder's private non-blocking stream: it has to wait for kernels that
+    are still producing those weights on the caller's stream (the engine's transposes right after load_state_dict).
+    Staged here: a weight is poisoned, and the copy that restores it is queued behind ~100 ms of unrelated work."""
+    m = gpu_model("ragged")
+    eng = m.engine()
+    feats = _lm_feats().to(DEV)
+    ref = m.language_model.generate(feats, max_length=8)
+    eng.close()  # the next generate() creates (and packs) a new decoder
+    w = eng._dec_keep[4]  # layer 0 c_attn weight
+    saved = w.clone()
+    w.fill_(float("nan"))
+    torch.cuda.synchronize()
+    a = torch.randn((8192, 8192), device=DEV)
+    for _ in range(12):
+        a @ a
+    w.copy_(saved)
+    out = m.language_model.generate(feats, max_length=8)
+    assert torch.equal(out, ref)
 
 
 def test_decoder_graph_replay_equals_eager_launches():
@@ -343,17 +366,17 @@ def test_eval_forward_matches_reference_fixture():
     assert torch.equal(out[5].cpu(), e["class_detected"]) and torch.equal(out[6].cpu(), e["selected_regions"])
     assert torch.equal(out[7].cpu(), e["predicted_abnormal_regions"])
     assert (out[4]["top_region_boxes"].cpu() - e["top_region_boxes"]).abs().max().item() <= 1e-2
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):  # image_targets are supported (tests/test_gpu_detector_losses.py) but validated first
         m(images, [{"boxes": None, "labels": None}], None, None, None, None)
     m.pretrain_without_lm_model = True
     assert len(m(images, None, None, None, i["region_has_sentence"].to(DEV), i["region_is_abnormal"].to(DEV))) == 7
     m.invalidate_engine()
 
 
-@pytest.mark.parametrize("S,T", [(3, 130), (2, 255), (5, 32), (4, 1 + 32)])
+@pytest.mark.parametrize("S,T", [(3, 130), (2, 255), (5, 32), (4, 1 + 32), (2, 300)])
 def test_teacher_forced_long_and_tile_edge_sequences(S, T):
-    """Key-tile edges of the register attention (T + 1 = 33/34 keys, 8-tile variant up to T = 255) vs the oracle:
-    logits within 2e-3, loss within 2e-4."""
+    """Key-tile edges of the register attention (T + 1 = 33/34 keys, 8-tile variant up to T = 255) and the streaming
+    kernel beyond 256 keys (T = 300; the reference allows 1024 positions) vs the oracle: logits within 2e-3, loss 2e-4."""
     m = gpu_model("ragged")
     g = torch.Generator().manual_seed(S * 1000 + T)
     ids = torch.randint(0, 50257, (S, T), generator=g)
@@ -369,6 +392,35 @@ def test_teacher_forced_long_and_tile_edge_sequences(S, T):
     assert (logits.cpu() - o_logits).abs().max().item() <= 2e-3
     assert abs(loss.item() - o_loss.item()) <= 2e-4
     assert valid.any()
+
+
+def test_streaming_prefill_attention_is_bit_identical_to_the_register_kernel():
+    """attn_prefill_stream_kernel recomputes the score tiles in the register kernel's order: forced for short sequences
+    (RGRG_PREFILL_STREAM=1, read once per process -> child process) it must reproduce logits and loss bit for bit."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import gpu_model\n"
+        "m = gpu_model('ragged'); g = torch.Generator().manual_seed(5)\n"
+        "out = {}\n"
+        "for S, T in ((3, 70), (2, 200)):\n"
+        "    ids = torch.randint(0, 50257, (S, T), generator=g); am = torch.ones(S, T, dtype=torch.int64); am[1, T // 2:] = 0\n"
+        "    feats = torch.randn((S, 1024), generator=g)\n"
+        "    lg, ls = m.engine().lm_forward(feats.cuda(), ids.cuda(), am.cuda(), want_logits=True, want_loss=True)\n"
+        "    out[T] = (lg.cpu(), ls.cpu())\n"
+        "torch.save(out, sys.argv[1])\n" % (REPO, os.path.join(REPO, "tests")))
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for flag in ("0", "1"):
+            path = os.path.join(tmp, f"o{flag}.pt")
+            env = dict(os.environ, RGRG_PREFILL_STREAM=flag)
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[flag] = torch.load(path)
+    for T in (70, 200):
+        assert torch.equal(res["0"][T][0], res["1"][T][0]) and torch.equal(res["0"][T][1], res["1"][T][1])
 
 
 # ------------------------------------------------------------------------- training pass of the decoder (SURVEY 8(f) rank 2)

@@ -69,6 +69,17 @@ def test_beam_search_wide_beams(nb):
     assert out.shape == ref.shape and torch.equal(out.cpu(), ref)
 
 
+def test_beam_search_returns_several_hypotheses_per_region():
+    """num_return_sequences <= num_beams (language_model.py:450-475, HF BeamSearchScorer.finalize with
+    num_beam_hyps_to_keep > 1): rows [region * n + j] = the j-th best hypothesis."""
+    m = gpu_model("ragged")
+    feats = _feats(3, 36)
+    for n, early in ((2, False), (4, True)):
+        ref = o_lm.beam_generate(synth_sd("ragged"), feats, 12, 4, early_stopping=early, num_return_sequences=n)
+        out = m.language_model.generate(feats.to(DEV), max_length=12, num_beams=4, early_stopping=early, num_return_sequences=n)
+        assert out.shape == ref.shape and out.shape[0] == 3 * n and torch.equal(out.cpu(), ref)
+
+
 _BF16_SCRIPT = r"""
 import json, sys, torch
 sys.path.insert(0, {repo!r})

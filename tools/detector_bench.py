@@ -19,11 +19,19 @@ images = synth.make_images(B, 1234).cuda()
 
 
 def timed(fn, iters=5):
-    fn()
+    """Mean ms per call.  Three warm-up calls first, every result dropped before the next call: round 1 kept the previous
+    result alive across iterations, so at batch 8 every iteration of the trunk (~1 GB of intermediate activations) missed
+    torch's caching allocator and paid hipMalloc + a device synchronisation - the "22 ms / 0.096 of peak" trunk figure of
+    profiles/r01_detector_stages_b8.md was that artefact (the whole detector took 26.8 ms in the same run, fc6 alone 16.9)."""
+    out = None
+    for _ in range(3):
+        out = None
+        out = fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
+        out = None
         out = fn()
     e1.record()
     torch.cuda.synchronize()
