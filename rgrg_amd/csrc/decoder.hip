@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <vector>
 

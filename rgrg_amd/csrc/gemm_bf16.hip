@@ -154,27 +154,25 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Param
                 __builtin_amdgcn_sched_barrier(0);
                 const u16* Ab = &As[(buf * BM + wm * TM + frow) * LDB + fk];
                 const u16* Bb = &Bs[(buf * BN + wn * TN + frow) * LDB + fk];
-                // ALL fragments of the tile's 4 K steps are requested up front (12 / 8 ds_read_b128 in flight, pinned by
-                // the scheduling fence): LDS returns in order, so step ks only waits for its own fragments (counted
-                // lgkmcnt) and one LDS latency is exposed per K tile instead of one per fragment - the compiler's own
-                // order was read -> wait -> MFMA for every fragment (round 1: ~2400 cycles per K tile for 512 cycles of
-                // MFMA).  One quarter of tile kt+1 (the oldest global loads in flight) is written to the other LDS
-                // buffer after each step's MFMAs (its last readers passed the barrier of iteration kt-1).
-                bf16x8 a[BK16 / 16][MI], b[BK16 / 16][NI];
+                // the 4 K steps of the tile; the fragments of step ks+1 are read before the MFMAs of step ks, and
+                // one quarter of tile kt+1 (the oldest loads in flight) is converted and written to the other LDS
+                // buffer in the shadow of each step's MFMAs (its last readers passed the barrier of iteration kt-1)
+                bf16x8 a[2][MI], b[2][NI];
 #pragma unroll
-                for (int ks = 0; ks < BK16 / 16; ++ks) {
+                for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * LDB);
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) a[ks][mi] = *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * LDB + ks * 16);
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) b[ks][ni] = *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * LDB + ks * 16);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                for (int ni = 0; ni < NI; ++ni) b[0][ni] = *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * LDB);
 #define RGRG_KSTEP(KS)                                                                                       \
     {                                                                                                        \
+        if ((KS) + 1 < BK16 / 16) {                                                                          \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) a[((KS) + 1) & 1][mi] =                        \
+                *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * LDB + ((KS) + 1) * 16);                      \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) b[((KS) + 1) & 1][ni] =                        \
+                *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * LDB + ((KS) + 1) * 16);                      \
+        }                                                                                                    \
         _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)  \
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[KS][mi], b[KS][ni], acc[mi][ni], 0, 0, 0); \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(KS) & 1][mi], b[(KS) & 1][ni], acc[mi][ni], 0, 0, 0); \
         RGRG_STORE_ITEM((s + 1) % NS, buf ^ 1, KS)                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
                 RGRG_KSTEP(0) RGRG_KSTEP(1) RGRG_KSTEP(2) RGRG_KSTEP(3)
 #undef RGRG_KSTEP

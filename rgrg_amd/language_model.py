@@ -86,7 +86,7 @@ class _TeacherForcedLoss(torch.autograd.Function):
         low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
         lm.dropout_seed += 1  # a fresh counter-based stream per pass
         loss, g = lm.engine().lm_loss_grad(feats, input_ids, attention_mask, bf16=bool(low), dropout_p=float(lm.dropout_p),
-                                           dropout_seed=lm.dropout_seed)
+                                           dropout_seed=lm.pass_dropout_seed())
         D, grads = 1024, []
         for l in range(len(lm.gpt.h)):  # same order as LanguageModel.trainable_parameters()
             grads += [g["ukv_w"][(2 * l) * D:(2 * l + 1) * D], g["ukv_b"][(2 * l) * D:(2 * l + 1) * D],
@@ -150,7 +150,8 @@ class LanguageModel(EngineOwner):
         am2 = attention_mask.view(ids2.shape[0], -1)
         if self.training and torch.is_grad_enabled():
             # training pass: loss with a grad_fn; loss.backward() fills .grad of uk/uv/feature_space_transformation_nn
-            # (what the reference trains in the decoder).  fp32, no dropout.
+            # (what the reference trains in the decoder).  GPT-2's four dropout sites are active with self.dropout_p
+            # (0.1 as in the reference; 0 = deterministic), bf16 GEMMs under torch.autocast.
             self.sync_trainable_if_stale()
             loss = _TeacherForcedLoss.apply(self, ids2, am2, image_hidden_states, *self.trainable_parameters())
         else:
@@ -168,6 +169,14 @@ class LanguageModel(EngineOwner):
             ps += [b.attn.uk.weight, b.attn.uk.bias, b.attn.uv.weight, b.attn.uv.bias]
         f = self.feature_space_transformation_nn
         return ps + [f[0].weight, f[0].bias, f[2].weight, f[2].bias]
+
+    def pass_dropout_seed(self) -> int:
+        """Seed of the current training pass: the per-pass counter, offset per data-parallel rank so that replicas
+        draw different masks; rank 0 / no process group = the counter itself."""
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        return int(self.dropout_seed) + (rank << 40)
 
     def sync_trainable_if_stale(self) -> None:
         """Push optimizer-updated parameters into the engine (cheap version check: torch bumps ``_version`` on every

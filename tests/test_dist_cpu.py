@@ -186,6 +186,10 @@ def _bucket_worker(rank, world, port, ret):
             loss.backward()
         assert [p.grad.data_ptr() for p in params] == ptrs and gb.owns_all_grads()
         n = gb.allreduce()
+        # replicas draw different dropout masks: the per-pass seed is offset by the rank (rank 0 keeps the plain counter)
+        from types import SimpleNamespace
+        from rgrg_amd.language_model import LanguageModel
+        ret[f"seed{rank}"] = LanguageModel.pass_dropout_seed(SimpleNamespace(dropout_seed=0x5EED0001))
         if rank == 0:
             ret["n"] = n
             ret["grads"] = [p.grad.clone() for p in params]
@@ -205,5 +209,6 @@ def test_grad_buckets_allreduce_in_place_on_flat_views():
     ret = mgr.dict()
     mp.spawn(_bucket_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret["n"] >= 2 and ret["zeroed"] and ret["detects_lost_view"]
+    assert ret["seed0"] == 0x5EED0001 and ret["seed1"] == 0x5EED0001 + (1 << 40)
     for i, gr in enumerate(ret["grads"]):                      # 2 backward passes x mean over ranks of (rank + 1)(i + 1)
         assert torch.allclose(gr, torch.full_like(gr, 2 * 1.5 * (i + 1)), atol=1e-5)
