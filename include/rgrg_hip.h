@@ -152,8 +152,10 @@ typedef struct rgrg_decoder_weights {
 typedef struct rgrg_decoder rgrg_decoder;
 
 /* Allocates device memory (weights repacked into MFMA-fragment tiles for the
- * <=32-sequence path, workspace for max_seqs sequences x max_len positions).  May
- * synchronise.  Not on the hot loop. */
+ * <=32-sequence path - LayerNorm gains folded in -, workspace for max_seqs sequences x max_len
+ * positions).  SYNCHRONISES THE DEVICE on entry and before returning: the weights are packed on the
+ * decoder's own stream and this entry has no stream argument, so it first waits for whatever is still
+ * producing them on the caller's streams.  Not on the hot loop. */
 int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, int max_len, rgrg_decoder** out);
 void rgrg_decoder_destroy(rgrg_decoder* d);
 /* feats [S,1024] (selected region features); out_ids int64 [S,max_length] is filled
