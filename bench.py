@@ -69,7 +69,7 @@ def rooflines(eng, S_dec, dtype, max_length):
                 "avg_launch_us": 1e3 * p["ms_gemm"] / n, "algorithmic_flops_per_launch": p["gemm_flops"] / n,
                 "note": "achieved = 2 M N K of the GEMM launches of one decode step / their duration between two HIP events on the decoder stream"}
     ach = p["kv_bytes"] / (p["ms_attn"] * 1e-3) / 1e9
-    attn = {"bound": "hbm", "kernel": "attn_decode_kv16_kernel" if (dtype == "bf16" and S_dec > 128) else "attn_decode_kernel",
+    attn = {"bound": "hbm", "kernel": "attn_decode_kv16_wave_kernel" if (dtype == "bf16" and S_dec > 128) else "attn_decode_kernel",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(f"attn_{cfg}"),
             "launches_per_decode_step": 24, "avg_launch_us": 1e3 * p["ms_attn"] / 24, "algorithmic_bytes_per_launch": p["kv_bytes"] / 24,
             "keys_per_sequence": nkeys,

@@ -738,6 +738,173 @@ __global__ __launch_bounds__(256) void attn_decode_kv16_kernel(const float* __re
     }
 }
 
+// Wave-per-head variant of the bf16-cache attention (round 2): a WAVE owns one (sequence, head) - the 4 waves of a
+// workgroup are 4 consecutive heads of one sequence - so there is no LDS, no barrier and a quarter of the workgroups
+// (3712 instead of 14 848 at batch 32).  An 8-lane group still owns one key (one 16-byte load per lane and operand); a
+// wave covers 8 keys per load instruction and keeps a whole chunk of 8 * NI keys (K and V: 2 * NI loads per lane)
+// in flight.  The chunk size is picked per chunk from the wave-uniform key count (72 / 48 / 24 keys: a uniform branch
+// around a fully unrolled, unconditional, clamped load block - never a branch around a single load), each group keeps
+// a running softmax, and the 8 groups are merged at the end with cross-lane exchanges (lane ^ 8 by DPP row rotate,
+// ^ 16 / ^ 32 through the LDS crossbar).
+struct Kv16Row {  // this lane's 8 dims of the current token's q / k / v (fp32, as c_attn wrote them)
+    f32x4 q0, q1, k0, k1, v0, v1;
+};
+__device__ __forceinline__ u32x4 kv16_pack_round(const f32x4& lo, const f32x4& hi) {  // 8 fp32 -> 8 bf16 (RNE), packed
+    u32x4 o;
+    o[0] = bf16_rne_bits(lo[0]) | (bf16_rne_bits(lo[1]) << 16);
+    o[1] = bf16_rne_bits(lo[2]) | (bf16_rne_bits(lo[3]) << 16);
+    o[2] = bf16_rne_bits(hi[0]) | (bf16_rne_bits(hi[1]) << 16);
+    o[3] = bf16_rne_bits(hi[2]) | (bf16_rne_bits(hi[3]) << 16);
+    return o;
+}
+
+// FIRST: the first chunk of a wave turns the raw q / k / v into q[8] and the packed bf16 kn16 / vn16 (after its loads)
+template <int NI, bool HAS_SRC, bool FIRST>
+__device__ __forceinline__ void kv16_wave_chunk(const __amdgpu_buffer_rsrc_t kc, const __amdgpu_buffer_rsrc_t vc, const int* __restrict__ srow,
+                                                int s, int hd, int H, int T, int base, int nkeys, int slot, int g, int d8,
+                                                Kv16Row& r, float (&q)[8], u32x4& kn16, u32x4& vn16, float& m, float& l, float (&acc)[8]) {
+    int rowi[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) rowi[i] = HAS_SRC ? srow[min(base + i * 8 + g, nkeys - 1)] : s;
+    u32x4 kk[NI], vv[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int jc = min(base + i * 8 + g, nkeys - 1);
+        // 32-bit byte offsets into one layer's K (V) plane through a buffer descriptor (the launcher checks that the
+        // plane is < 2 GiB): half the address registers of 64-bit pointers; nt: a cache row is read once per step
+        const unsigned off = ((unsigned)((rowi[i] * H + hd) * T + jc) * 64u + (unsigned)d8 * 8u) * 2u;
+        kk[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(kc, (int)off, 0, 2));
+        vv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vc, (int)off, 0, 2));
+    }
+    // All 2 * NI cache loads are in flight before anything waits.  The current token's q / k / v (requested before
+    // the cache rows, so they arrive first) are consumed only HERE: used ahead of the chunk they would make the wave
+    // wait for them before it has even issued the cache loads - two serialised memory latencies per wave.
+    // (the empty asm pins the use below the loads: the compiler otherwise schedules / hoists the conversions of k and v
+    // in front of the cache loads again)
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FIRST) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            asm volatile("" : "+v"(r.q0[e]), "+v"(r.q1[e]), "+v"(r.k0[e]), "+v"(r.k1[e]), "+v"(r.v0[e]), "+v"(r.v1[e]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { q[e] = r.q0[e]; q[4 + e] = r.q1[e]; }
+        kn16 = kv16_pack_round(r.k0, r.k1);
+        vn16 = kv16_pack_round(r.v0, r.v1);
+    }
+    float sc[NI];
+    float cmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int j = base + i * 8 + g;
+        if (j == slot) { kk[i] = kn16; vv[i] = vn16; }
+        float dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            dot += q[2 * e] * __uint_as_float(kk[i][e] << 16) + q[2 * e + 1] * __uint_as_float(kk[i][e] & 0xffff0000u);
+        dot += dpp_get<0xB1, 0xf>(dot);
+        dot += dpp_get<0x4E, 0xf>(dot);
+        dot += dpp_get<0x141, 0xf>(dot);  // row_half_mirror: sum over the 8 lanes of the group
+        sc[i] = j < nkeys ? dot / 8.0f : -INFINITY;
+        cmax = fmaxf(cmax, sc[i]);
+    }
+    const float m_new = fmaxf(m, cmax);
+    const float scale = (m == -INFINITY) ? 0.f : expf(m - m_new);  // a group without any key yet keeps m = -inf
+    const bool any = m_new != -INFINITY;
+    l *= scale;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= scale;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int j = base + i * 8 + g;
+        const float pj = (j < nkeys && any) ? expf(sc[i] - m_new) : 0.f;
+        l += pj;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned u = j < nkeys ? vv[i][e] : 0u;
+            acc[2 * e] += pj * __uint_as_float(u << 16);
+            acc[2 * e + 1] += pj * __uint_as_float(u & 0xffff0000u);
+        }
+    }
+    m = m_new;
+}
+
+template <bool HAS_SRC>
+__global__ __launch_bounds__(256) void attn_decode_kv16_wave_kernel(const float* __restrict__ qkv, int ld_qkv,
+                                                                    u16* __restrict__ kc, u16* __restrict__ vc,
+                                                                    const int* __restrict__ step, float* __restrict__ out,
+                                                                    int S, int H, int T, const int* __restrict__ src,
+                                                                    u16* __restrict__ out16) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);  // (sequence, head); grid = S * H / 4 (H is a multiple of 4)
+    const int s = item / H, hd = item - s * H;
+    const int t = *step, nkeys = t + 2, slot = t + 1;
+    const int g = lane >> 3, d8 = lane & 7;
+    const float* row = qkv + (size_t)s * ld_qkv;
+    const int D = H * 64;
+    const int* srow = HAS_SRC ? src + (size_t)s * T : nullptr;
+    Kv16Row r;
+    r.q0 = *reinterpret_cast<const f32x4*>(row + hd * 64 + d8 * 8);
+    r.q1 = *reinterpret_cast<const f32x4*>(row + hd * 64 + d8 * 8 + 4);
+    r.k0 = *reinterpret_cast<const f32x4*>(row + D + hd * 64 + d8 * 8);
+    r.k1 = *reinterpret_cast<const f32x4*>(row + D + hd * 64 + d8 * 8 + 4);
+    r.v0 = *reinterpret_cast<const f32x4*>(row + 2 * D + hd * 64 + d8 * 8);
+    r.v1 = *reinterpret_cast<const f32x4*>(row + 2 * D + hd * 64 + d8 * 8 + 4);
+    float m = -INFINITY, l = 0.f, acc[8], q[8];
+    u32x4 kn16, vn16;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const __amdgpu_buffer_rsrc_t rk = dx_rsrc(kc), rv = dx_rsrc(vc);
+#define KV16_CHUNK(NI_, FIRST_, BASE_) \
+    kv16_wave_chunk<NI_, HAS_SRC, FIRST_>(rk, rv, srow, s, hd, H, T, BASE_, nkeys, slot, g, d8, r, q, kn16, vn16, m, l, acc)
+    // chunks of 72 keys while more than 48 remain, then one of 48 or 24 (nkeys >= 2: at least one chunk runs)
+    if (nkeys > 48) {
+        KV16_CHUNK(9, true, 0);
+        int base = 72;
+        for (; nkeys - base > 48; base += 72) KV16_CHUNK(9, false, base);
+        if (nkeys - base > 24) KV16_CHUNK(6, false, base);
+        else if (nkeys - base > 0) KV16_CHUNK(3, false, base);
+    } else if (nkeys > 24) {
+        KV16_CHUNK(6, true, 0);
+    } else {
+        KV16_CHUNK(3, true, 0);
+    }
+#undef KV16_CHUNK
+    if (g == 0) {  // the new token's key / value -> cache slot t + 1 (8 lanes x 16 B = the 128-byte row)
+        const size_t o = (((size_t)s * H + hd) * T + slot) * 64 + d8 * 8;
+        *reinterpret_cast<u32x4*>(kc + o) = kn16;
+        *reinterpret_cast<u32x4*>(vc + o) = vn16;
+    }
+    // merge the 8 groups (lanes with equal d8): global max, rescale, sums
+    float M = fmaxf(m, dpp_get<0x128, 0xf>(m));  // row_ror:8 = lane ^ 8 inside a 16-lane row
+    M = fmaxf(M, __shfl_xor(M, 16, 64));
+    M = fmaxf(M, __shfl_xor(M, 32, 64));
+    const float wgt = (m == -INFINITY) ? 0.f : expf(m - M);  // M is finite: key 0 (the image) always exists
+    l *= wgt;
+    l += dpp_get<0x128, 0xf>(l);
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float o = acc[e] * wgt;
+        o += dpp_get<0x128, 0xf>(o);
+        o += __shfl_xor(o, 16, 64);
+        o += __shfl_xor(o, 32, 64);
+        acc[e] = o / l;
+    }
+    if (g == 0) {
+        const size_t o = (size_t)s * D + hd * 64 + d8 * 8;
+        if (out16) {
+            u32x4 pk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pk[i] = bf16_rne_bits(acc[2 * i]) | (bf16_rne_bits(acc[2 * i + 1]) << 16);
+            *reinterpret_cast<u32x4*>(out16 + o) = pk;  // feeds the bf16 attn_proj GEMM only
+        } else {
+            *reinterpret_cast<f32x4*>(out + o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            *reinterpret_cast<f32x4*>(out + o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+        }
+    }
+}
+
 // image key/value (uk/uv outputs) -> cache slot 0 of every layer
 template <typename KV>  // float, or u16 (bf16 cache)
 __global__ __launch_bounds__(256) void kv_slot0_kernel(const float* __restrict__ ukv, int ld, KV* __restrict__ kv_all,
@@ -1552,6 +1719,19 @@ static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsig
     if (kv_is_bf16(d, S)) {
         u16* kc16 = reinterpret_cast<u16*>(d->kv) + (size_t)l * d->kv_layer_stride;
         static const int kv_ni = [] { const char* e = getenv("RGRG_KV16_NI"); return e ? atoi(e) : 1; }();  // measured at 928 sequences: 1 -> 59.7 us, 2 -> 62.9, 3 -> 60.0, 5 -> 81.2 per launch
+        // RGRG_KV16_WAVE=0: the round-1 workgroup-per-(sequence, head) kernel (kept for A/B measurements)
+        static const int kv_wave = [] { const char* e = getenv("RGRG_KV16_WAVE"); return e ? atoi(e) : 1; }();
+        if (kv_wave && (d->H & 3) == 0 && (size_t)d->kv_kv_stride * sizeof(u16) < ((size_t)1 << 31)) {
+            const dim3 wgrid(S * d->H / 4), wblk(256);
+            if (src)
+                hipLaunchKernelGGL((attn_decode_kv16_wave_kernel<true>), wgrid, wblk, 0, st, d->qkv, 3 * D, kc16, kc16 + d->kv_kv_stride,
+                                   d->step, d->att, S, d->H, d->T, src, att16);
+            else
+                hipLaunchKernelGGL((attn_decode_kv16_wave_kernel<false>), wgrid, wblk, 0, st, d->qkv, 3 * D, kc16, kc16 + d->kv_kv_stride,
+                                   d->step, d->att, S, d->H, d->T, src, att16);
+            RGRG_LAUNCH_CHECK();
+            return RGRG_OK;
+        }
         const dim3 grid(S * d->H), blk(256);
 #define KV_LAUNCH(NI_, SRC_) hipLaunchKernelGGL((attn_decode_kv16_kernel<NI_, SRC_>), grid, blk, 0, st, d->qkv, 3 * D, kc16, kc16 + d->kv_kv_stride, d->step, d->att, S, d->H, d->T, src, att16)
 #define KV_NI_SWITCH(SRC_) do { if (kv_ni == 2) KV_LAUNCH(2, SRC_); else if (kv_ni == 3) KV_LAUNCH(3, SRC_); else if (kv_ni == 5) KV_LAUNCH(5, SRC_); else KV_LAUNCH(1, SRC_); } while (0)

@@ -80,6 +80,21 @@ def test_beam_search_returns_several_hypotheses_per_region():
         assert out.shape == ref.shape and out.shape[0] == 3 * n and torch.equal(out.cpu(), ref)
 
 
+def test_beam_search_under_bf16_autocast_stays_close_to_the_fp32_beams():
+    """160 beam rows (> 128) under torch.autocast: bf16 GEMMs + the bf16 K/V cache read through the ancestor table
+    (attn_decode_kv16_wave_kernel<HAS_SRC>).  Not bit-exact by construction: >= 85 % of the tokens and >= 75 % of the
+    sequences of the fp32 beams (94 % / 90 % measured), same shape conventions."""
+    m = gpu_model("ragged")
+    feats = _feats(40, 37).to(DEV)
+    a = m.language_model.generate(feats, max_length=14, num_beams=4, early_stopping=False)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        b = m.language_model.generate(feats, max_length=14, num_beams=4, early_stopping=False)
+    assert b.dtype == torch.int64 and b.shape[0] == 40 and (b[:, 0] == 50256).all()
+    L = min(a.shape[1], b.shape[1])
+    same = a[:, :L] == b[:, :L]
+    assert same.float().mean().item() >= 0.85 and same.all(1).float().mean().item() >= 0.75
+
+
 _BF16_SCRIPT = r"""
 import json, sys, torch
 sys.path.insert(0, {repo!r})
