@@ -110,6 +110,17 @@ def test_generation_mode_errors_match_reference(model):
         lm.generate(f, 8, num_beams=2, num_return_sequences=3)
     with pytest.raises(NotImplementedError):
         lm.generate(f, 8, num_beams=4, num_beam_groups=2)
+    with pytest.raises(NotImplementedError, match="num_beams <= 8"):
+        lm.generate(f, 8, num_beams=9)
+
+
+def test_image_targets_are_validated_like_the_reference(model):
+    """object_detector.py:133-162: boxes must be [N, 4] tensors with positive width and height (checked before any GPU work)."""
+    images = torch.zeros(1, 1, 512, 512)
+    with pytest.raises(ValueError, match="positive height and width"):
+        model.object_detector(images, [{"boxes": torch.tensor([[10.0, 10.0, 10.0, 50.0]]), "labels": torch.tensor([1])}])
+    with pytest.raises(ValueError, match="shape"):
+        model.object_detector(images, [{"boxes": torch.zeros(4), "labels": torch.tensor([1])}])
 
 
 def test_no_cpu_fallback(model):
