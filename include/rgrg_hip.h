@@ -112,9 +112,11 @@ int rgrg_bce_with_logits_masked_f32(const float* logits, const uint8_t* mask, co
 /* Replaces the albumentations pipeline of get_image_tensor (src/full_model/generate_reports_for_images.py:129-147;
  * SURVEY 8(f) rank 4) for a decoded 8-bit gray image already in device memory: LongestMaxSize(512, cv2.INTER_AREA)
  * [the caller passes new_h/new_w = py3round(dim * 512 / max(h, w))] -> centred zero PadIfNeeded(512, 512) ->
- * Normalize(mean, std; max_pixel_value 255) -> dst f32 [512*512] (= the [1,1,512,512] tensor).  Down-scaling only
- * (new_h <= h, new_w <= w).  OpenCV / albumentations are third-party and absent here: arithmetic restated from their
- * published sources, parity unpinned (oracle/preprocess.py). */
+ * Normalize(mean, std; max_pixel_value 255) -> dst f32 [512*512] (= the [1,1,512,512] tensor).  Shrinking uses
+ * OpenCV's INTER_AREA tables / integer fast paths; an image smaller than 512 px is ENLARGED the way OpenCV does it
+ * for INTER_AREA with an enlarged axis (its 8-bit fixed-point bilinear path with the area coordinate rule).
+ * OpenCV / albumentations are third-party and absent here: arithmetic restated from their published sources,
+ * parity unpinned (oracle/preprocess.py). */
 int rgrg_preprocess_u8_f32(const uint8_t* src, int h, int w, int src_stride, int new_h, int new_w, float mean, float std,
                            float* dst, void* stream);
 /* BinaryClassifierRegionSelection threshold + mask + row-major compaction
@@ -223,6 +225,13 @@ int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, const int64_t
  * flat element index i of the site's tensor ([S*T,1024] for sites 0/2/3, [S,16,T,T+1] for the attention probabilities);
  * stream_id = layer*4 + site. */
 int rgrg_dropout_mask_f32(uint64_t seed, uint32_t stream_id, float p, int64_t n, float* out, void* stream);
+/* Token ids of the two teacher-forced entries above are validated ON THE DEVICE (no host round trip per call): an id
+ * outside [0, vocab) is clamped for every load (embedding row, cross-entropy label), the loss AND the gradients of that
+ * pass come out as NaN, and the NEXT decoder call that finds the (asynchronously mirrored) error word set fails with
+ * "index out of range in self" (torch.nn.Embedding's IndexError in the Python layer).  This entry synchronises the
+ * decoder's stream and hands the pending error over (*pending = 1, cleared) - the host calls it before it destroys a
+ * decoder so that the report is not lost with the object. */
+int rgrg_decoder_take_id_error(rgrg_decoder* d, int* pending);
 /* After an optimizer step changed the trainable decoder weights IN PLACE (the fst0/fst2/ukv pointers given to
  * rgrg_decoder_create): rebuild the kernel-side copies derived from them (packed skinny layouts, transposes). */
 int rgrg_decoder_refresh_trainable(rgrg_decoder* d, void* stream);
@@ -276,11 +285,6 @@ int rgrg_fastrcnn_loss_f32(const float* pred, int ld, int num_classes, const int
 
 /* Debug/parity taps: logits of the LAST executed step [S, vocab] -> dst (device). */
 int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S, void* stream);
-/* Times `iters` replays of one decode step's weight-streaming GEMM launches with HIP
- * events on the decoder's stream; returns total ms and the algorithmic weight bytes
- * of those launches (bench.py roofline). */
-int rgrg_decoder_time_gemms(rgrg_decoder* d, int S, int iters, float* ms_total, double* bytes_per_iter,
-                            int* launches_per_iter);
 /* bench.py roofline, any sequence count / precision mode: `iters` replays of (a) the projection GEMM launches of one
  * decode step for S token rows as the step would launch them, (b) its 24 single-query attention launches at `nkeys`
  * keys per sequence, each family between one pair of HIP events on the decoder's stream.  Returns total ms of each,

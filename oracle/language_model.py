@@ -84,7 +84,7 @@ def pseudo_attention(sd: SD, p: str, x: Tensor, img: Tensor, add_mask: Tensor,
 
 def lm_forward(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_states: Tensor,
                past: Optional[List[Tuple[Tensor, Tensor]]], position_ids: Tensor, p: str = "language_model.",
-               drop_masks: Optional[Dict[Tuple[int, int], Tensor]] = None, bf16: bool = False):
+               drop_masks: Optional[Dict[Tuple[int, int], Tensor]] = None, bf16: bool = False, return_hidden: bool = False):
     """LanguageModel.forward(return_loss=False, use_cache=True) (:258-366).  ``bf16``: the decoder blocks and lm_head
     with bf16 GEMM operands / bf16 K/V cache (LayerNorm, residual stream, softmax in fp32) - the arithmetic of the
     build's opt-in bf16 path, for checking it against something other than itself."""
@@ -114,9 +114,46 @@ def lm_forward(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_s
         x = h + x
         presents.append(present)
     x = F.layer_norm(x, (D_MODEL,), sd[g + "ln_f.weight"], sd[g + "ln_f.bias"], LN_EPS)
+    if return_hidden:  # the caller applies lm_head itself (row chunks: [S,T,50257] does not fit for many rows)
+        return x, presents
     lmw = sd[p + "gpt_with_lm_head.lm_head.weight"]
     logits = F.linear(_r16(x), _r16(lmw)) if bf16 else F.linear(x, lmw)  # [S,T,50257]
     return logits, presents
+
+
+@torch.no_grad()
+def teacher_forced_trace(sd: SD, ids: Tensor, image_hidden_states: Tensor, bf16: bool = False, topk: int = 1,
+                         rows_per_chunk: int = 8, p: str = "language_model."):
+    """ONE teacher-forced pass of the restated forward over token histories ``ids`` [S, L] (leading BOS included) that
+    some decoder produced: position t sees ids[:, :t+1] exactly as the incremental greedy / beam loop did (positions =
+    arange, attention mask of ones - what prepare_inputs_for_generation :498-520 builds during generation).  Returns,
+    for the L-1 predicting positions: the logit of the token that was actually chosen next (``chosen`` [S, L-1]), the
+    ``topk`` largest logits and their ids (``top_val`` / ``top_idx`` [S, L-1, topk], ties: lower id first like
+    torch.argmax) and the full logits of the LAST predicting position (``last_logits`` [S, 50257]).  The lm_head runs
+    over chunks of rows so that the [S, L, 50257] logits never exist at once.  Cheap way to pin EVERY step of a long
+    or wide decode (hundreds of sequences, > 100 tokens) against the oracle: O(one forward), not O(L) cached steps."""
+    S, L = ids.shape
+    T = L - 1
+    pos = torch.arange(T, dtype=torch.long)[None, :]
+    am = torch.ones((S, T), dtype=torch.int64)
+    x, _ = lm_forward(sd, ids[:, :T], am, image_hidden_states, None, pos, p, bf16=bf16, return_hidden=True)
+    lmw = sd[p + "gpt_with_lm_head.lm_head.weight"]
+    if bf16:
+        x, lmw = _r16(x), _r16(lmw)
+    chosen = torch.empty((S, T))
+    top_val = torch.empty((S, T, topk))
+    top_idx = torch.empty((S, T, topk), dtype=torch.int64)
+    last = torch.empty((S, VOCAB))
+    for r0 in range(0, S, rows_per_chunk):
+        lg = F.linear(x[r0:r0 + rows_per_chunk], lmw)  # [r, T, V]
+        chosen[r0:r0 + rows_per_chunk] = lg.gather(-1, ids[r0:r0 + rows_per_chunk, 1:, None]).squeeze(-1)
+        if topk == 1:
+            v, i = lg.max(-1, keepdim=True)
+        else:
+            v, i = torch.topk(lg, topk, dim=-1)
+        top_val[r0:r0 + rows_per_chunk], top_idx[r0:r0 + rows_per_chunk] = v, i
+        last[r0:r0 + rows_per_chunk] = lg[:, -1]
+    return {"chosen": chosen, "top_val": top_val, "top_idx": top_idx, "last_logits": last}
 
 
 @torch.no_grad()

@@ -11,6 +11,14 @@ The reference delegates the arithmetic to third-party code that is ABSENT from t
         area times ``float(1 / area)``, ``saturate_cast<uchar>`` (round half to even);
       - otherwise ``computeResizeAreaTab`` (fractional coverage weights, double arithmetic, float weights) and
         ``ResizeArea_Invoker`` (float accumulation: x first in table order, then rows in order), ``saturate_cast``;
+  * OpenCV 4.x ``resize`` INTER_AREA when EITHER axis is enlarged (scale = src / dst < 1 on an axis; images smaller
+    than 512 px: ``LongestMaxSize`` up-scales them): "true area interpolation is only implemented for the case
+    scale_x >= 1 && scale_y >= 1, in other cases it is emulated using some variant of bilinear" - the 8-bit
+    fixed-point bilinear path (``HResizeLinear`` / ``VResizeLinear<uchar,int,short>``) with the AREA coordinate rule:
+    ``s = floor(d * scale)``, ``f = (d + 1) - (s + 1) * inv_scale``, ``f = f <= 0 ? 0 : f - floor(f)`` (float32),
+    weights ``saturate_cast<short>((1 - f, f) * 2048)``; columns with ``s + 1 >= width`` take ``S[width - 1] * 2048``;
+    the second row index is clamped to ``height - 1``; vertical pass
+    ``uchar((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2)``;
   * ``PadIfNeeded(512, 512, border_mode=cv2.BORDER_CONSTANT)``: centred, value 0, top/left = ``int((512 - n) / 2)``;
   * ``Normalize(mean=0.471, std=0.302)``, ``max_pixel_value=255``: float32 ``(x - mean*255) * (1 / (std*255))``;
   * ``ToTensorV2`` + ``unsqueeze(0)`` -> float32 [1, 1, 512, 512].
@@ -48,12 +56,53 @@ def resize_area_tab(ssize: int, dsize: int, scale: float):
     return tab
 
 
-def resize_area_u8(img: np.ndarray, new_h: int, new_w: int) -> np.ndarray:
-    """cv2.resize(img, (new_w, new_h), interpolation=cv2.INTER_AREA) for uint8 [h, w], down-scaling."""
+def _area_linear_coeffs(ssize: int, dsize: int):
+    """Per destination index of the bilinear emulation: source index s, short weights (a0, a1) and the `edge` flag
+    (s + 1 >= ssize: HResizeLinear's tail ``D[dx] = S[xofs[dx]] * ONE``), following resize.cpp's area_mode branch."""
+    scale = 1.0 / (dsize / ssize)            # scale_x = 1. / inv_scale_x, double
+    inv_scale = dsize / ssize
+    d = np.arange(dsize, dtype=np.float64)
+    s = np.floor(d * scale).astype(np.int64)
+    f = ((d + 1.0) - (s + 1).astype(np.float64) * inv_scale).astype(np.float32)
+    f = np.where(f <= 0, np.float32(0), f - np.floor(f)).astype(np.float32)
+    edge = s + 1 >= ssize
+    f = np.where(s >= ssize - 1, np.float32(0), f).astype(np.float32)
+    s = np.minimum(s, ssize - 1)
+    a0 = np.clip(np.rint((np.float32(1.0) - f) * np.float32(2048.0)), -32768, 32767).astype(np.int64)
+    a1 = np.clip(np.rint(f * np.float32(2048.0)), -32768, 32767).astype(np.int64)
+    return s, a0, a1, edge
+
+
+def resize_area_as_linear_u8(img: np.ndarray, new_h: int, new_w: int) -> np.ndarray:
+    """cv2.resize(..., INTER_AREA) for uint8 [h, w] when an axis is enlarged: the fixed-point bilinear emulation."""
     h, w = img.shape
-    assert img.dtype == np.uint8 and new_h <= h and new_w <= w
+    src = img.astype(np.int64)
+    sx, a0, a1, xedge = _area_linear_coeffs(w, new_w)
+    sx1 = np.minimum(sx + 1, w - 1)
+    hbuf = np.where(xedge[None, :], src[:, sx] * 2048, src[:, sx] * a0[None, :] + src[:, sx1] * a1[None, :])   # [h, new_w] int
+    # the y loop of resize() applies no edge rule: weights from f as computed, second row clamped by the invoker
+    scale_y, inv_y = 1.0 / (new_h / h), new_h / h
+    dy = np.arange(new_h, dtype=np.float64)
+    sy = np.floor(dy * scale_y).astype(np.int64)
+    fy = ((dy + 1.0) - (sy + 1).astype(np.float64) * inv_y).astype(np.float32)
+    fy = np.where(fy <= 0, np.float32(0), fy - np.floor(fy)).astype(np.float32)
+    b0 = np.clip(np.rint((np.float32(1.0) - fy) * np.float32(2048.0)), -32768, 32767).astype(np.int64)
+    b1 = np.clip(np.rint(fy * np.float32(2048.0)), -32768, 32767).astype(np.int64)
+    r0 = np.clip(sy, 0, h - 1)
+    r1 = np.clip(sy + 1, 0, h - 1)
+    s0, s1 = hbuf[r0] >> 4, hbuf[r1] >> 4
+    out = (((b0[:, None] * s0) >> 16) + ((b1[:, None] * s1) >> 16) + 2) >> 2
+    return (out & 0xFF).astype(np.uint8)      # uchar(...) cast
+
+
+def resize_area_u8(img: np.ndarray, new_h: int, new_w: int) -> np.ndarray:
+    """cv2.resize(img, (new_w, new_h), interpolation=cv2.INTER_AREA) for uint8 [h, w]."""
+    h, w = img.shape
+    assert img.dtype == np.uint8
     if (new_h, new_w) == (h, w):
         return img.copy()
+    if not (w / new_w >= 1 and h / new_h >= 1):
+        return resize_area_as_linear_u8(img, new_h, new_w)
     sx, sy = w / new_w, h / new_h
     isx, isy = int(round(sx)), int(round(sy))
     if abs(sx - isx) < np.finfo(np.float64).eps and abs(sy - isy) < np.finfo(np.float64).eps:
@@ -83,9 +132,7 @@ def get_image_tensor_from_array(image: np.ndarray) -> np.ndarray:
     h, w = image.shape
     scale = IMAGE_INPUT_SIZE / float(max(h, w))
     if scale != 1.0:
-        nh, nw = py3round(h * scale), py3round(w * scale)
-        if scale > 1.0:
-            raise NotImplementedError("INTER_AREA up-scaling (images smaller than 512) is not restated")
+        nh, nw = max(py3round(h * scale), 1), max(py3round(w * scale), 1)
         image = resize_area_u8(image, nh, nw)
     h, w = image.shape
     top, left = int((IMAGE_INPUT_SIZE - h) / 2.0), int((IMAGE_INPUT_SIZE - w) / 2.0)

@@ -48,26 +48,47 @@ def is_stale() -> bool:
         return f.read().strip() != _source_hash()
 
 
+def _compile(hipcc: str, src: str, tmpdir: str, verbose: bool) -> str:
+    obj = os.path.join(tmpdir, src.replace(".hip", ".o"))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
+           "-Wno-pass-failed", "-c", os.path.join(CSRC, src), "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return obj
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into ``rgrg_amd/lib/librgrg_hip.so``."""
+    """Compile every HIP source for gfx950 into ``rgrg_amd/lib/librgrg_hip.so``.
+
+    Safe against concurrent callers (every rank of a torchrun job calls ``_hip.load()`` at the same time): the build
+    runs under an exclusive ``flock`` on the lib directory, objects go to a private temporary directory, and the
+    library and its source hash are put in place with ``os.replace``; a rank that waited for the lock re-checks the
+    hash and returns without rebuilding."""
     if not force and not is_stale():
         return LIB_PATH
+    import fcntl
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = _hipcc()
-    objs = []
-    for src in SOURCES:
-        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
-               "-Wno-pass-failed", "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
-        objs.append(obj)
-    tmp = LIB_PATH + ".tmp"
-    subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs, check=True)
-    os.replace(tmp, LIB_PATH)
-    with open(HASH_PATH, "w") as f:
-        f.write(_source_hash() + "\n")
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():  # another process built it while this one waited
+                return LIB_PATH
+            with tempfile.TemporaryDirectory(prefix="build.", dir=LIB_DIR) as tmpdir:
+                with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+                    objs = list(pool.map(lambda src: _compile(hipcc, src, tmpdir, verbose), SOURCES))
+                tmp = os.path.join(tmpdir, "librgrg_hip.so")
+                subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs, check=True)
+                os.replace(tmp, LIB_PATH)
+            tmp_hash = HASH_PATH + f".{os.getpid()}"
+            with open(tmp_hash, "w") as f:
+                f.write(_source_hash() + "\n")
+            os.replace(tmp_hash, HASH_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

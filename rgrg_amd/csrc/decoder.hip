@@ -49,15 +49,6 @@ static int skinny_max_rows() {
         if (v > SKINNY_MAX_ROWS) v = SKINNY_MAX_ROWS; if (v < 32) v = 32; }
     return v;
 }
-// Decode plan for <= 128 token rows.  1 (default): fused, fragment-direct (skinny_direct.inc) - 5 launches per layer:
-// LayerNorm folded into the consumer GEMM's weights, split-K combine and embedding rebuilt while the consumer loads its
-// A fragments, attn_proj adds bias + residual itself.  0 (RGRG_DECODE_PLAN=0): the round-1 sequence (7 launches per
-// layer, LDS-staged GEMMs, separate LayerNorm / combine kernels), kept for A/B timing.
-static int decode_plan() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("RGRG_DECODE_PLAN"); v = e ? atoi(e) : 1; }
-    return v;
-}
 constexpr int BOS_ID = 50256, EOS_ID = 50256, PAD_ID = 50256;
 constexpr float LN_EPS = 1e-5f;
 
@@ -79,23 +70,6 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
 }
 
-// 16-column tiles for v_mfma_f32_16x16x4_f32: P [NT][K/16][64 lanes][4], lane l = (j = l&15,
-// q = l>>4) holds W[nt*16+j][kc*16 + 4q .. +3].
-__global__ __launch_bounds__(256) void pack_weights16_kernel(const float* __restrict__ W, float* __restrict__ P, int N,
-                                                             int K, int NT) {
-    const size_t total = (size_t)NT * (K / 16) * 64;
-    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
-        const int l = (int)(o & 63);
-        const size_t t = o >> 6;
-        const int kc = (int)(t % (K / 16));
-        const int nt = (int)(t / (K / 16));
-        const int n = nt * 16 + (l & 15);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < N) v = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + kc * 16 + (l >> 4) * 4);
-        reinterpret_cast<f32x4*>(P)[o] = v;
-    }
-}
-
 // ------------------------------------------------------------------ skinny GEMM
 struct SkinnyArgs {
     const float* X;     // [32][K] (rows >= M are zero)
@@ -105,9 +79,6 @@ struct SkinnyArgs {
     float* Y;           // [32][ldy]
     float* part;        // [KS][32][NT*32] partial sums when KS > 1
     int M, K, N, NT, KS, ldy, act;
-    float* cand_val;    // optional [32][NT] per-tile row maxima (fused arg-max of lm_head), KS == 1 only
-    int* cand_idx;
-    int ntile;          // 32 or 16 output columns per workgroup
 };
 
 __device__ __forceinline__ void skinny_store(const SkinnyArgs& a, int row, int col, float v) {
@@ -121,24 +92,23 @@ constexpr int SK_WAVES = 8;  // K is split over the 8 waves of a workgroup (and 
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-// Weight-streaming GEMM for <= 32 activation rows.  One workgroup = one NTILE-column tile of
-// the output x one K slice (K / KS):
+// Weight-streaming GEMM of the PREFILL (feature_space_transformation_nn, uk / uv of all layers; <= 128 activation
+// rows).  One workgroup = one 32-column tile of the output x one K slice (K / KS):
 //   1. the 32 x (K/KS) activation slice is staged ONCE into LDS with fully coalesced 16-B
 //      loads (rows padded by 4 floats -> conflict-free ds_read_b128 A fragments);
 //   2. each of the 8 waves streams its PW one-KiB chunks of pre-packed weights straight into
 //      registers (non-temporal, all PW loads in flight before the first MFMA);
-//   3. f32 MFMAs (32x32x2 for NTILE 32, 2 x 16x16x4 for NTILE 16) drain the chunks in arrival
-//      order; the 8 per-wave accumulators are summed through LDS in a fixed order.
-// KS == 1: bias / residual / activation epilogue (+ per-tile arg-max candidates for lm_head);
-// KS  > 1: partial sums to a.part, combined by the consumer kernel.
-template <int NTILE, int PW, int MT>
+//   3. v_mfma_f32_32x32x2_f32 drains the chunks in arrival order; the 8 per-wave accumulators are summed
+//      through LDS in a fixed order.
+// KS == 1: bias / residual / activation epilogue; KS > 1: partial sums to a.part, combined by skinny_reduce_kernel.
+// (The decode steps use the fragment-direct kernels of skinny_direct.inc.)
+template <int PW, int MT>
 __global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32(const SkinnyArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KC = (NTILE == 32) ? 8 : 16;  // k per weight chunk
+    constexpr int KC = 8;                        // k per weight chunk
     constexpr int KWG = PW * SK_WAVES * KC;      // K slice of this workgroup
     constexpr int LDX = KWG + 4;
     constexpr int XQ = KWG / 64;                 // float4 staging loads per thread (32*KWG/4/512)
-    constexpr int NACC = (NTILE == 32) ? 16 : 8; // accumulator registers per row tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, ks = blockIdx.y;
     const int chunks = a.K / KC;
@@ -162,7 +132,7 @@ __global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32(const SkinnyArgs a) 
     __builtin_amdgcn_sched_barrier(0);
     // The weights stay in registers while up to MT row tiles (32 sequences each) are streamed through LDS:
     // W is fetched from HBM once for up to 128 sequences.
-    float acc[MT][NACC];
+    float acc[MT][16];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (mt > 0) __syncthreads();  // every wave has finished reading the previous tile
@@ -174,93 +144,43 @@ __global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32(const SkinnyArgs a) 
         }
         __syncthreads();
         if (mt + 1 < MT) load_x(mt + 1);  // in flight during this tile's MFMAs
-        if constexpr (NTILE == 32) {
-            f32x16 c16;
+        f32x16 c16;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c16[r] = 0.f;
-            const float* xa = &smem[(lane & 31) * LDX + wave * PW * KC + (lane >> 5) * 4];
+        for (int r = 0; r < 16; ++r) c16[r] = 0.f;
+        const float* xa = &smem[(lane & 31) * LDX + wave * PW * KC + (lane >> 5) * 4];
 #pragma unroll
-            for (int c = 0; c < PW; ++c) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(xa + c * KC);
+        for (int c = 0; c < PW; ++c) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(xa + c * KC);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) c16 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], w[c][j], c16, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] = c16[r];
-        } else {
-            f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            const float* xa = &smem[(lane & 15) * LDX + wave * PW * KC + (lane >> 4) * 4];
-#pragma unroll
-            for (int c = 0; c < PW; ++c) {
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xa + c * KC);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(xa + 16 * LDX + c * KC);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], w[c][j], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], w[c][j], acc1, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { acc[mt][r] = acc0[r]; acc[mt][4 + r] = acc1[r]; }
+            for (int j = 0; j < 4; ++j) c16 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], w[c][j], c16, 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = c16[r];
     }
     float* red = smem;  // re-used after the MFMA loop
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         __syncthreads();  // LDS free: MFMA reads (mt == 0) or the previous tile's reduction are done
 #pragma unroll
-        for (int r = 0; r < NACC; ++r) red[(wave * NACC + r) * 64 + lane] = acc[mt][r];
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[mt][r];
         __syncthreads();
         const int row0 = mt * 32;
-        if constexpr (NTILE == 32) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int idx = tid + 512 * q;
-                const int r = idx >> 6, l = idx & 63;
-                float v = red[r * 64 + l];
+        for (int q = 0; q < 2; ++q) {
+            const int idx = tid + 512 * q;
+            const int r = idx >> 6, l = idx & 63;
+            float v = red[r * 64 + l];
 #pragma unroll
-                for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[(w2 * 16 + r) * 64 + l];
-                const int lrow = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-                const int row = row0 + lrow;
-                const int col = nt * 32 + (l & 31);
-                if (a.KS == 1) {
-                    skinny_store(a, row, col, v);
-                    if (a.cand_val) {
-                        // fused arg-max: the 32 columns of `row` in this tile live in one 32-lane half; first max wins
-                        float bv = (col < a.N) ? v + (a.bias ? a.bias[col] : 0.f) : -INFINITY;
-                        int bi = col;
-#pragma unroll
-                        for (int o = 16; o > 0; o >>= 1) {
-                            const float ov = __shfl_xor(bv, o, 64);
-                            const int oi = __shfl_xor(bi, o, 64);
-                            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                        }
-                        if ((l & 31) == 0 && row < a.M) {
-                            a.cand_val[(size_t)row * a.NT + nt] = bv;
-                            a.cand_idx[(size_t)row * a.NT + nt] = bi;
-                        }
-                    }
-                } else {
-                    a.part[(((size_t)mt * a.KS + ks) * PAD_ROWS + lrow) * (a.NT * NTILE) + col] = v;
-                }
-            }
-        } else {
-            // 32 rows x 16 cols = 512 outputs, one per thread.  C/D map of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
-            const int half = tid >> 8, r = (tid >> 6) & 3, l = tid & 63;
-            float v = red[(0 * 8 + half * 4 + r) * 64 + l];
-#pragma unroll
-            for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[(w2 * 8 + half * 4 + r) * 64 + l];
-            const int lrow = half * 16 + (l >> 4) * 4 + r;
-            const int col = nt * 16 + (l & 15);
-            if (a.KS == 1)
-                skinny_store(a, row0 + lrow, col, v);
-            else
-                a.part[(((size_t)mt * a.KS + ks) * PAD_ROWS + lrow) * (a.NT * NTILE) + col] = v;
+            for (int w2 = 1; w2 < SK_WAVES; ++w2) v += red[(w2 * 16 + r) * 64 + l];
+            const int lrow = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+            const int col = nt * 32 + (l & 31);
+            if (a.KS == 1) skinny_store(a, row0 + lrow, col, v);
+            else a.part[(((size_t)mt * a.KS + ks) * PAD_ROWS + lrow) * (a.NT * 32) + col] = v;
         }
     }
 }
 
-// Persistent variant for very wide outputs (lm_head: 1571 column tiles, uk/uv: 1536): the
+// Persistent variant for very wide outputs (uk/uv of all layers: 1536 column tiles): the
 // grid is one workgroup per CU; each workgroup stages the (<= 31) activation rows ONCE and
 // then walks column tiles nt = blockIdx.x, += gridDim.x.  A tile's 16 weight chunks per wave
 // live in two 8-chunk register buffers that are refilled with the NEXT tile's chunks as soon
@@ -332,20 +252,6 @@ __global__ __launch_bounds__(512) void rgrg_skinny_gemm_f32_wide(const SkinnyArg
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
             const int col = nt * 32 + (l & 31);
             skinny_store(a, row, col, v);
-            if (a.cand_val) {
-                float bv = (col < a.N) ? v + (a.bias ? a.bias[col] : 0.f) : -INFINITY;
-                int bi = col;
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(bv, o, 64);
-                    const int oi = __shfl_xor(bi, o, 64);
-                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                }
-                if ((l & 31) == 0 && row < a.M) {
-                    a.cand_val[(size_t)row * a.NT + nt] = bv;
-                    a.cand_idx[(size_t)row * a.NT + nt] = bi;
-                }
-            }
         }
     }
 }
@@ -357,51 +263,44 @@ constexpr int WIDE_MAX_ROWS = 31;  // 31 staged rows + the 32 KiB reduction buff
 constexpr size_t WIDE_LDS = (size_t)(WIDE_MAX_ROWS * (16 * SK_WAVES * 8 + 4) + SK_WAVES * 16 * 64) * sizeof(float);
 static_assert(WIDE_LDS <= 160 * 1024, "wide skinny GEMM must fit the 160 KiB LDS");
 
-template <int NTILE, int PW, int MT>
+template <int PW, int MT>
 static int launch_skinny(const SkinnyArgs& a, hipStream_t st) {
-    constexpr int KC = (NTILE == 32) ? 8 : 16;
-    constexpr size_t lds_x = (size_t)32 * (PW * SK_WAVES * KC + 4) * sizeof(float);
-    constexpr size_t lds_r = (size_t)SK_WAVES * (NTILE == 32 ? 16 : 8) * 64 * sizeof(float);
+    constexpr size_t lds_x = (size_t)32 * (PW * SK_WAVES * 8 + 4) * sizeof(float);
+    constexpr size_t lds_r = (size_t)SK_WAVES * 16 * 64 * sizeof(float);
     constexpr size_t lds = lds_x > lds_r ? lds_x : lds_r;
-    hipLaunchKernelGGL((rgrg_skinny_gemm_f32<NTILE, PW, MT>), dim3(a.NT, a.KS), dim3(64 * SK_WAVES), lds, st, a);
+    hipLaunchKernelGGL((rgrg_skinny_gemm_f32<PW, MT>), dim3(a.NT, a.KS), dim3(64 * SK_WAVES), lds, st, a);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
 
-template <int NTILE, int PW>
+template <int PW>
 static int launch_skinny_mt(const SkinnyArgs& a, hipStream_t st) {
     const int mt = (a.M + PAD_ROWS - 1) / PAD_ROWS;
-    if (mt <= 1) return launch_skinny<NTILE, PW, 1>(a, st);
-    if (mt == 2) return launch_skinny<NTILE, PW, 2>(a, st);
-    if (mt == 3) return launch_skinny<NTILE, PW, 3>(a, st);
-    if (mt == 4) return launch_skinny<NTILE, PW, 4>(a, st);
+    if (mt <= 1) return launch_skinny<PW, 1>(a, st);
+    if (mt == 2) return launch_skinny<PW, 2>(a, st);
+    if (mt == 3) return launch_skinny<PW, 3>(a, st);
+    if (mt == 4) return launch_skinny<PW, 4>(a, st);
     set_error("skinny GEMM: %d rows exceed 4 row tiles", a.M);
     return RGRG_EINVAL;
 }
 
-// chunks-per-wave PW = K / (KC * KS * 8) must be one of the instantiated values
-static int launch_skinny_any(int ntile, const SkinnyArgs& a, hipStream_t st) {
-    const int kc = ntile == 32 ? 8 : 16;
-    const int pw = a.K / (kc * a.KS * SK_WAVES);
-    if (ntile == 32 && pw == 16 && a.KS == 1 && a.NT > 512 && a.M <= WIDE_MAX_ROWS) {
+// chunks-per-wave PW = K / (8 * KS * 8) must be one of the instantiated values
+static int launch_skinny_any(const SkinnyArgs& a, hipStream_t st) {
+    const int pw = a.K / (8 * a.KS * SK_WAVES);
+    if (pw == 16 && a.KS == 1 && a.NT > 512 && a.M <= WIDE_MAX_ROWS) {
         hipLaunchKernelGGL(rgrg_skinny_gemm_f32_wide, dim3(256), dim3(64 * SK_WAVES), WIDE_LDS, st, a);
         RGRG_LAUNCH_CHECK();
         return RGRG_OK;
     }
-    if (ntile == 32) {
-        if (pw == 4) return launch_skinny_mt<32, 4>(a, st);
-        if (pw == 8) return launch_skinny_mt<32, 8>(a, st);
-        if (pw == 16) return launch_skinny_mt<32, 16>(a, st);
-    } else {
-        if (pw == 4) return launch_skinny_mt<16, 4>(a, st);
-        if (pw == 8) return launch_skinny_mt<16, 8>(a, st);
-    }
-    set_error("skinny GEMM: unsupported shape K=%d KS=%d ntile=%d (chunks per wave %d)", a.K, a.KS, ntile, pw);
+    if (pw == 4) return launch_skinny_mt<4>(a, st);
+    if (pw == 8) return launch_skinny_mt<8>(a, st);
+    if (pw == 16) return launch_skinny_mt<16>(a, st);
+    set_error("skinny GEMM: unsupported shape K=%d KS=%d (chunks per wave %d)", a.K, a.KS, pw);
     return RGRG_EINVAL;
 }
 
 __global__ __launch_bounds__(256) void skinny_reduce_kernel(const SkinnyArgs a) {
-    const int ldp = a.NT * a.ntile;
+    const int ldp = a.NT * 32;
     const int total = a.M * a.N;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int row = i / a.N, col = i - row * a.N;
@@ -469,24 +368,13 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
     else reinterpret_cast<f32x4*>(xn + (size_t)s * D)[tid] = o;
 }
 
-// Residual stream update fused with the split-K combine and the NEXT LayerNorm:
-//   x[row] += bias + sum_ks part[ks][row]   (fixed order)   ;   xn[row] = LN(x[row])
-// part == nullptr: x already holds the sum (tiled-GEMM path), only the LayerNorm runs.
-__global__ __launch_bounds__(256) void resid_ln_kernel(float* __restrict__ x, const float* __restrict__ bias,
-                                                       const float* __restrict__ part, int KS, int ldp,
-                                                       const float* __restrict__ g, const float* __restrict__ b,
-                                                       float* __restrict__ xn, int D, unsigned short* __restrict__ xn16 = nullptr) {
+// xn[row] = LayerNorm(x[row]) (many-sequence path: the tiled GEMM's epilogue already added bias + residual into x)
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                      const float* __restrict__ b, float* __restrict__ xn, int D,
+                                                      unsigned short* __restrict__ xn16 = nullptr) {
     __shared__ float sh[4];
     const int row = blockIdx.x, tid = threadIdx.x;
-    f32x4 v = reinterpret_cast<const f32x4*>(x + (size_t)row * D)[tid];
-    if (part) {
-        // partials are stored per 32-row tile: [tile][ks][32][ldp]
-        const float* pt = part + ((size_t)(row >> 5) * KS * PAD_ROWS + (row & 31)) * ldp;
-        f32x4 p = reinterpret_cast<const f32x4*>(pt)[tid];
-        for (int ks = 1; ks < KS; ++ks) p += reinterpret_cast<const f32x4*>(pt + (size_t)ks * PAD_ROWS * ldp)[tid];
-        v += p + reinterpret_cast<const f32x4*>(bias)[tid];
-        reinterpret_cast<f32x4*>(x + (size_t)row * D)[tid] = v;
-    }
+    const f32x4 v = reinterpret_cast<const f32x4*>(x + (size_t)row * D)[tid];
     const f32x4 o = ln_row(v, g, b, sh, D);
     if (xn16) store_bf16x4(xn16 + (size_t)row * D + 4 * tid, o);
     else reinterpret_cast<f32x4*>(xn + (size_t)row * D)[tid] = o;
@@ -612,131 +500,6 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float f) {
     return u >> 16;
 }
 __device__ __forceinline__ float bf16_round(float f) { return __uint_as_float(bf16_rne_bits(f) << 16); }
-
-// Same attention with a bf16 K/V cache (half the bytes of the kernel's only real traffic).  An 8-lane group owns
-// one key (8 dims = one 16-byte load per lane), a wave covers 8 consecutive keys (1 KiB) and the workgroup 32 keys
-// per pass; q, the scores, the softmax and the accumulation stay fp32.  The new token's k / v are rounded once and the
-// rounded values are used here too, so this step and later steps see the same numbers.  Same structure as
-// attn_decode_kernel: unconditional (clamped) loads of a whole chunk up front, per-group running softmax, one merge.
-template <int KV_NI, bool HAS_SRC>  // a chunk = 32 * KV_NI keys
-__global__ __launch_bounds__(256) void attn_decode_kv16_kernel(const float* __restrict__ qkv, int ld_qkv,
-                                                               u16* __restrict__ kc, u16* __restrict__ vc,
-                                                               const int* __restrict__ step, float* __restrict__ out,
-                                                               int S, int H, int T, const int* __restrict__ src,
-                                                               u16* __restrict__ out16) {
-    __shared__ float pm[32], pl[32];
-    __shared__ __attribute__((aligned(16))) float pacc[32][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s = blockIdx.x / H, hd = blockIdx.x - s * H;
-    const int t = *step, nkeys = t + 2, slot = t + 1;
-    const int g = lane >> 3, d8 = lane & 7;
-    const float* row = qkv + (size_t)s * ld_qkv;
-    const int D = H * 64;
-    const int* srow = HAS_SRC ? src + (size_t)s * T : nullptr;
-    int rowi[KV_NI];  // first chunk's ancestor-table entries: the oldest loads of the kernel
-#pragma unroll
-    for (int i = 0; i < KV_NI; ++i) rowi[i] = HAS_SRC ? srow[min((i * 4 + wave) * 8 + g, nkeys - 1)] : s;
-    float q[8], kn[8], vn[8];
-    {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(row + hd * 64 + d8 * 8);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(row + hd * 64 + d8 * 8 + 4);
-        const f32x4 c = *reinterpret_cast<const f32x4*>(row + D + hd * 64 + d8 * 8);
-        const f32x4 e = *reinterpret_cast<const f32x4*>(row + D + hd * 64 + d8 * 8 + 4);
-        const f32x4 f = *reinterpret_cast<const f32x4*>(row + 2 * D + hd * 64 + d8 * 8);
-        const f32x4 h = *reinterpret_cast<const f32x4*>(row + 2 * D + hd * 64 + d8 * 8 + 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            q[i] = a[i]; q[4 + i] = b[i];
-            kn[i] = bf16_round(c[i]); kn[4 + i] = bf16_round(e[i]);
-            vn[i] = bf16_round(f[i]); vn[4 + i] = bf16_round(h[i]);
-        }
-    }
-    auto pack8 = [](const float* v) -> u32x4 {
-        u32x4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (__float_as_uint(v[2 * i]) >> 16) | (__float_as_uint(v[2 * i + 1]) & 0xffff0000u);
-        return o;
-    };
-    const u32x4 kn16 = pack8(kn), vn16 = pack8(vn);
-    constexpr int CHUNK = 32 * KV_NI;
-    float m = -INFINITY, l = 0.f, acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int base = 0; base < nkeys; base += CHUNK) {
-        if (HAS_SRC && base > 0) {
-#pragma unroll
-            for (int i = 0; i < KV_NI; ++i) rowi[i] = srow[min(base + (i * 4 + wave) * 8 + g, nkeys - 1)];
-        }
-        u32x4 kk[KV_NI], vv[KV_NI];
-#pragma unroll
-        for (int i = 0; i < KV_NI; ++i) {
-            const int jc = min(base + (i * 4 + wave) * 8 + g, nkeys - 1);
-            const size_t off = (((size_t)rowi[i] * H + hd) * T + jc) * 64 + d8 * 8;
-            kk[i] = *reinterpret_cast<const u32x4*>(kc + off);
-            vv[i] = *reinterpret_cast<const u32x4*>(vc + off);
-        }
-        __builtin_amdgcn_sched_barrier(0);  // all 2 * KV_NI loads are in flight before the first dot product waits
-        float sc[KV_NI];
-        float cmax = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < KV_NI; ++i) {
-            const int j = base + (i * 4 + wave) * 8 + g;
-            if (j == slot) { kk[i] = kn16; vv[i] = vn16; }
-            float dot = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                dot += q[2 * e] * __uint_as_float(kk[i][e] << 16) + q[2 * e + 1] * __uint_as_float(kk[i][e] & 0xffff0000u);
-            dot += dpp_get<0xB1, 0xf>(dot);
-            dot += dpp_get<0x4E, 0xf>(dot);
-            dot += dpp_get<0x141, 0xf>(dot);  // row_half_mirror: sum over the 8 lanes of the group
-            sc[i] = j < nkeys ? dot / 8.0f : -INFINITY;
-            cmax = fmaxf(cmax, sc[i]);
-        }
-        const float m_new = fmaxf(m, cmax);
-        const float scale = (m == -INFINITY) ? 0.f : expf(m - m_new);
-        l *= scale;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] *= scale;
-#pragma unroll
-        for (int i = 0; i < KV_NI; ++i) {
-            const int j = base + (i * 4 + wave) * 8 + g;
-            const float pj = j < nkeys ? expf(sc[i] - m_new) : 0.f;
-            l += pj;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned u = j < nkeys ? vv[i][e] : 0u;
-                acc[2 * e] += pj * __uint_as_float(u << 16);
-                acc[2 * e + 1] += pj * __uint_as_float(u & 0xffff0000u);
-            }
-        }
-        m = m_new;
-    }
-    if (wave == 0 && g == 0) {
-        const size_t o = (((size_t)s * H + hd) * T + slot) * 64 + d8 * 8;
-        *reinterpret_cast<u32x4*>(kc + o) = kn16;
-        *reinterpret_cast<u32x4*>(vc + o) = vn16;
-    }
-    const int grp = wave * 8 + g;
-    if (d8 == 0) { pm[grp] = m; pl[grp] = l; }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) pacc[grp][d8 * 8 + e] = acc[e];
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        float M = pm[0];
-#pragma unroll
-        for (int k = 1; k < 32; ++k) M = fmaxf(M, pm[k]);
-        float L = 0.f, o = 0.f;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const float wgt = expf(pm[k] - M);
-            L += pl[k] * wgt;
-            o += pacc[k][threadIdx.x] * wgt;
-        }
-        o /= L;
-        if (out16) out16[(size_t)s * D + hd * 64 + threadIdx.x] = (u16)bf16_rne_bits(o);  // feeds the bf16 attn_proj GEMM only
-        else out[(size_t)s * D + hd * 64 + threadIdx.x] = o;
-    }
-}
 
 // Wave-per-head variant of the bf16-cache attention (round 2): a WAVE owns one (sequence, head) - the 4 waves of a
 // workgroup are 4 consecutive heads of one sequence - so there is no LDS, no barrier and a quarter of the workgroups
@@ -1436,7 +1199,7 @@ static int launch_attn_prefill(const float* qkv, const float* ukv, int ld_ukv, i
 __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, size_t ld, int V, int row0,
                                                       const long long* __restrict__ ids, const float* __restrict__ am, int T,
                                                       float* __restrict__ row_loss, int* __restrict__ row_valid,
-                                                      float* __restrict__ row_lse) {
+                                                      float* __restrict__ row_lse, int* __restrict__ id_error) {
     __shared__ float shv[4];
     const int r = row0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = r % T;
@@ -1461,7 +1224,14 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
     if (tid == 0) {
         const float tot = (shv[0] + shv[1]) + (shv[2] + shv[3]);
         const float lse = m + logf(tot);
-        row_loss[r] = lse - x[ids[r + 1]];
+        // the label is a raw caller-supplied id: clamp it for the read (an id outside [0, V) would index outside the
+        // logits row) and raise the error word - that pass's loss and gradients come out as NaN, the next call reports it
+        long long label = ids[r + 1];
+        if (label < 0 || label >= V) {
+            atomicOr(id_error, 1);
+            label = label < 0 ? 0 : V - 1;
+        }
+        row_loss[r] = lse - x[label];
         row_valid[r] = 1;
         if (row_lse) row_lse[r] = lse;
     }
@@ -1547,8 +1317,13 @@ struct rgrg_decoder {
     int *src_a, *src_b, *beam_tok, *beam_parent, *cand_tok, *cand_beam, *top_tok;
     float *beam_scores, *row_max, *row_logsum, *top_val, *cand_score;
     int* h_done;  // pinned
-    int* id_error = nullptr;    // device: set by the teacher-forced embedding when a token id is outside [0, vocab)
-    int* h_id_error = nullptr;  // pinned mirror, copied back asynchronously at the end of a pass, checked by the next call
+    // Token-id validation of the teacher-forced passes, without a host round trip.  id_error[0]: raised by the CURRENT
+    // pass (embedding / cross-entropy kernels) when an id is outside [0, vocab), cleared when a pass starts - it poisons
+    // THAT pass's loss and gradients (NaN).  id_error[1]: sticky "some pass failed and has not been reported yet",
+    // folded from [0] at the end of every pass and copied to the pinned mirror; the next call that finds the mirror set
+    // reports torch.nn.Embedding's IndexError and clears both.
+    int* id_error = nullptr;
+    int* h_id_error = nullptr;
     hipStream_t stream;
     hipEvent_t ev_in;
     std::vector<GraphEntry> graphs;
@@ -1584,7 +1359,7 @@ static int dmalloc(rgrg_decoder* d, void** p, size_t bytes, bool zero) {
 static int pick_ks(int NT, int chunks) {
     // Wide outputs (>= 64 column tiles) keep the whole K in one workgroup: no partial sums.
     // Narrow ones (N = 1024) split K over workgroups until ~all CUs stream, keeping a
-    // multiple of 4 one-KiB chunks per wave; the consumer (resid_ln_kernel) adds the partials.
+    // multiple of 4 one-KiB chunks per wave; skinny_reduce_kernel adds the partials.
     int ks = 1;
     if (NT >= 64) return ks;
     while (NT * ks < 256 && chunks % (ks * 2 * SK_WAVES * 4) == 0) ks *= 2;
@@ -1594,7 +1369,7 @@ static int pick_ks(int NT, int chunks) {
 static int make_lin(rgrg_decoder* d, Lin& l, const float* w, const float* b, int N, int K, bool pack,
                     bool direct = false, const float* ln_g = nullptr, const float* ln_b = nullptr) {
     l.w = w; l.b = b; l.N = N; l.K = K;
-    if (direct && decode_plan() == 1) {
+    if (direct) {
         // fused plan: 16-column tiles, one 1024-wide K slice per workgroup (mlp_proj: 4 slices -> 256 workgroups, the
         // fp32 MFMA work needs every CU; the 4 partial sums are added by the consumer while it loads its fragments)
         if (!(K == DK_SLICE || (K == 4 * DK_SLICE && !ln_g && N == DK_SLICE))) { set_error("decoder: N=%d K=%d unsupported by the fused plan", N, K); return RGRG_EINVAL; }
@@ -1612,18 +1387,13 @@ static int make_lin(rgrg_decoder* d, Lin& l, const float* w, const float* b, int
         }
         return RGRG_OK;
     }
-    if (K == 1024 && N >= 2048 && N <= 8192) {
-        // c_attn / c_fc: 16-column tiles -> 192 / 256 workgroups with the whole K each (no partial sums)
-        l.ntile = 16; l.KS = 1;
-    } else {
-        l.ntile = 32;
-        l.KS = pick_ks((N + 31) / 32, K / 8);
-    }
+    // prefill GEMMs (fst-nn, uk/uv): LDS-staged weight-streaming kernel, 32-column tiles
+    l.ntile = 32;
+    l.KS = pick_ks((N + 31) / 32, K / 8);
     l.NT = (N + l.ntile - 1) / l.ntile;
-    const int kc = l.ntile == 32 ? 8 : 16;
+    const int kc = 8;
     const int pw = K / (kc * l.KS * SK_WAVES);
-    const bool ok = (K % (kc * l.KS * SK_WAVES) == 0) &&
-                    (l.ntile == 32 ? (pw == 4 || pw == 8 || pw == 16) : (pw == 4 || pw == 8));
+    const bool ok = (K % (kc * l.KS * SK_WAVES) == 0) && (pw == 4 || pw == 8 || pw == 16);
     if (!ok) {
         set_error("decoder: no skinny GEMM instance for N=%d K=%d (ntile %d, KS %d, %d chunks per wave)", N, K, l.ntile, l.KS, pw);
         return RGRG_EINVAL;
@@ -1632,61 +1402,52 @@ static int make_lin(rgrg_decoder* d, Lin& l, const float* w, const float* b, int
         const size_t bytes = (size_t)l.NT * l.ntile * K * sizeof(float);
         int rc = dmalloc(d, (void**)&l.packed, bytes, false);
         if (rc) return rc;
-        if (l.ntile == 32)
-            hipLaunchKernelGGL(pack_weights_kernel, dim3(2048), dim3(256), 0, d->stream, w, l.packed, N, K, l.NT);
-        else
-            hipLaunchKernelGGL(pack_weights16_kernel, dim3(2048), dim3(256), 0, d->stream, w, l.packed, N, K, l.NT);
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(2048), dim3(256), 0, d->stream, w, l.packed, N, K, l.NT);
         RGRG_LAUNCH_CHECK();
     }
     return RGRG_OK;
 }
 
 // hipFuncSetAttribute is not capturable: raise the dynamic-LDS limit of every instance up front
-template <int NTILE, int PW, int MT>
+template <int PW, int MT>
 static int skinny_attr1() {
-    constexpr int KC = (NTILE == 32) ? 8 : 16;
-    constexpr size_t lds_x = (size_t)32 * (PW * SK_WAVES * KC + 4) * sizeof(float);
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_gemm_f32<NTILE, PW, MT>),
+    constexpr size_t lds_x = (size_t)32 * (PW * SK_WAVES * 8 + 4) * sizeof(float);
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_gemm_f32<PW, MT>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_x > 65536 ? lds_x : 65536)));
     return RGRG_OK;
 }
-template <int NTILE, int PW>
+template <int PW>
 static int skinny_attr() {
     int rc;
-    if ((rc = skinny_attr1<NTILE, PW, 1>())) return rc;
-    if ((rc = skinny_attr1<NTILE, PW, 2>())) return rc;
-    if ((rc = skinny_attr1<NTILE, PW, 3>())) return rc;
-    return skinny_attr1<NTILE, PW, 4>();
+    if ((rc = skinny_attr1<PW, 1>())) return rc;
+    if ((rc = skinny_attr1<PW, 2>())) return rc;
+    if ((rc = skinny_attr1<PW, 3>())) return rc;
+    return skinny_attr1<PW, 4>();
 }
 static int init_skinny_attrs() {
     int rc;
-    if ((rc = skinny_attr<32, 4>())) return rc;
-    if ((rc = skinny_attr<32, 8>())) return rc;
-    if ((rc = skinny_attr<32, 16>())) return rc;
-    if ((rc = skinny_attr<16, 4>())) return rc;
+    if ((rc = skinny_attr<4>())) return rc;
+    if ((rc = skinny_attr<8>())) return rc;
     RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_gemm_f32_wide),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS));
-    return skinny_attr<16, 8>();
+    return skinny_attr<16>();
 }
 
 // bf16 K/V cache: with the bf16 GEMMs, i.e. on the many-sequence path of the opt-in bf16 mode.  `rows` is the
 // number of token rows of the decode steps (sequences x beams), the same for every launch of one generate call.
 static bool kv_is_bf16(const rgrg_decoder* d, int rows) { return d->bf16_gemms && rows > skinny_max_rows(); }
 
-// Y[:M] = act(X W^T + b + R).  <= 32 rows: weight-streaming skinny GEMM; when the layer
-// splits K over workgroups (KS > 1) and `defer` is set, only the partial sums are produced
-// (d->part) and the caller's next kernel (resid_ln_kernel) combines them with bias and
-// residual; otherwise a small reduce kernel finishes the job.  > 32 rows: tiled MFMA GEMM.
+// Y[:M] = act(X W^T + b + R).  Prefill GEMMs (packed, <= 128 rows): LDS-staged weight-streaming kernel (+ a small
+// reduce kernel when the layer splits K over workgroups); everything else: tiled MFMA GEMM (fp32, or the bf16-weight
+// kernel in the opt-in bf16 mode, optionally with bf16 activations in / out).
 static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R, float* Y, int M, int ldy, int act,
-                  bool count, bool defer = false, bool cand = false, const unsigned short* X16 = nullptr,
-                  unsigned short* Y16 = nullptr) {
+                  bool count, const unsigned short* X16 = nullptr, unsigned short* Y16 = nullptr) {
     if (M <= skinny_max_rows() && l.packed && !l.direct) {
         // up to 4 row tiles of 32 sequences in ONE launch: the weights stay in registers across the tiles
-        SkinnyArgs a{X, l.packed, l.b, R, Y, d->part, M, l.K, l.N, l.NT, l.KS, ldy, act, nullptr, nullptr, l.ntile};
-        if (cand && l.KS == 1 && l.ntile == 32) { a.cand_val = d->cand_val; a.cand_idx = d->cand_idx; }
-        int rc = launch_skinny_any(l.ntile, a, d->stream);
+        SkinnyArgs a{X, l.packed, l.b, R, Y, d->part, M, l.K, l.N, l.NT, l.KS, ldy, act};
+        int rc = launch_skinny_any(a, d->stream);
         if (rc) return rc;
-        if (l.KS > 1 && !defer) {
+        if (l.KS > 1) {
             const int total = M * l.N;
             hipLaunchKernelGGL(skinny_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, d->stream, a);
             RGRG_LAUNCH_CHECK();
@@ -1718,26 +1479,20 @@ static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsig
     float* vc = kc + d->kv_kv_stride;
     if (kv_is_bf16(d, S)) {
         u16* kc16 = reinterpret_cast<u16*>(d->kv) + (size_t)l * d->kv_layer_stride;
-        static const int kv_ni = [] { const char* e = getenv("RGRG_KV16_NI"); return e ? atoi(e) : 1; }();  // measured at 928 sequences: 1 -> 59.7 us, 2 -> 62.9, 3 -> 60.0, 5 -> 81.2 per launch
-        // RGRG_KV16_WAVE=0: the round-1 workgroup-per-(sequence, head) kernel (kept for A/B measurements)
-        static const int kv_wave = [] { const char* e = getenv("RGRG_KV16_WAVE"); return e ? atoi(e) : 1; }();
-        if (kv_wave && (d->H & 3) == 0 && (size_t)d->kv_kv_stride * sizeof(u16) < ((size_t)1 << 31)) {
-            const dim3 wgrid(S * d->H / 4), wblk(256);
-            if (src)
-                hipLaunchKernelGGL((attn_decode_kv16_wave_kernel<true>), wgrid, wblk, 0, st, d->qkv, 3 * D, kc16, kc16 + d->kv_kv_stride,
-                                   d->step, d->att, S, d->H, d->T, src, att16);
-            else
-                hipLaunchKernelGGL((attn_decode_kv16_wave_kernel<false>), wgrid, wblk, 0, st, d->qkv, 3 * D, kc16, kc16 + d->kv_kv_stride,
-                                   d->step, d->att, S, d->H, d->T, src, att16);
-            RGRG_LAUNCH_CHECK();
-            return RGRG_OK;
+        // one wave per (sequence, head); the cache rows are addressed with 32-bit byte offsets into one layer's K (V)
+        // plane through a buffer descriptor, which bounds a plane at 2 GiB (8128 sequences at max_length 128)
+        if ((d->H & 3) != 0 || (size_t)d->kv_kv_stride * sizeof(u16) >= ((size_t)1 << 31)) {
+            set_error("decoder: the bf16 K/V cache plane of one layer (%zu bytes) exceeds the 2 GiB the attention kernel addresses: "
+                      "lower the batch or max_length", (size_t)d->kv_kv_stride * sizeof(u16));
+            return RGRG_EINVAL;
         }
-        const dim3 grid(S * d->H), blk(256);
-#define KV_LAUNCH(NI_, SRC_) hipLaunchKernelGGL((attn_decode_kv16_kernel<NI_, SRC_>), grid, blk, 0, st, d->qkv, 3 * D, kc16, kc16 + d->kv_kv_stride, d->step, d->att, S, d->H, d->T, src, att16)
-#define KV_NI_SWITCH(SRC_) do { if (kv_ni == 2) KV_LAUNCH(2, SRC_); else if (kv_ni == 3) KV_LAUNCH(3, SRC_); else if (kv_ni == 5) KV_LAUNCH(5, SRC_); else KV_LAUNCH(1, SRC_); } while (0)
-        if (src) KV_NI_SWITCH(true); else KV_NI_SWITCH(false);
-#undef KV_NI_SWITCH
-#undef KV_LAUNCH
+        const dim3 wgrid(S * d->H / 4), wblk(256);
+        if (src)
+            hipLaunchKernelGGL((attn_decode_kv16_wave_kernel<true>), wgrid, wblk, 0, st, d->qkv, 3 * D, kc16, kc16 + d->kv_kv_stride,
+                               d->step, d->att, S, d->H, d->T, src, att16);
+        else
+            hipLaunchKernelGGL((attn_decode_kv16_wave_kernel<false>), wgrid, wblk, 0, st, d->qkv, 3 * D, kc16, kc16 + d->kv_kv_stride,
+                               d->step, d->att, S, d->H, d->T, src, att16);
     } else {
         const dim3 grid(S * d->H), blk(256);
 #define ATT_LAUNCH(SRC_, NI_) hipLaunchKernelGGL((attn_decode_kernel<SRC_, NI_>), grid, blk, 0, st, d->qkv, 3 * D, kc, vc, d->step, d->att, S, d->H, d->T, src, frag_out)
@@ -1849,16 +1604,15 @@ static int enqueue_step_fused(rgrg_decoder* d, int S, bool count, const int* tok
     return RGRG_OK;
 }
 
-// One decode step.  <= 32 sequences: 1 + 24*7 + 2 = 171 launches (lm_head emits arg-max candidates)
-//   embed+ln1 | per layer: c_attn, attention, attn_proj(partials), resid+ln2, c_fc+gelu,
-//   mlp_proj(partials), resid+ln1(next layer / ln_f) | lm_head, argmax+bookkeeping
+// One decode step.  <= 128 token rows: the fused plan above.  More rows (many images, beam rows): tiled MFMA GEMMs
+//   embed+ln1 | per layer: c_attn, attention, attn_proj (+ residual), ln2, c_fc+gelu, mlp_proj (+ residual),
+//   ln1 of the next layer / ln_f | lm_head, per-32-column arg-max candidates, argmax + bookkeeping
 static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_override = nullptr, const int* src = nullptr,
                         bool beam = false) {
-    if (d->lm_head.direct && S <= skinny_max_rows()) return enqueue_step_fused(d, S, count, tok_override, src, beam);
+    if (S <= skinny_max_rows()) return enqueue_step_fused(d, S, count, tok_override, src, beam);
     if (count) { d->gemm_bytes_per_step = 0; d->gemm_flops_per_step = 0.0; d->gemm_launches_per_step = 0; }
     hipStream_t st = d->stream;
     const int D = d->D;
-    const bool skinny = S <= skinny_max_rows();
     int rc;
     // bf16 many-sequence mode: the GEMM inputs (LayerNorm output, attention output, GELU output) are written ONCE as
     // bf16 by their producers - the same round-to-nearest-even the GEMM would apply to an fp32 input, so the results
@@ -1873,28 +1627,22 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
         const LayerW& w = d->layers[l];
         const float* ng = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_g : d->lnf_g;
         const float* nb = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_b : d->lnf_b;
-        if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, count, false, false, xn16))) return rc;
+        if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, count, xn16))) return rc;
         if ((rc = launch_attention(d, l, S, src, att16))) return rc;
-        const bool defer_a = skinny && w.attn_proj.KS > 1, defer_m = skinny && w.mlp_proj.KS > 1;
-        if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count, defer_a, false, att16))) return rc;
-        hipLaunchKernelGGL(resid_ln_kernel, dim3(S), dim3(256), 0, st, d->x, w.attn_proj.b, defer_a ? d->part : nullptr,
-                           w.attn_proj.KS, w.attn_proj.NT * w.attn_proj.ntile, w.ln2_g, w.ln2_b, d->xn, D, xn16);
+        if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count, att16))) return rc;
+        hipLaunchKernelGGL(ln_rows_kernel, dim3(S), dim3(256), 0, st, d->x, w.ln2_g, w.ln2_b, d->xn, D, xn16);
         RGRG_LAUNCH_CHECK();
-        if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, count, false, false, xn16, ff16))) return rc;
-        if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->x, S, D, RGRG_ACT_NONE, count, defer_m, false, ff16))) return rc;
-        hipLaunchKernelGGL(resid_ln_kernel, dim3(S), dim3(256), 0, st, d->x, w.mlp_proj.b, defer_m ? d->part : nullptr,
-                           w.mlp_proj.KS, w.mlp_proj.NT * w.mlp_proj.ntile, ng, nb, d->xn, D, xn16);
+        if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, count, xn16, ff16))) return rc;
+        if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->x, S, D, RGRG_ACT_NONE, count, ff16))) return rc;
+        hipLaunchKernelGGL(ln_rows_kernel, dim3(S), dim3(256), 0, st, d->x, ng, nb, d->xn, D, xn16);
         RGRG_LAUNCH_CHECK();
     }
-    if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, false, !beam, xn16))) return rc;
+    if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, xn16))) return rc;
     if (beam) return RGRG_OK;  // the caller ranks the logits (beam_row_topk / beam_merge)
-    int cand_nt = d->lm_head.NT;  // candidates per row: the lm_head kernel's column tiles, or 32-column tiles of the logits
-    if (!(skinny && !d->lm_head.direct && d->lm_head.KS == 1 && d->lm_head.ntile == 32)) {
-        cand_nt = (d->V + 31) / 32;  // ld_logits >= 32 * cand_nt, and the candidate buffers hold lm_head.NT >= cand_nt per row
-        hipLaunchKernelGGL(logits_candidates_kernel, dim3(4, S), dim3(256), 0, st, d->logits, d->ld_logits, d->V,
-                           cand_nt, d->cand_val, d->cand_idx);
-        RGRG_LAUNCH_CHECK();
-    }
+    const int cand_nt = (d->V + 31) / 32;  // ld_logits >= 32 * cand_nt, and the candidate buffers hold lm_head.NT >= cand_nt per row
+    hipLaunchKernelGGL(logits_candidates_kernel, dim3(4, S), dim3(256), 0, st, d->logits, d->ld_logits, d->V,
+                       cand_nt, d->cand_val, d->cand_idx);
+    RGRG_LAUNCH_CHECK();
     hipLaunchKernelGGL(argmax_update_kernel, dim3(S), dim3(256), 0, st, d->cand_val, d->cand_idx, cand_nt, d->ids,
                        d->max_len, d->finished, d->step, d->done_len, d->sync, S);
     RGRG_LAUNCH_CHECK();
@@ -1993,7 +1741,7 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     TRY(dmalloc(d, (void**)&d->step, 4, true));
     TRY(dmalloc(d, (void**)&d->done_len, 4, true));
     TRY(dmalloc(d, (void**)&d->sync, 64, true));
-    TRY(dmalloc(d, (void**)&d->id_error, 4, true));
+    TRY(dmalloc(d, (void**)&d->id_error, 8, true));
     TRY(dmalloc(d, (void**)&d->cand_val, R * d->lm_head.NT * 4, true));
     TRY(dmalloc(d, (void**)&d->cand_idx, R * d->lm_head.NT * 4, true));
     TRY(dmalloc(d, (void**)&d->src_a, R * d->T * 4, true));
@@ -2268,10 +2016,25 @@ namespace rgrg {
 static int check_id_error(rgrg_decoder* d) {
     if (d->h_id_error && *d->h_id_error) {
         *d->h_id_error = 0;
-        (void)hipMemsetAsync(d->id_error, 0, sizeof(int), d->stream);
-        set_error("index out of range in self: a token id of the previous teacher-forced pass was outside [0, %d)", d->V);
+        (void)hipMemsetAsync(d->id_error, 0, 2 * sizeof(int), d->stream);
+        set_error("index out of range in self: a token id of a previous teacher-forced pass was outside [0, %d)", d->V);
         return RGRG_EINVAL;
     }
+    return RGRG_OK;
+}
+__global__ void id_error_fold_kernel(int* __restrict__ e) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && e[0]) e[1] = 1;
+}
+// start of a pass (on the decoder stream, after the wait for the caller): this pass's error word starts clean
+static int id_error_begin(rgrg_decoder* d) {
+    RGRG_HIP(hipMemsetAsync(d->id_error, 0, sizeof(int), d->stream));
+    return RGRG_OK;
+}
+// end of a pass: fold this pass's word into the sticky one and mirror the sticky word to the host (asynchronously)
+static int id_error_end(rgrg_decoder* d) {
+    hipLaunchKernelGGL(id_error_fold_kernel, dim3(1), dim3(64), 0, d->stream, d->id_error);
+    RGRG_LAUNCH_CHECK();
+    RGRG_HIP(hipMemcpyAsync(d->h_id_error, d->id_error + 1, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     return RGRG_OK;
 }
 constexpr int TF_LOGIT_ROWS = 2048;  // lm_head + cross entropy run over chunks of this many token rows (412 MB of logits)
@@ -2324,6 +2087,7 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
     hipStream_t caller = as_stream(stream), st = d->stream;
     RGRG_HIP(hipEventRecord(d->ev_in, caller));
     RGRG_HIP(hipStreamWaitEvent(st, d->ev_in, 0));
+    if ((rc = id_error_begin(d))) return rc;
     // feature_space_transformation_nn (:284), then uk / uv of every layer in one GEMM (:145-150)
     RGRG_HIP(hipMemcpyAsync(d->feats, feats, (size_t)S * D * sizeof(float), hipMemcpyDeviceToDevice, st));
     if ((rc = linear(d, d->fst0, d->feats, nullptr, d->h1, S, D, RGRG_ACT_RELU, false))) return rc;
@@ -2342,11 +2106,11 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
                                       DropoutParams{0ull, 0u, 0.f}, st)))
             return rc;
         if ((rc = tf_linear(d, w.attn_proj, d->tf_att, d->tf_x, d->tf_x, M, D, RGRG_ACT_NONE))) return rc;
-        hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, d->tf_x, nullptr, nullptr, 1, 0, w.ln2_g, w.ln2_b, d->tf_xn, D);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3(M), dim3(256), 0, st, d->tf_x, w.ln2_g, w.ln2_b, d->tf_xn, D);
         RGRG_LAUNCH_CHECK();
         if ((rc = tf_linear(d, w.c_fc, d->tf_xn, nullptr, d->tf_ff, M, 4 * D, RGRG_ACT_GELU_NEW))) return rc;
         if ((rc = tf_linear(d, w.mlp_proj, d->tf_ff, d->tf_x, d->tf_x, M, D, RGRG_ACT_NONE))) return rc;
-        hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, d->tf_x, nullptr, nullptr, 1, 0, ng, nb, d->tf_xn, D);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3(M), dim3(256), 0, st, d->tf_x, ng, nb, d->tf_xn, D);
         RGRG_LAUNCH_CHECK();
     }
     // lm_head (tied to wte, no bias) and the loss, over chunks of token rows
@@ -2356,7 +2120,7 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
         if ((rc = tf_linear(d, d->lm_head, d->tf_xn + (size_t)r0 * D, nullptr, lg, rows, d->V, RGRG_ACT_NONE))) return rc;
         if (loss_out) {
             hipLaunchKernelGGL(ce_rows_kernel, dim3(rows), dim3(256), 0, st, lg, (size_t)d->V, d->V, r0, ids, attention_mask, T,
-                               d->tf_row_loss, d->tf_row_valid, (float*)nullptr);
+                               d->tf_row_loss, d->tf_row_valid, (float*)nullptr, d->id_error);
             RGRG_LAUNCH_CHECK();
         }
     }
@@ -2365,7 +2129,7 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
                            d->id_error);
         RGRG_LAUNCH_CHECK();
     }
-    RGRG_HIP(hipMemcpyAsync(d->h_id_error, d->id_error, sizeof(int), hipMemcpyDeviceToHost, st));
+    if ((rc = id_error_end(d))) return rc;
     // the caller's stream continues after this pass (no host synchronisation)
     RGRG_HIP(hipEventRecord(d->ev_in, st));
     RGRG_HIP(hipStreamWaitEvent(caller, d->ev_in, 0));
@@ -2380,7 +2144,7 @@ int launch_gelu_backward(float* d, const float* pre, size_t n, hipStream_t st);
 int launch_relu_backward(float* d, const float* h, size_t n, hipStream_t st);
 int launch_ln_backward(const float* dy, const float* x, const float* g, float* out, int rows, int D, int accumulate, hipStream_t st);
 int launch_ce_backward(float* logits, size_t ld, int V, int row0, int rows, const long long* ids, const int* row_valid,
-                       const float* row_lse, const int* n_scored, float scale, hipStream_t st);
+                       const float* row_lse, const int* n_scored, float scale, const int* id_error, hipStream_t st);
 int launch_transpose_pad(const float* src, float* dst, int R, int Cc, int Rp, hipStream_t st);
 int launch_colsum(const float* src, float* out, int R, int Cc, hipStream_t st);
 int attn_backward_max_t();
@@ -2492,6 +2256,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
     hipStream_t caller = as_stream(stream), st = d->stream;
     RGRG_HIP(hipEventRecord(d->ev_in, caller));
     RGRG_HIP(hipStreamWaitEvent(st, d->ev_in, 0));
+    if ((rc = id_error_begin(d))) return rc;
     if ((rc = ensure_wT(d))) return rc;
     const long long* ids = reinterpret_cast<const long long*>(input_ids);
     const size_t MD = (size_t)M * D;
@@ -2507,7 +2272,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
     RGRG_LAUNCH_CHECK();
     if (dropout_p > 0.f) {  // self.drop on the embeddings (language_model.py:311), then ln_1 of layer 0 again
         if ((rc = launch_dropout_add(xs(0), nullptr, xs(0), MD, DropoutParams{dropout_seed, 0u, dropout_p}, st))) return rc;
-        hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, xs(0), nullptr, nullptr, 1, 0, d->layers[0].ln1_g,
+        hipLaunchKernelGGL(ln_rows_kernel, dim3(M), dim3(256), 0, st, xs(0), d->layers[0].ln1_g,
                            d->layers[0].ln1_b, d->tf_xn, D);
         RGRG_LAUNCH_CHECK();
     }
@@ -2527,7 +2292,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
             if ((rc = tr_lin(d, w.attn_proj, false, att, nullptr, d->tr_dbig, M, D))) return rc;
             if ((rc = launch_dropout_add(d->tr_dbig, xs(2 * l), xs(2 * l + 1), MD, dp_r1, st))) return rc;
         } else if ((rc = tr_lin(d, w.attn_proj, false, att, xs(2 * l), xs(2 * l + 1), M, D))) return rc;
-        hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, xs(2 * l + 1), nullptr, nullptr, 1, 0, w.ln2_g, w.ln2_b, d->tf_xn, D);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3(M), dim3(256), 0, st, xs(2 * l + 1), w.ln2_g, w.ln2_b, d->tf_xn, D);
         RGRG_LAUNCH_CHECK();
         if ((rc = tr_lin(d, w.c_fc, false, d->tf_xn, nullptr, ffpre, M, 4 * D))) return rc;
         if ((rc = launch_gelu_apply(ffpre, d->tr_ff, (size_t)M * 4 * D, st))) return rc;
@@ -2535,7 +2300,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
             if ((rc = tr_lin(d, w.mlp_proj, false, d->tr_ff, nullptr, d->tr_dxn, M, D))) return rc;
             if ((rc = launch_dropout_add(d->tr_dxn, xs(2 * l + 1), xs(2 * l + 2), MD, dp_r2, st))) return rc;
         } else if ((rc = tr_lin(d, w.mlp_proj, false, d->tr_ff, xs(2 * l + 1), xs(2 * l + 2), M, D))) return rc;
-        hipLaunchKernelGGL(resid_ln_kernel, dim3(M), dim3(256), 0, st, xs(2 * l + 2), nullptr, nullptr, 1, 0, ng, nb, d->tf_xn, D);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3(M), dim3(256), 0, st, xs(2 * l + 2), ng, nb, d->tf_xn, D);
         RGRG_LAUNCH_CHECK();
     }
     // ---------------- lm_head + loss + d(logits) + d(ln_f output), chunk by chunk (the logits never exist as a whole)
@@ -2547,17 +2312,17 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
         const int rows = (M - r0 < TF_LOGIT_ROWS) ? M - r0 : TF_LOGIT_ROWS;
         if ((rc = tr_lin(d, d->lm_head, false, d->tf_xn + (size_t)r0 * D, nullptr, d->tr_logits, rows, VP))) return rc;
         hipLaunchKernelGGL(ce_rows_kernel, dim3(rows), dim3(256), 0, st, d->tr_logits, (size_t)VP, V, r0, ids, attention_mask, T,
-                           d->tf_row_loss, d->tf_row_valid, d->tr_row_lse);
+                           d->tf_row_loss, d->tf_row_valid, d->tr_row_lse, d->id_error);
         RGRG_LAUNCH_CHECK();
         if ((rc = launch_ce_backward(d->tr_logits, (size_t)VP, V, r0, rows, ids, d->tf_row_valid, d->tr_row_lse, d->tr_count,
-                                     loss_scale, st)))
+                                     loss_scale, d->id_error, st)))
             return rc;
         if ((rc = tr_lin(d, d->lm_head, true, d->tr_logits, nullptr, d->tr_dxn + (size_t)r0 * D, rows, D))) return rc;
     }
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, d->tf_row_loss, d->tf_row_valid, M, loss_out, (int*)nullptr,
                        d->id_error);
-    RGRG_HIP(hipMemcpyAsync(d->h_id_error, d->id_error, sizeof(int), hipMemcpyDeviceToHost, st));
     RGRG_LAUNCH_CHECK();
+    if ((rc = id_error_end(d))) return rc;
     // ---------------- backward through ln_f and the 24 frozen blocks (activation gradients only)
     if ((rc = launch_ln_backward(d->tr_dxn, xs(2 * L), d->lnf_g, d->tr_dx, M, D, 0, st))) return rc;
     for (int l = L - 1; l >= 0; --l) {
@@ -2611,6 +2376,17 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
     return RGRG_OK;
 }
 
+extern "C" int rgrg_decoder_take_id_error(rgrg_decoder* d, int* pending) {
+    RGRG_CHECK_ARG(d && pending);
+    RGRG_HIP(hipStreamSynchronize(d->stream));
+    *pending = (d->h_id_error && *d->h_id_error) ? 1 : 0;
+    if (*pending) {
+        *d->h_id_error = 0;
+        RGRG_HIP(hipMemsetAsync(d->id_error, 0, 2 * sizeof(int), d->stream));
+    }
+    return RGRG_OK;
+}
+
 extern "C" int rgrg_decoder_refresh_trainable(rgrg_decoder* d, void* stream) {
     RGRG_CHECK_ARG(d);
     hipStream_t caller = as_stream(stream), st = d->stream;
@@ -2619,10 +2395,7 @@ extern "C" int rgrg_decoder_refresh_trainable(rgrg_decoder* d, void* stream) {
     Lin* ls[] = {&d->fst0, &d->fst2, &d->ukv};
     for (Lin* l : ls) {
         if (l->packed) {
-            if (l->ntile == 32)
-                hipLaunchKernelGGL(pack_weights_kernel, dim3(2048), dim3(256), 0, st, l->w, l->packed, l->N, l->K, l->NT);
-            else
-                hipLaunchKernelGGL(pack_weights16_kernel, dim3(2048), dim3(256), 0, st, l->w, l->packed, l->N, l->K, l->NT);
+            hipLaunchKernelGGL(pack_weights_kernel, dim3(2048), dim3(256), 0, st, l->w, l->packed, l->N, l->K, l->NT);
             RGRG_LAUNCH_CHECK();
         }
         if (l->wT) {
@@ -2675,56 +2448,6 @@ extern "C" int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S,
     return RGRG_OK;
 }
 
-extern "C" int rgrg_decoder_time_gemms(rgrg_decoder* d, int S, int iters, float* ms_total, double* bytes_per_iter,
-                                       int* launches_per_iter) {
-    RGRG_CHECK_ARG(d && S > 0 && S <= SKINNY_MAX_ROWS && S <= d->max_seqs && iters > 0 && ms_total && bytes_per_iter);
-    hipEvent_t e0, e1;
-    RGRG_HIP(hipEventCreate(&e0));
-    RGRG_HIP(hipEventCreate(&e1));
-    const int D = d->D;
-    d->gemm_bytes_per_step = 0;
-    d->gemm_launches_per_step = 0;
-    float total = 0.f;
-    int rc = RGRG_OK;
-    const bool fused = d->lm_head.direct;
-    // the 97 weight-streaming GEMM launches of one decode step, back to back in step order, between ONE
-    // pair of events on the decoder's stream (the two event records amortise over the 97 launches)
-    for (int it = 0; it < iters && !rc; ++it) {
-        const bool c = it == 0;
-        RGRG_HIP(hipEventRecord(e0, d->stream));
-        for (int l = 0; l < d->n_layer && !rc; ++l) {
-            const LayerW& w = d->layers[l];
-            if (fused) {  // the GEMM launches of the fused plan (combine / folded LayerNorm included), step order
-                if ((rc = enqueue_layer_gemms(d, l ? l : 1, S, c, nullptr, d->x, d->x2, 0))) break;
-                if ((rc = enqueue_layer_gemms(d, l, S, c, nullptr, d->x, d->x2, 1))) break;
-                continue;
-            }
-            if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, c, true))) break;
-            if ((rc = linear(d, w.attn_proj, d->att, nullptr, d->h1, S, D, RGRG_ACT_NONE, c, true))) break;
-            if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, c, true))) break;
-            if ((rc = linear(d, w.mlp_proj, d->ff, nullptr, d->h1, S, D, RGRG_ACT_NONE, c, true))) break;
-        }
-        if (!rc && fused) {
-            DirectArgs h{};
-            h.Xf = d->x; h.part = d->part; h.Y = d->logits; h.ldy = d->ld_logits; h.act = RGRG_ACT_NONE;
-            rc = direct_linear(d, d->lm_head, h, DX_COMBINE4, S, c, true);
-        } else if (!rc) rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, c, true, true);
-        if (rc) break;
-        RGRG_HIP(hipEventRecord(e1, d->stream));
-        RGRG_HIP(hipEventSynchronize(e1));
-        float ms = 0.f;
-        RGRG_HIP(hipEventElapsedTime(&ms, e0, e1));
-        total += ms;
-    }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (rc) return rc;
-    *ms_total = total;
-    *bytes_per_iter = (double)d->gemm_bytes_per_step;
-    if (launches_per_iter) *launches_per_iter = d->gemm_launches_per_step;
-    return RGRG_OK;
-}
-
 namespace rgrg {
 __global__ void set_int_kernel(int* p, int v) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *p = v;
@@ -2763,17 +2486,17 @@ extern "C" int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, i
                 if ((rc = enqueue_layer_gemms(d, l, S, c, nullptr, d->x, d->x2, 1))) break;
                 continue;
             }
-            if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, c, true, false, xn16))) break;
-            if ((rc = linear(d, w.attn_proj, d->att, d->x, d->h1, S, D, RGRG_ACT_NONE, c, true, false, att16))) break;
-            if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, c, true, false, xn16, ff16))) break;
-            if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->h1, S, D, RGRG_ACT_NONE, c, true, false, ff16))) break;
+            if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, c, xn16))) break;
+            if ((rc = linear(d, w.attn_proj, d->att, d->x, d->h1, S, D, RGRG_ACT_NONE, c, att16))) break;
+            if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, c, xn16, ff16))) break;
+            if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->h1, S, D, RGRG_ACT_NONE, c, ff16))) break;
         }
         if (!rc && fused) {
             DirectArgs h{};
             h.Xf = d->x; h.part = d->part; h.Y = d->logits; h.ldy = d->ld_logits; h.act = RGRG_ACT_NONE;
             rc = direct_linear(d, d->lm_head, h, DX_COMBINE4, S, c, true);
         } else if (!rc) {
-            rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, c, true, true, xn16);
+            rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, c, xn16);
         }
         if (rc) break;
         RGRG_HIP(hipEventRecord(e1, d->stream));

@@ -554,7 +554,27 @@ __global__ __launch_bounds__(256) void bce_logits_masked_kernel(const float* __r
 // The INTER_AREA arithmetic follows OpenCV's resize.cpp for 8-bit down-scaling (third-party, restated: see
 // oracle/preprocess.py): mode 1 = 2x2 integer ((a+b+c+d+2)>>2), mode 2 = integer scales (int sum * float(1/area)),
 // mode 3 = fractional coverage tables (double geometry, float weights, float sums: x in table order, then rows in
-// order), saturate_cast = round half to even.  Compiled with fp contraction off (file pragma).
+// order), saturate_cast = round half to even; mode 4 = an axis is ENLARGED (images smaller than 512 px): OpenCV
+// emulates INTER_AREA with its 8-bit fixed-point bilinear path and the area coordinate rule (s = floor(d * scale),
+// f = (d + 1) - (s + 1) * inv_scale, f <= 0 ? 0 : f - floor(f); short weights x 2048; columns with s + 1 >= width read
+// S[width - 1] * 2048; second row clamped; ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2 >> 2).
+// Compiled with fp contraction off (file pragma).
+struct LinTap { int s; int a0, a1; bool edge; };
+__device__ __forceinline__ LinTap area_linear_tap(int d, int ssize, int dsize) {
+    const double inv_scale = (double)dsize / (double)ssize, scale = 1.0 / inv_scale;
+    LinTap t;
+    t.s = (int)floor((double)d * scale);
+    float f = (float)(((double)d + 1.0) - ((double)t.s + 1.0) * inv_scale);
+    f = f <= 0.f ? 0.f : f - floorf(f);
+    t.edge = t.s + 1 >= ssize;
+    t.a0 = (int)fminf(fmaxf(rintf((1.0f - f) * 2048.0f), -32768.f), 32767.f);
+    t.a1 = (int)fminf(fmaxf(rintf(f * 2048.0f), -32768.f), 32767.f);
+    return t;
+}
+__device__ __forceinline__ int area_linear_hrow(const unsigned char* __restrict__ r, const LinTap& x, int w) {
+    if (x.edge) return (int)r[w - 1] * 2048;   // s >= w - 1 there: fx = 0, sx = w - 1
+    return (int)r[x.s] * x.a0 + (int)r[x.s + 1] * x.a1;
+}
 struct AreaTaps {  // the <= 3 kinds of entries of one destination index: [partial first][full ...][partial last]
     int first, n_full, last;  // source index of the partial-first entry (-1: none), count of full entries, last (-1: none)
     int full0;
@@ -599,6 +619,12 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char*
             for (int j = 0; j < isy; ++j)
                 for (int i = 0; i < isx; ++i) sum += src[(size_t)(y * isy + j) * stride + x * isx + i];
             v = fminf(fmaxf(rintf((float)sum * (1.0f / (float)(isx * isy))), 0.f), 255.f);
+        } else if (mode == 4) {
+            const LinTap tx = area_linear_tap(x, w, nw), ty = area_linear_tap(y, h, nh);
+            const int r0 = min(max(ty.s, 0), h - 1), r1 = min(max(ty.s + 1, 0), h - 1);
+            const int s0 = area_linear_hrow(src + (size_t)r0 * stride, tx, w) >> 4;
+            const int s1 = area_linear_hrow(src + (size_t)r1 * stride, tx, w) >> 4;
+            v = (float)(((((ty.a0 * s0) >> 16) + ((ty.a1 * s1) >> 16) + 2) >> 2) & 0xFF);
         } else {
             const AreaTaps tx = area_taps(x, w, sx), ty = area_taps(y, h, sy);
             float sum = 0.f;
@@ -724,11 +750,11 @@ extern "C" int rgrg_preprocess_u8_f32(const uint8_t* src, int h, int w, int src_
                                       float std, float* dst, void* stream) {
     constexpr int SIZE = 512;
     RGRG_CHECK_ARG(src && dst && h > 0 && w > 0 && src_stride >= w && new_h > 0 && new_w > 0 && new_h <= SIZE && new_w <= SIZE);
-    RGRG_CHECK_ARG(new_h <= h && new_w <= w);  // INTER_AREA up-scaling (inputs smaller than 512) is not implemented
     const double sx = (double)w / new_w, sy = (double)h / new_h;
     const int isx = (int)lround(sx), isy = (int)lround(sy);
     int mode = 3;
     if (new_h == h && new_w == w) mode = 0;
+    else if (!(sx >= 1.0 && sy >= 1.0)) mode = 4;  // an axis is enlarged: OpenCV's bilinear emulation of INTER_AREA
     else if (fabs(sx - isx) < DBL_EPSILON && fabs(sy - isy) < DBL_EPSILON) mode = (isx == 2 && isy == 2) ? 1 : 2;
     const int top = (int)((SIZE - new_h) / 2.0), left = (int)((SIZE - new_w) / 2.0);
     const float mean255 = mean * 255.0f, denom = 1.0f / (std * 255.0f);

@@ -97,14 +97,16 @@ __global__ __launch_bounds__(256) void ln_backward_kernel(const float* __restric
 __global__ __launch_bounds__(256) void ce_backward_kernel(float* __restrict__ logits, size_t ld, int V, int row0,
                                                           const long long* __restrict__ ids, const int* __restrict__ row_valid,
                                                           const float* __restrict__ row_lse, const int* __restrict__ n_scored,
-                                                          float scale) {
+                                                          float scale, const int* __restrict__ id_error) {
     const int r = row0 + blockIdx.x;
     float* x = logits + (size_t)blockIdx.x * ld;
     if (!row_valid[r]) {
         for (int i = threadIdx.x; i < V; i += 256) x[i] = 0.f;
         return;
     }
-    const float lse = row_lse[r], f = scale / (float)(*n_scored);
+    // an invalid token id in this pass (ids were clamped for the loads): the gradients are poisoned like the loss, so an
+    // optimizer step taken before the error is reported cannot apply finite-but-wrong updates
+    const float lse = row_lse[r], f = *id_error ? nanf("") : scale / (float)(*n_scored);
     const int label = (int)ids[r + 1];
     for (int i = threadIdx.x; i < V; i += 256) x[i] = (expf(x[i] - lse) - (i == label ? 1.f : 0.f)) * f;
 }
@@ -568,8 +570,9 @@ int launch_ln_backward(const float* dy, const float* x, const float* g, float* o
     return RGRG_OK;
 }
 int launch_ce_backward(float* logits, size_t ld, int V, int row0, int rows, const long long* ids, const int* row_valid,
-                       const float* row_lse, const int* n_scored, float scale, hipStream_t st) {
-    hipLaunchKernelGGL(ce_backward_kernel, dim3(rows), dim3(256), 0, st, logits, ld, V, row0, ids, row_valid, row_lse, n_scored, scale);
+                       const float* row_lse, const int* n_scored, float scale, const int* id_error, hipStream_t st) {
+    hipLaunchKernelGGL(ce_backward_kernel, dim3(rows), dim3(256), 0, st, logits, ld, V, row0, ids, row_valid, row_lse, n_scored, scale,
+                       id_error);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }

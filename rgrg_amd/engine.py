@@ -229,6 +229,10 @@ class HipEngine:
 
     def close(self):
         if self._decoder is not None:
+            # a token-id error of the last teacher-forced pass that has not been reported yet outlives the decoder
+            pending = C.c_int(0)
+            if self.lib.rgrg_decoder_take_id_error(self._decoder, C.byref(pending)) == 0 and pending.value:
+                self._pending_id_error = True
             self.lib.rgrg_decoder_destroy(self._decoder)
             self._decoder = None
 
@@ -660,6 +664,13 @@ class HipEngine:
                    "rgrg_decoder_beam_search")
         return out[:, :out_len.value].contiguous()
 
+    def _raise_pending_id_error(self) -> None:
+        """An unreported token-id error of a decoder that has been re-created since (close())."""
+        if getattr(self, "_pending_id_error", False):
+            self._pending_id_error = False
+            raise IndexError("index out of range in self: a token id of a previous teacher-forced pass was outside "
+                             f"[0, {self.vocab})")
+
     @staticmethod
     def _check_ids(rc: int, what: str) -> None:
         """Token ids are validated on the device: an out-of-range id poisons that pass's loss (NaN) and is reported by
@@ -684,6 +695,7 @@ class HipEngine:
             raise NotImplementedError("the teacher-forced pass supports sequences of up to 1023 tokens")
         # token ids are range-checked on the device (no host sync here): see embed_seq_ln_kernel
         dec = self._get_decoder(S, 2)
+        self._raise_pending_id_error()
         _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")
         feats = feats.to(torch.float32).contiguous()
         ids = input_ids.to(torch.int64).contiguous()
@@ -710,6 +722,7 @@ class HipEngine:
             raise NotImplementedError("the HIP training pass supports sequences of up to 160 tokens (159 with dropout)")
         # token ids are range-checked on the device (no host sync here): see embed_seq_ln_kernel
         dec = self._get_decoder(S, 2)
+        self._raise_pending_id_error()
         _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")
         feats = feats.detach().to(torch.float32).contiguous()
         ids = input_ids.to(torch.int64).contiguous()
@@ -767,11 +780,3 @@ class HipEngine:
                                                          C.byref(wb), C.byref(kv), C.byref(n)), "rgrg_decoder_time_step_parts")
         return {"ms_gemm": mg.value / iters, "ms_attn": ma.value / iters, "gemm_flops": fl.value, "gemm_weight_bytes": wb.value,
                 "kv_bytes": kv.value, "gemm_launches": n.value}
-
-    def time_decode_gemms(self, S: int, iters: int = 3) -> Tuple[float, float, int]:
-        """(avg ms per decode step spent in the weight-streaming GEMM launches, algorithmic
-        weight bytes per step, launches per step) measured with HIP events on the decoder's stream."""
-        ms, nbytes, n = C.c_float(0), C.c_double(0), C.c_int(0)
-        _hip.check(self.lib.rgrg_decoder_time_gemms(self._decoder, S, iters, C.byref(ms), C.byref(nbytes), C.byref(n)),
-                   "rgrg_decoder_time_gemms")
-        return ms.value / iters, nbytes.value, n.value

@@ -1,5 +1,5 @@
 """GPU image preprocessing equal to ``get_image_tensor`` (src/full_model/generate_reports_for_images.py:129-147;
-SURVEY.md 8(f) rank 4): LongestMaxSize(512, INTER_AREA) -> centred zero PadIfNeeded(512, 512) ->
+SURVEY.md 8(f) rank 4): LongestMaxSize(512, INTER_AREA; images smaller than 512 px are enlarged) -> centred zero PadIfNeeded(512, 512) ->
 Normalize(0.471, 0.302) -> [1, 1, 512, 512] float32, on the HIP kernel ``rgrg_preprocess_u8_f32``.  File decoding
 stays on the host (cv2 if installed, else PIL)."""
 from __future__ import annotations
@@ -23,8 +23,6 @@ def preprocess_image(image, device="cuda") -> torch.Tensor:
     h, w = img.shape
     scale = IMAGE_INPUT_SIZE / float(max(h, w))
     nh, nw = (h, w) if scale == 1.0 else (int(round(h * scale)), int(round(w * scale)))  # py3round, albumentations
-    if scale > 1.0:
-        raise NotImplementedError("images smaller than 512 px (INTER_AREA up-scaling) are not supported")
     nh, nw = max(nh, 1), max(nw, 1)
     src = img.to(dev).contiguous()
     out = torch.empty((1, 1, IMAGE_INPUT_SIZE, IMAGE_INPUT_SIZE), dtype=torch.float32, device=dev)

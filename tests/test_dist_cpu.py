@@ -212,3 +212,25 @@ def test_grad_buckets_allreduce_in_place_on_flat_views():
     assert ret["seed0"] == 0x5EED0001 and ret["seed1"] == 0x5EED0001 + (1 << 40)
     for i, gr in enumerate(ret["grads"]):                      # 2 backward passes x mean over ranks of (rank + 1)(i + 1)
         assert torch.allclose(gr, torch.full_like(gr, 2 * 1.5 * (i + 1)), atol=1e-5)
+
+
+def test_bench_self_spawns_n_ranks_when_no_launcher_is_present():
+    """`python bench.py --gpus N` (no torchrun environment) must start by itself.  The launcher
+    path - re-execution under torch.distributed.run on 127.0.0.1 with a free port, barrier-bracketed timing, the MAX
+    over ranks, generate_sharded's gather and the ONE JSON line from rank 0 - runs here on gloo x 2 with the script's
+    CPU stub model (--stub-cpu: no GPU work, never a measurement)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "3", "--stub-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout                 # exactly one JSON line, from rank 0
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak"
+    assert r["config"]["global_batch"] == 6 and r["config"]["regions_generated"] == 6 * 29
+    assert r["value"] > 0 and abs(r["value"] - 6 * 2 / (r["ms_per_step"] * 2e-3)) < 1e-6 * r["value"]

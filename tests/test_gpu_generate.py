@@ -705,3 +705,69 @@ def test_teacher_forced_pass_validates_token_ids_on_the_device():
         eng.lm_forward(feats, ids, mask)
     _, again = eng.lm_forward(feats, ids, mask)
     assert torch.equal(again, good)
+
+
+@pytest.mark.parametrize("bad", [2 ** 40, -7, 50257])
+def test_teacher_forced_pass_huge_and_negative_ids_are_clamped_everywhere(bad):
+    """the label read of the cross entropy (x[ids[r + 1]]) is clamped like the embedding read - ids far
+    outside the logits row (2**40, negative) must not fault - and the training pass poisons the GRADIENTS as well as
+    the loss, so an optimizer step taken before the error surfaces cannot apply finite-but-wrong updates."""
+    eng = gpu_model("ragged").engine()
+    g = torch.Generator().manual_seed(2)
+    feats = torch.randn((2, 1024), generator=g).to(DEV)
+    ids = torch.randint(0, 50000, (2, 7), generator=g).to(DEV)
+    mask = torch.ones((2, 7), device=DEV)
+    bad_ids = ids.clone()
+    bad_ids[0, 3] = bad           # scored as a label (position 3) and embedded
+    _, loss = eng.lm_forward(feats, bad_ids, mask)
+    torch.cuda.synchronize()
+    assert torch.isnan(loss)
+    with pytest.raises(IndexError):
+        eng.lm_forward(feats, ids, mask)
+    loss, grads = eng.lm_loss_grad(feats, bad_ids, mask)
+    torch.cuda.synchronize()
+    assert torch.isnan(loss) and all(torch.isnan(v).all() for v in grads.values())
+    with pytest.raises(IndexError):
+        eng.lm_loss_grad(feats, ids, mask)
+    loss, grads = eng.lm_loss_grad(feats, ids, mask)
+    assert torch.isfinite(loss) and all(torch.isfinite(v).all() for v in grads.values())
+
+
+def test_id_error_blames_the_right_pass_and_survives_decoder_recreation():
+    """A valid pass queued right behind a bad one (before the error word reaches the host) keeps its finite loss - the
+    per-pass error word is cleared when a pass starts, only the sticky word travels - and an unreported error is not
+    lost when the decoder is re-created for more sequences."""
+    eng = gpu_model("ragged").engine()
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn((2, 1024), generator=g).to(DEV)
+    ids = torch.randint(0, 50000, (2, 6), generator=g).to(DEV)
+    mask = torch.ones((2, 6), device=DEV)
+    _, good = eng.lm_forward(feats, ids, mask)
+    torch.cuda.synchronize()
+    bad_ids = ids.clone()
+    bad_ids[1, 2] = 70000
+    # queue ~50 ms of work in front so that the bad pass has not finished when the next call is issued
+    a = torch.randn((8192, 8192), device=DEV)
+    for _ in range(6):
+        a @ a
+    _, bad = eng.lm_forward(feats, bad_ids, mask)
+    try:
+        _, after = eng.lm_forward(feats, ids, mask)       # usually issued before the mirror landed: runs, finite loss
+        torch.cuda.synchronize()
+        assert torch.equal(after, good)
+        with pytest.raises(IndexError):
+            eng.lm_forward(feats, ids, mask)
+    except IndexError:
+        pass                                              # the mirror had already landed: reported one call earlier
+    assert torch.isnan(bad)
+    _, again = eng.lm_forward(feats, ids, mask)
+    assert torch.equal(again, good)
+    # decoder re-creation with a pending error
+    _, bad = eng.lm_forward(feats, bad_ids, mask)
+    cap = eng._decoder_caps[0]
+    feats_big = torch.randn((cap + 1, 1024), generator=g).to(DEV)
+    ids_big = torch.randint(0, 50000, (cap + 1, 6), generator=g).to(DEV)
+    with pytest.raises(IndexError):
+        eng.lm_forward(feats_big, ids_big, None)
+    _, ok = eng.lm_forward(feats_big, ids_big, None)
+    assert torch.isfinite(ok)

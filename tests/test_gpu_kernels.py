@@ -341,12 +341,14 @@ def test_linear_bf16w(eng, M, N, K, act, res):
 
 
 # ------------------------------------------------------------------------- image preprocessing
-@pytest.mark.parametrize("h,w", [(3056, 2544), (2544, 3056), (1024, 1024), (1536, 1536), (768, 512), (512, 512), (700, 513)])
+@pytest.mark.parametrize("h,w", [(3056, 2544), (2544, 3056), (1024, 1024), (1536, 1536), (768, 512), (512, 512), (700, 513),
+                                 (300, 200), (200, 300), (256, 256), (511, 3), (37, 41)])
 def test_preprocess_matches_the_restated_opencv_pipeline(h, w):
     """rgrg_preprocess_u8_f32 vs oracle/preprocess.py (OpenCV INTER_AREA + albumentations pad/normalize restated; the
     third-party originals are absent -> unpinned): the rounded 8-bit pixel must be identical, so the float output is
     bit-identical.  Shapes cover the general table path (5.97x, portrait and landscape), the integer 2x2 and 3x3 fast
-    paths, a 1.5x scale, no resize, and an odd size."""
+    paths, a 1.5x scale, no resize, an odd size, and images SMALLER than 512 px (round 3: LongestMaxSize enlarges them and
+    OpenCV emulates INTER_AREA with its fixed-point bilinear path - 1.7x, exact 2x, a 3-pixel-wide strip, a tiny image)."""
     import numpy as np
     from oracle import preprocess as P
     from rgrg_amd.preprocess import preprocess_image

@@ -112,6 +112,21 @@ def test_preprocess_oracle_hand_cases():
     for d, _s, a in tab:
         sums[d] += a
     assert np.abs(sums - 1).max() < 1e-6
+    # ENLARGING (an image smaller than 512 px): OpenCV's fixed-point bilinear emulation of INTER_AREA.  2x2 -> 3x3 by hand
+    # (scale 2/3): columns/rows (S0, (S0 + S1) / 2 with weights 1024/1024, S1); vertical pass
+    # (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2 with H = S * 2048 or S0 * 1024 + S1 * 1024:
+    # centre = ((1024 * 6400 >> 16) + (1024 * 29120 >> 16) + 2) >> 2 = (100 + 455 + 2) >> 2 = 139
+    up = P.resize_area_u8(np.array([[0, 100], [200, 255]], np.uint8), 3, 3)
+    assert (up == np.array([[0, 50, 100], [100, 139, 178], [200, 228, 255]])).all()
+    # 300 x 200 -> 512 x 341: pixel (0, 1): s = 0, f = 2 - 341/200 = .295 -> weights 1444 / 604, top row weight 2048:
+    # H = 95 * 1444 + 130 * 604 = 215700 -> ((2048 * (215700 >> 4)) >> 16) + 2 >> 2 = 105
+    im = np.zeros((300, 200), np.uint8)
+    im[0, :2] = (95, 130)
+    big = P.resize_area_u8(im, 512, 341)
+    assert big.shape == (512, 341) and big[0, 0] == 95 and big[0, 1] == 105
+    assert (P.resize_area_u8(np.full((7, 5), 137, np.uint8), 512, 366) == 137).all()      # constants are preserved
+    small = P.get_image_tensor_from_array(np.full((256, 128), 255, np.uint8))               # 2x: 512 x 256, centred
+    assert abs(small[0, 0, 5, 127] + 0.471 / 0.302) < 1e-6 and abs(small[0, 0, 5, 128] - (1 - 0.471) / 0.302) < 1e-6
     # py3round (half to even) decides the short side: 2500 x 2001 -> 512 x 410 (409.8), 3000 x 2010 -> 343.04 -> 343
     assert P.py3round(2001 * 512 / 2500) == 410 and P.py3round(0.5) == 0 and P.py3round(1.5) == 2
 

@@ -35,4 +35,4 @@ if "--decode" in sys.argv:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f"decode S=29 L=128 graph={use_graph}: {dt*1e3:.1f} ms  ({dt/127*1e6:.0f} us/step)", flush=True)
-    print("gemm timing (ms/step, bytes/step, launches):", eng.time_decode_gemms(29, 3))
+    print("step parts:", eng.time_step_parts(29, 65, 3))
