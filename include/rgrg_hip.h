@@ -258,6 +258,17 @@ int rgrg_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* 
 int rgrg_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 int rgrg_linear_bf16w_f32(const float* A, const uint16_t* Wb, const float* shift, const float* R, float* Y, int M,
                           int N, int K, int ldy, int act, void* stream);
+/* The same product with BOTH operands already bf16 in device memory (A16 [M,K], Wb [N,K], K % 256 == 0): the
+ * LDS-DMA kernel of the opt-in bf16 decode / box-head paths (operands go HBM -> LDS without touching registers, 4 LDS
+ * stages in flight across the barriers).  fp32 accumulate; epilogue shift [N] / residual R fp32 [M,ldy] / activation
+ * in fp32; the result is stored as fp32 (Y) or as bf16 (Y16, feeds the next GEMM) - exactly one of them non-NULL. */
+int rgrg_linear_bf16_f32(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
+                         uint16_t* Y16, int M, int N, int K, int ldy, int act, void* stream);
+/* Measurement hook (tools/gemm_bf16_bench.py): the LDS-DMA kernel with a forced configuration: tile = shape + 16 * stages
+ * (shape 0 heuristic, 1 128x128, 2 64x64, 3 128x64, 4 64x128; stages 0 = 4, or 2 / 3 / 4 LDS stages) and operand row
+ * pitches lda / ldw in elements (0 = K). */
+int rgrg_debug_linear_bf16_tile(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
+                                int M, int N, int K, int ldy, int act, int tile, int lda, int ldw, void* stream);
 /* ---- detector targets and losses: ObjectDetector.forward(images, targets), the detector half of
  * ReportGenerationModel.forward(images, image_targets, ...) (src/full_model/report_generation_model.py:55,91 ->
  * src/object_detector/object_detector.py:216-224 -> custom_rpn.py:74-83, custom_roi_heads.py:225-242, and underneath

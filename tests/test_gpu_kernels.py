@@ -340,6 +340,46 @@ def test_linear_bf16w(eng, M, N, K, act, res):
     close(y, ref, 2e-5, 2e-6, f"bf16w linear {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K,act,res,out16", [(923, 3072, 1024, 0, False, False), (923, 1024, 4096, 0, True, False),
+                                                   (923, 4096, 1024, 2, False, True), (129, 50257, 1024, 0, False, False),
+                                                   (70, 192, 256, 0, True, False), (300, 1000, 768, 2, False, False),
+                                                   (1, 64, 256, 0, False, False)])
+def test_linear_bf16_lds_dma_kernel(eng, M, N, K, act, res, out16):
+    """Round-3 LDS-DMA GEMM (both operands bf16 in HBM, `buffer_load ... lds`, 4 stages across raw barriers, XOR-swizzled
+    LDS rows): against a float64 reference on the same bf16 operands.  Shapes: the four decode projections at the
+    configs[2] row count (923: ragged last row tile; 128x128 and 64x64 tile paths), the vocabulary edge (50257 columns:
+    ragged last column tile), tiny / odd shapes, K = 256 (the shortest pipeline: prologue + tail only), bf16 output."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn((M, K), generator=g)
+    W = torch.randn((N, K), generator=g) / math.sqrt(K)
+    b = torch.randn((N,), generator=g)
+    R = torch.randn((M, N), generator=g) if res else None
+    ref = A.bfloat16().double() @ W.bfloat16().double().t() + b.double()
+    if res:
+        ref = ref + R.double()
+    ref = {0: lambda x: x, 2: lambda x: F.gelu(x, approximate="tanh")}[act](ref)
+    A16 = A.bfloat16().view(torch.int16).to(DEV)
+    Wb = W.bfloat16().view(torch.int16).to(DEV)
+    bd = b.to(DEV)
+    Rd = R.to(DEV) if res else None
+    y = torch.empty((M, N), device=DEV)
+    y16 = torch.empty((M, N), dtype=torch.int16, device=DEV)
+    _hip.check(eng.lib.rgrg_linear_bf16_f32(A16.data_ptr(), Wb.data_ptr(), bd.data_ptr(), Rd.data_ptr() if res else None,
+                                            None if out16 else y.data_ptr(), y16.data_ptr() if out16 else None, M, N, K, N, act,
+                                            _stream()))
+    if out16:
+        assert torch.equal(y16.cpu().view(torch.bfloat16), ref.float().bfloat16()) or \
+            (y16.cpu().view(torch.bfloat16).double() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+    else:
+        close(y, ref, 2e-5, 2e-6, f"bf16 LDS-DMA linear {M}x{N}x{K}")
+    tol = (2e-5, 2e-6) if act == 0 else (2e-5, 4e-6)  # GELU on the hardware exp2 / rcp (~1e-7 relative to tanhf)
+    for tile in [shape + 16 * nst for shape in (1, 2, 3, 4) for nst in (2, 3, 4)]:   # every tile shape x stage count
+        y2 = torch.empty((M, N), device=DEV)
+        _hip.check(eng.lib.rgrg_debug_linear_bf16_tile(A16.data_ptr(), Wb.data_ptr(), bd.data_ptr(), Rd.data_ptr() if res else None,
+                                                       y2.data_ptr(), M, N, K, N, act, tile, 0, 0, _stream()))
+        close(y2, ref, tol[0], tol[1], f"bf16 LDS-DMA linear {M}x{N}x{K} tile {tile}")
+
+
 # ------------------------------------------------------------------------- image preprocessing (SURVEY 8(f) rank 4)
 @pytest.mark.parametrize("h,w", [(3056, 2544), (2544, 3056), (1024, 1024), (1536, 1536), (768, 512), (512, 512), (700, 513),
                                  (300, 200), (200, 300), (256, 256), (511, 3), (37, 41)])
