@@ -1339,7 +1339,8 @@ struct rgrg_decoder {
     // beam search
     int *src_a, *src_b, *beam_tok, *beam_parent, *cand_tok, *cand_beam, *top_tok;
     float *beam_scores, *row_max, *row_logsum, *top_val, *cand_score;
-    int* h_done;  // pinned
+    int* h_done;  // pinned: [0] final read, [1..2] the two in-flight "all finished" polls of the greedy loop
+    hipEvent_t ev_poll[2] = {nullptr, nullptr};
     // Token-id validation of the teacher-forced passes, without a host round trip.  id_error[0]: raised by the CURRENT
     // pass (embedding / cross-entropy kernels) when an id is outside [0, vocab), cleared when a pass starts - it poisons
     // THAT pass's loss and gradients (NaN).  id_error[1]: sticky "some pass failed and has not been reported yet",
@@ -1540,6 +1541,9 @@ static int direct_linear(rgrg_decoder* d, const Lin& l, DirectArgs a, int mode, 
     hipStream_t st = d->stream;
     if (l.lnf && mode == DX_COMBINE4 && l.NT > 512 && mt == 1) {  // lm_head, one row tile: persistent kernel
         hipLaunchKernelGGL((rgrg_skinny_direct_wide_f32<DX_COMBINE4, true>), dim3(256), blk, 0, st, a);
+    } else if (!l.lnf && mode == DX_PLAIN && l.KS == 1 && mt == 1 && l.NT <= 64 && M > 16 && !cand) {
+        // attn_proj': few column tiles, MFMA bound -> one row half per workgroup (2 x NT workgroups)
+        hipLaunchKernelGGL(rgrg_skinny_direct_half_f32, dim3(l.NT, 2), blk, 0, st, a);
     } else {
 #define DX_LAUNCH(MT_, MODE_, LNF_) hipLaunchKernelGGL((rgrg_skinny_direct_f32<MT_, MODE_, LNF_>), grid, blk, 0, st, a)
 #define DX_MODES(MT_)                                                                        \
@@ -1721,7 +1725,9 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
         return RGRG_EHIP;
     }
     if (hipHostMalloc((void**)&d->h_id_error, sizeof(int), 0) == hipSuccess) *d->h_id_error = 0;
-    if (hipHostMalloc((void**)&d->h_done, sizeof(int), 0) != hipSuccess) {
+    if (hipHostMalloc((void**)&d->h_done, 4 * sizeof(int), 0) != hipSuccess ||
+        hipEventCreateWithFlags(&d->ev_poll[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&d->ev_poll[1], hipEventDisableTiming) != hipSuccess) {
         set_error("decoder: hipHostMalloc failed");
         delete d;
         return RGRG_EHIP;
@@ -1805,6 +1811,8 @@ extern "C" void rgrg_decoder_destroy(rgrg_decoder* d) {
     tf_free(d);
     tr_free(d);
     if (d->h_done) (void)hipHostFree(d->h_done);
+    for (hipEvent_t e : d->ev_poll)
+        if (e) (void)hipEventDestroy(e);
     if (d->h_id_error) (void)hipHostFree(d->h_id_error);
     if (d->ev_in) (void)hipEventDestroy(d->ev_in);
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -1840,6 +1848,13 @@ extern "C" int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S,
     }
     const int steps = limit - 1;
     int done = 0;
+    // "every row has emitted EOS" is polled WITHOUT draining the pipeline: every 16 steps the device-side length word is
+    // copied to a pinned slot behind the step that produced it, and the host then waits for the copy it queued 16 steps
+    // EARLIER - so 16 steps are always queued behind the one it waits for (round 2 synchronised the stream here: a
+    // bubble of an idle GPU + a relaunch every 16 steps), and the host never runs more than 32 steps ahead; after the
+    // last row finishes at most 32 more steps run, which only write PAD behind the recorded length.
+    int polls = 0;
+    d->h_done[1] = d->h_done[2] = 0;
     for (int t = 0; t < steps; ++t) {
         if (exec) {
             RGRG_HIP(hipGraphLaunch(exec, d->stream));
@@ -1847,10 +1862,16 @@ extern "C" int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S,
             rc = enqueue_step(d, S, t == 0);
             if (rc) return rc;
         }
-        if ((t & 15) == 15 && t + 1 < steps) {  // poll "all finished" every 16 steps
-            RGRG_HIP(hipMemcpyAsync(d->h_done, d->done_len, sizeof(int), hipMemcpyDeviceToHost, d->stream));
-            RGRG_HIP(hipStreamSynchronize(d->stream));
-            if (*d->h_done) { done = *d->h_done; break; }
+        if ((t & 15) == 15 && t + 1 < steps) {
+            if (polls > 0) {
+                const int prev = (polls - 1) & 1;
+                RGRG_HIP(hipEventSynchronize(d->ev_poll[prev]));
+                if (d->h_done[1 + prev]) break;
+            }
+            const int cur = polls & 1;
+            RGRG_HIP(hipMemcpyAsync(d->h_done + 1 + cur, d->done_len, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+            RGRG_HIP(hipEventRecord(d->ev_poll[cur], d->stream));
+            ++polls;
         }
     }
     RGRG_HIP(hipMemcpyAsync(d->h_done, d->done_len, sizeof(int), hipMemcpyDeviceToHost, d->stream));
