@@ -1450,6 +1450,8 @@ static int skinny_attr() {
 }
 static int init_skinny_attrs() {
     int rc;
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_lm_head_wave_f32<DX_COMBINE4>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LMH_LDS));
     if ((rc = skinny_attr<4>())) return rc;
     if ((rc = skinny_attr<8>())) return rc;
     RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_skinny_gemm_f32_wide),
@@ -1539,8 +1541,8 @@ static int direct_linear(rgrg_decoder* d, const Lin& l, DirectArgs a, int mode, 
     const int mt = (M + PAD_ROWS - 1) / PAD_ROWS;
     const dim3 grid(l.NT, l.KS), blk(64 * SK_WAVES);
     hipStream_t st = d->stream;
-    if (l.lnf && mode == DX_COMBINE4 && l.NT > 512 && mt == 1) {  // lm_head, one row tile: persistent kernel
-        hipLaunchKernelGGL((rgrg_skinny_direct_wide_f32<DX_COMBINE4, true>), dim3(256), blk, 0, st, a);
+    if (l.lnf && mode == DX_COMBINE4 && l.NT > 512 && mt == 1 && l.K == DK_SLICE) {  // lm_head, one row tile: a wave per column tile
+        hipLaunchKernelGGL((rgrg_lm_head_wave_f32<DX_COMBINE4>), dim3(256), blk, LMH_LDS, st, a);
     } else if (!l.lnf && mode == DX_PLAIN && l.KS == 1 && mt == 1 && l.NT <= 64 && M > 16 && !cand) {
         // attn_proj': few column tiles, MFMA bound -> one row half per workgroup (2 x NT workgroups)
         hipLaunchKernelGGL(rgrg_skinny_direct_half_f32, dim3(l.NT, 2), blk, 0, st, a);
