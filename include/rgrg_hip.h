@@ -170,7 +170,7 @@ int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S, int max_le
                           int out_ld, int* out_len, int use_graph, void* stream);
 /* Beam search (LanguageModel.generate num_beams > 1 -> beam_search, language_model.py:450-475,
  * :529-607, with transformers 4.19.2 BeamSearchScorer semantics; 1 <= num_return_sequences <= num_beams).
- * The decoder must have been created with max_seqs >= S*num_beams; 2*num_beams <= 16.
+ * The decoder must have been created with max_seqs >= S*num_beams; num_beams <= 16.
  * Device side: one decode step over the S*num_beams beam rows (KV cache never re-ordered:
  * per-slot ancestor table), per-row log-sum-exp + top-2*num_beams, per-item merge.  Host
  * side (one small D2H/H2D per step, like the reference's scorer): hypothesis bookkeeping.
@@ -225,6 +225,19 @@ int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, const int64_t
  * flat element index i of the site's tensor ([S*T,1024] for sites 0/2/3, [S,16,T,T+1] for the attention probabilities);
  * stream_id = layer*4 + site. */
 int rgrg_dropout_mask_f32(uint64_t seed, uint32_t stream_id, float p, int64_t n, float* out, void* stream);
+/* Replaces the INCREMENTAL form of LanguageModel.forward - use_cache=True with or without past_key_values
+ * (src/language_model/language_model.py:258-366, :396-399), the call the reference's own generate loop makes every step -
+ * over this decoder's pre-allocated K/V cache instead of concatenated tensors.  past_len = number of tokens already in the
+ * cache (0: feats [S,1024] must be given, the image key / value goes to slot 0, :135-157; > 0: feats must be NULL).  The T
+ * tokens input_ids [S,T] (int64) are fed at positions past_len .. past_len + T - 1 (wte[token] + wte[position], the
+ * position_ids the reference's prepare_inputs_for_generation passes, :498-520), each appending its key / value;
+ * logits_out f32 [S,T,vocab] receives lm_logits of every fed position.  past_len + T <= the decoder's max_len.  All-ones
+ * attention mask (generation).  Runs on the decoder's stream between two event edges with `stream`. */
+int rgrg_decoder_forward_cached(rgrg_decoder* d, const float* feats, const int64_t* input_ids, int S, int T, int past_len,
+                                float* logits_out, void* stream);
+/* Device address and geometry of one cache plane (layer, kv = 0 key / 1 value): f32 [max_seqs][16][slots][64]; the host
+ * wraps rows [:S], slots [:1 + tokens] as the `presents` views of forward(use_cache=True) - no copy. */
+int rgrg_decoder_cache_plane(rgrg_decoder* d, int layer, int kv, void** ptr, int* max_seqs, int* slots, int* is_bf16);
 /* Token ids of the two teacher-forced entries above are validated ON THE DEVICE (no host round trip per call): an id
  * outside [0, vocab) is clamped for every load (embedding row, cross-entropy label), the loss AND the gradients of that
  * pass come out as NaN, and the NEXT decoder call that finds the (asynchronously mirrored) error word set fails with

@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256) void decode_reset_kernel(long long* __restrict
 }
 
 // ------------------------------------------------------------------ beam search kernels
-constexpr int BEAM_K = 16;  // max 2*num_beams candidates per row
+constexpr int BEAM_K = 32;  // max 2*num_beams candidates per row (num_beams <= 16)
 
 // Per beam row: max, log-sum-exp and the top-K (value desc, token asc on ties) logits.
 // log_softmax is monotonic within a row, so the row's best continuations are its top logits.
@@ -889,14 +889,15 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
 
 // Per batch item: log_softmax + beam score for the nb*K row candidates, then the top K = 2*nb
 // of the item (score desc; ties: lower flat index beam*V + token first) - language_model.py:545-561.
-__global__ __launch_bounds__(128) void beam_merge_kernel(const float* __restrict__ row_max, const float* __restrict__ row_logsum,
+constexpr int BEAM_MERGE_THREADS = BEAM_K * BEAM_K / 2;  // one thread per candidate: nb * 2 nb <= 512
+__global__ __launch_bounds__(BEAM_MERGE_THREADS) void beam_merge_kernel(const float* __restrict__ row_max, const float* __restrict__ row_logsum,
                                                          const float* __restrict__ top_val, const int* __restrict__ top_tok,
                                                          const float* __restrict__ beam_scores, int nb, int K, int V,
                                                          float* __restrict__ out_score, int* __restrict__ out_tok,
                                                          int* __restrict__ out_beam) {
-    // n = nb * 2 nb candidates (<= 128 for nb <= 8): one thread each, ranked against all others through LDS
-    __shared__ float ssc[128];
-    __shared__ long long sflat[128];
+    // n = nb * 2 nb candidates (<= 512 for nb <= 16): one thread each, ranked against all others through LDS
+    __shared__ float ssc[BEAM_MERGE_THREADS];
+    __shared__ long long sflat[BEAM_MERGE_THREADS];
     const int item = blockIdx.x, tid = threadIdx.x;
     const int n = nb * K;
     float sc = -INFINITY;
@@ -1963,7 +1964,7 @@ extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int
                 if (!rc) {
                     hipLaunchKernelGGL(beam_row_topk_kernel, dim3(R), dim3(256), 0, st, d->logits, d->ld_logits, d->V, K,
                                        d->row_max, d->row_logsum, d->top_val, d->top_tok);
-                    hipLaunchKernelGGL(beam_merge_kernel, dim3(S), dim3(128), 0, st, d->row_max, d->row_logsum, d->top_val,
+                    hipLaunchKernelGGL(beam_merge_kernel, dim3(S), dim3(BEAM_MERGE_THREADS), 0, st, d->row_max, d->row_logsum, d->top_val,
                                        d->top_tok, d->beam_scores, nb, K, d->V, d->cand_score, d->cand_tok, d->cand_beam);
                 }
                 hipError_t e = hipStreamEndCapture(st, &graph);
@@ -2055,6 +2056,23 @@ extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int
     *out_len = L;
     return RGRG_OK;
 }
+
+namespace rgrg {
+__global__ void set_int_kernel(int* p, int v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *p = v;
+}
+// incremental forward: the tokens of input position j (clamped into the vocabulary) -> the step's token-override buffer,
+// and the step counter = the position (cache slot position + 1, embedding row wte[position])
+__global__ __launch_bounds__(256) void forward_cached_tokens_kernel(const long long* __restrict__ ids, int T, int j, int S, int V,
+                                                                    int* __restrict__ tok, int* __restrict__ step, int position) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s < S) {
+        const long long t = ids[(size_t)s * T + j];
+        tok[s] = (int)(t < 0 ? 0 : (t >= V ? V - 1 : t));
+    }
+    if (s == 0) *step = position;
+}
+}  // namespace rgrg
 
 // ------------------------------------------------------------------ teacher-forced pass (host side)
 namespace rgrg {
@@ -2422,6 +2440,48 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
     return RGRG_OK;
 }
 
+// LanguageModel.forward(input_ids, ..., past_key_values, use_cache=True) (language_model.py:258-366, :396-399): the
+// incremental form the reference's own generate loop is built on, over THIS decoder's K/V cache.  past_len == 0: the image
+// key / value is computed from feats and stored in slot 0 (past_key_values=None, :135-157); then the T tokens of every row
+// are fed one position at a time (position = past_len + j; wte[token] + wte[position], :298-307), each appending its
+// key / value to the cache; logits_out [S, T, vocab] receives lm_head of every fed position.  No arg-max, no EOS bookkeeping.
+extern "C" int rgrg_decoder_forward_cached(rgrg_decoder* d, const float* feats, const int64_t* input_ids, int S, int T, int past_len,
+                                           float* logits_out, void* stream) {
+    RGRG_CHECK_ARG(d && input_ids && logits_out && S > 0 && S <= d->max_seqs && T >= 1 && past_len >= 0);
+    RGRG_CHECK_ARG((past_len == 0) == (feats != nullptr));
+    RGRG_CHECK_ARG(past_len + T <= d->max_len);   // slot of the last token = past_len + T <= T_cache - 1
+    hipStream_t caller = as_stream(stream), st = d->stream;
+    RGRG_HIP(hipEventRecord(d->ev_in, caller));
+    RGRG_HIP(hipStreamWaitEvent(st, d->ev_in, 0));
+    int rc;
+    if (past_len == 0 && (rc = enqueue_prefill(d, feats, S))) return rc;   // also resets the step counter to 0
+    for (int j = 0; j < T; ++j) {
+        hipLaunchKernelGGL(forward_cached_tokens_kernel, dim3((S + 255) / 256), dim3(256), 0, st,
+                           reinterpret_cast<const long long*>(input_ids), T, j, S, d->V, d->beam_tok, d->step, past_len + j);
+        RGRG_LAUNCH_CHECK();
+        if ((rc = enqueue_step(d, S, false, d->beam_tok, nullptr, true))) return rc;   // ... lm_head: logits, nothing else
+        RGRG_HIP(hipMemcpy2DAsync(logits_out + (size_t)j * d->V, (size_t)T * d->V * sizeof(float), d->logits,
+                                  (size_t)d->ld_logits * sizeof(float), (size_t)d->V * sizeof(float), S, hipMemcpyDeviceToDevice, st));
+    }
+    hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, st, d->step, past_len + T);
+    RGRG_LAUNCH_CHECK();
+    RGRG_HIP(hipEventRecord(d->ev_in, st));
+    RGRG_HIP(hipStreamWaitEvent(caller, d->ev_in, 0));
+    return RGRG_OK;
+}
+
+// Where the cache of layer `layer` lives: K (kv = 0) or V (kv = 1) plane [max_seqs][16][max_len + 1][64] fp32 (bf16 in the
+// opt-in many-sequence mode: *is_bf16); slots 0 .. past_len of a row are valid.  The host wraps these as the `presents`
+// views forward(use_cache=True) returns - no copy.
+extern "C" int rgrg_decoder_cache_plane(rgrg_decoder* d, int layer, int kv, void** ptr, int* max_seqs, int* slots, int* is_bf16) {
+    RGRG_CHECK_ARG(d && ptr && layer >= 0 && layer < d->n_layer && (kv == 0 || kv == 1));
+    *ptr = d->kv + (size_t)layer * d->kv_layer_stride + (size_t)kv * d->kv_kv_stride;
+    if (max_seqs) *max_seqs = d->max_seqs;
+    if (slots) *slots = d->T;
+    if (is_bf16) *is_bf16 = 0;   // forward_cached always runs the fp32 path (rows <= 128 or fp32 mode)
+    return RGRG_OK;
+}
+
 extern "C" int rgrg_decoder_take_id_error(rgrg_decoder* d, int* pending) {
     RGRG_CHECK_ARG(d && pending);
     RGRG_HIP(hipStreamSynchronize(d->stream));
@@ -2493,12 +2553,6 @@ extern "C" int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S,
     RGRG_HIP(hipStreamSynchronize(as_stream(stream)));
     return RGRG_OK;
 }
-
-namespace rgrg {
-__global__ void set_int_kernel(int* p, int v) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *p = v;
-}
-}  // namespace rgrg
 
 // Live timing of the two kernel families of one decode step, each as `iters` back-to-back replays of ITS launches of
 // one step (24 layers [+ lm_head]) between one pair of HIP events on the decoder's stream:

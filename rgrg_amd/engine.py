@@ -766,6 +766,66 @@ class HipEngine:
         if self._decoder is not None:
             _hip.check(self.lib.rgrg_decoder_refresh_trainable(self._decoder, self._s()), "rgrg_decoder_refresh_trainable")
 
+    def forward_cached(self, feats: Optional[Tensor], input_ids: Tensor, past_len: int, cache_len: int = 1024):
+        """LanguageModel.forward(use_cache=True[, past_key_values]) over the decoder's K/V cache (rgrg_decoder_forward_cached):
+        feeds input_ids [S,T] at positions past_len .. past_len + T - 1 -> (logits f32 [S,T,V], presents) where presents is
+        the reference's tuple of 24 (key, value) pairs, each a VIEW [S,16,1 + past_len + T,64] of the cache."""
+        S, T = input_ids.shape
+        if past_len == 0:
+            if feats is None or feats.shape[0] != S:
+                raise ValueError("image_hidden_states [S,1024] is needed when past_key_values is None")
+            _require_gpu(feats.device)
+            dec = self._get_decoder(S, max(cache_len, T))
+            self._cached = {"S": S, "tokens": 0}
+        else:
+            c = getattr(self, "_cached", None)
+            if self._decoder is None or c is None or c["S"] != S or c["tokens"] != past_len:
+                raise NotImplementedError("past_key_values must be the presents returned by the previous forward(use_cache=True) "
+                                          "of this model (the cache lives in the HIP decoder)")
+            dec = self._decoder
+        if past_len + T > self._decoder_caps[1]:
+            raise NotImplementedError(f"the K/V cache holds {self._decoder_caps[1]} tokens; sequence of {past_len + T} requested")
+        _hip.check(self.lib.rgrg_decoder_set_precision(dec, 0), "rgrg_decoder_set_precision")
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        f = None if past_len else feats.to(torch.float32).contiguous()
+        logits = torch.empty((S, T, self.vocab), dtype=torch.float32, device=self.device)
+        _hip.check(self.lib.rgrg_decoder_forward_cached(dec, _hip.ptr(f), _hip.ptr(ids), S, T, int(past_len), _hip.ptr(logits), self._s()),
+                   "rgrg_decoder_forward_cached")
+        self._cached["tokens"] = past_len + T
+        return logits, self._cache_views(dec, S, 1 + past_len + T)
+
+    def _cache_views(self, dec, S: int, n_keys: int):
+        class _Plane:
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (ptr, False), "version": 2}
+        out = []
+        for l in range(self.n_layer):
+            pair = []
+            for kv in (0, 1):
+                ptr, ms, slots, b16 = C.c_void_p(), C.c_int(0), C.c_int(0), C.c_int(0)
+                _hip.check(self.lib.rgrg_decoder_cache_plane(dec, l, kv, C.byref(ptr), C.byref(ms), C.byref(slots), C.byref(b16)),
+                           "rgrg_decoder_cache_plane")
+                t = torch.as_tensor(_Plane(ptr.value, (ms.value, 16, slots.value, 64)), device=self.device)
+                pair.append(t[:S, :, :n_keys])
+            out.append(tuple(pair))
+        return tuple(out)
+
+    def owns_cache(self, past_key_values) -> Optional[int]:
+        """Number of tokens cached if ``past_key_values`` are this decoder's own presents (as returned by the previous
+        forward_cached), else None."""
+        c = getattr(self, "_cached", None)
+        if self._decoder is None or c is None or past_key_values is None:
+            return None
+        try:
+            k0 = past_key_values[0][0]
+            ptr = C.c_void_p()
+            _hip.check(self.lib.rgrg_decoder_cache_plane(self._decoder, 0, 0, C.byref(ptr), None, None, None), "rgrg_decoder_cache_plane")
+            if k0.data_ptr() == ptr.value and k0.shape[0] == c["S"] and k0.shape[-2] == 1 + c["tokens"] and len(past_key_values) == self.n_layer:
+                return c["tokens"]
+        except Exception:  # noqa: BLE001
+            return None
+        return None
+
     def last_logits(self, S: int) -> Tensor:
         dst = torch.empty((S, self.vocab), dtype=torch.float32, device=self.device)
         _hip.check(self.lib.rgrg_decoder_copy_last_logits(self._decoder, _hip.ptr(dst), S, self._s()), "copy_last_logits")

@@ -138,8 +138,7 @@ class LanguageModel(EngineOwner):
         ``use_cache=True`` form belongs to the reference's own generate loop; here ``generate()`` owns the cache.
         In ``train()`` mode with gradients enabled the returned loss carries a ``grad_fn`` (HIP backward pass)."""
         if past_key_values is not None or use_cache:
-            raise NotImplementedError("incremental forward(use_cache=True / past_key_values) is internal to generate() "
-                                      "in the HIP path; call generate()")
+            return self._forward_cached(input_ids, attention_mask, image_hidden_states, return_loss, past_key_values, position_ids)
         if position_ids is not None:
             T = input_ids.shape[-1]
             if not torch.equal(position_ids.view(-1, T).cpu(), torch.arange(T).view(1, T).expand(position_ids.view(-1, T).shape[0], T)):
@@ -160,6 +159,40 @@ class LanguageModel(EngineOwner):
             _, loss = self.engine().lm_forward(image_hidden_states, ids2, am2, want_logits=False, want_loss=True, bf16=bool(low))
         ids2[~am2.to(torch.bool)] = -100  # the reference's in-place label write (labels IS input_ids)
         return loss
+
+    @torch.no_grad()
+    def _forward_cached(self, input_ids, attention_mask, image_hidden_states, return_loss, past_key_values, position_ids):
+        """The incremental form (language_model.py:258-366, :396-399): ``forward(..., use_cache=True)`` returns
+        ``(lm_logits [S,T,50257], presents)``; ``presents`` - 24 (key, value) pairs [S,16,1+tokens,64], the image key / value
+        in slot 0 - are zero-copy VIEWS of the HIP decoder's pre-allocated cache, and feeding them back as
+        ``past_key_values`` continues on that cache (the reference concatenates new tensors every step).  Limits, all
+        raised: the presents must come from the previous call of this model (no foreign / re-ordered tensors), positions
+        are the token indices (what prepare_inputs_for_generation passes, :498-520; with ``position_ids=None`` and a past
+        the reference counts the image key as a position, :298-300 - pass the ids), no padding inside the prompt, eval
+        mode, no loss."""
+        if return_loss or self.training:
+            raise NotImplementedError("forward(use_cache=True) is the generation form: eval mode, return_loss=False")
+        self.sync_trainable_if_stale()
+        ids2 = input_ids.view(-1, input_ids.shape[-1])
+        S, T = ids2.shape
+        eng = self.engine()
+        if past_key_values is None:
+            past = 0
+        else:
+            past = eng.owns_cache(past_key_values)
+            if past is None:
+                raise NotImplementedError("past_key_values must be the presents returned by the previous forward(use_cache=True) of "
+                                          "this model, unmodified (the cache lives in the HIP decoder)")
+        if attention_mask is not None and not bool((attention_mask.reshape(S, -1) != 0).all()):
+            raise NotImplementedError("forward(use_cache=True) supports the all-ones attention mask of generation only")
+        expect = torch.arange(past, past + T)
+        if position_ids is None:
+            if past != 0:
+                raise NotImplementedError("pass position_ids = token indices with past_key_values (the reference's default would "
+                                          "count the image key as a position)")
+        elif not torch.equal(position_ids.reshape(-1, T).cpu(), expect.view(1, T).expand(position_ids.reshape(-1, T).shape[0], T)):
+            raise NotImplementedError("position_ids must be the token indices arange(past_tokens, past_tokens + seq_len)")
+        return eng.forward_cached(image_hidden_states if past == 0 else None, ids2, past)
 
     def trainable_parameters(self):
         """uk/uv of every layer, then feature_space_transformation_nn: the language-model tensors the reference
@@ -225,8 +258,8 @@ class LanguageModel(EngineOwner):
                 raise ValueError("'num_return_sequences' has to be smaller or equal to 'num_beams'.")
             if max_length is None:
                 raise ValueError("max_length has to be set for beam generation.")
-            if 2 * num_beams > 16:
-                raise NotImplementedError("the HIP beam search supports num_beams <= 8")
+            if num_beams > 16:
+                raise NotImplementedError("the HIP beam search supports num_beams <= 16")
             # length_penalty = 1.0 as in the reference (language_model.py:461)
             low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
             return self.engine().beam_search(image_hidden_states, max_length, num_beams, early_stopping, 1.0, bf16=bool(low),

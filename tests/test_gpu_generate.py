@@ -787,3 +787,54 @@ def test_id_error_blames_the_right_pass_and_survives_decoder_recreation():
         eng.lm_forward(feats_big, ids_big, None)
     _, ok = eng.lm_forward(feats_big, ids_big, None)
     assert torch.isfinite(ok)
+
+
+def test_incremental_forward_with_use_cache_reproduces_the_oracles_cached_steps():
+    """forward(..., use_cache=True[, past_key_values]) (language_model.py:258-366, :396-399) over the HIP decoder's cache:
+    a 3-token prompt, then single tokens with the returned presents fed back - logits of every call vs the oracle's
+    lm_forward with a concatenated cache (2e-3), presents are views of the cache with the reference's shapes and hold the
+    oracle's keys / values; a hand-rolled greedy loop on top of forward() reproduces generate()."""
+    m = gpu_model("ragged")
+    lm = m.language_model
+    sd = synth_sd("ragged")
+    g = torch.Generator().manual_seed(21)
+    feats = torch.randn((3, 1024), generator=g)
+    prompt = torch.randint(0, 50000, (3, 3), generator=g)
+    nxt = [torch.randint(0, 50000, (3, 1), generator=g) for _ in range(2)]
+    # oracle: prompt, then two cached steps
+    o_logits, o_past = o_lm.lm_forward(sd, prompt, torch.ones((3, 3), dtype=torch.int64), feats, None, torch.arange(3)[None, :])
+    logits, presents = lm(prompt.to(DEV), torch.ones((3, 3), device=DEV), feats.to(DEV), return_loss=False, use_cache=True)
+    assert logits.shape == (3, 3, 50257) and len(presents) == 24 and presents[0][0].shape == (3, 16, 4, 64)
+    assert (logits.cpu() - o_logits).abs().max().item() <= 2e-3
+    ntok = 3
+    for step_ids in nxt:
+        am = torch.ones((3, ntok + 1), dtype=torch.int64)
+        o_logits, o_past = o_lm.lm_forward(sd, step_ids, am, feats, o_past, torch.full((3, 1), ntok))
+        logits, presents = lm(step_ids.to(DEV), am.to(DEV), feats.to(DEV), return_loss=False, past_key_values=presents,
+                              position_ids=torch.full((3, 1), ntok), use_cache=True)
+        ntok += 1
+        assert logits.shape == (3, 1, 50257) and presents[5][1].shape == (3, 16, ntok + 1, 64)
+        assert (logits.cpu() - o_logits).abs().max().item() <= 2e-3
+    for l in (0, 11, 23):
+        assert (presents[l][0].cpu() - o_past[l][0]).abs().max().item() <= 2e-3
+        assert (presents[l][1].cpu() - o_past[l][1]).abs().max().item() <= 2e-3
+    # foreign / re-ordered past tensors are refused, loudly
+    with pytest.raises(NotImplementedError, match="presents returned by the previous"):
+        lm(nxt[0].to(DEV), torch.ones((3, ntok + 1), device=DEV), feats.to(DEV), past_key_values=tuple((k.clone(), v.clone()) for k, v in presents),
+           position_ids=torch.full((3, 1), ntok), use_cache=True)
+    # greedy loop written against forward(), as the reference's greedy_search does (:609-652)
+    f5 = _lm_feats().to(DEV)
+    ref = lm.generate(f5, max_length=10)
+    ids = torch.full((5, 1), 50256, dtype=torch.int64, device=DEV)
+    past, unfinished = None, torch.ones((5,), dtype=torch.int64, device=DEV)
+    while True:
+        cur = ids.shape[1]
+        inp = ids if past is None else ids[:, -1:]
+        pos = torch.arange(cur)[None, :] if past is None else torch.full((5, 1), cur - 1)
+        lg, past = lm(inp, torch.ones((5, cur), device=DEV), f5, return_loss=False, past_key_values=past, position_ids=pos, use_cache=True)
+        tok = lg[:, -1].argmax(-1) * unfinished + 50256 * (1 - unfinished)
+        ids = torch.cat([ids, tok[:, None]], dim=1)
+        unfinished = unfinished * (tok != 50256).long()
+        if unfinished.max() == 0 or ids.shape[1] >= 10:
+            break
+    assert torch.equal(ids, ref)

@@ -59,9 +59,10 @@ def test_many_sequences_fp32_path_over_more_steps():
     assert int(bad.sum()) == 0, bad.nonzero().flatten().tolist()
 
 
-@pytest.mark.parametrize("nb", [6, 8])
+@pytest.mark.parametrize("nb", [6, 8, 16])
 def test_beam_search_wide_beams(nb):
-    """2 * nb * nb candidates per item exceed one wave for nb >= 6: ranked through LDS by 128 threads."""
+    """2 * nb * nb candidates per item exceed one wave for nb >= 6: ranked through LDS, one thread per
+    candidate (512 at the round-3 limit of 16 beams)."""
     m = gpu_model("ragged")
     feats = _feats(3, 34)
     ref = o_lm.beam_generate(synth_sd("ragged"), feats, 10, nb, early_stopping=False)
