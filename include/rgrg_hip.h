@@ -94,6 +94,12 @@ int rgrg_rpn_proposals_f32(const float* head_out, const float* anchors, float* p
 int rgrg_roi_align_avgpool_f32(const float* feat, const float* proposals, const int32_t* offsets, float* out,
                                float* pooled, int B, int FH, int FW, int C, int max_props, int R_total,
                                float spatial_scale, void* stream);
+/* The same with the [R, 64, C] maps stored as bf16 (round to nearest even; pooled stays f32 from unrounded values): what
+ * the box head consumes under torch.autocast (generate_reports_for_images.py:108) - fc6 then runs on
+ * rgrg_linear_bf16_f32 with half the A bytes. */
+int rgrg_roi_align_avgpool_bf16maps(const float* feat, const float* proposals, const int32_t* offsets, uint16_t* out16,
+                                    float* pooled, int B, int FH, int FW, int C, int max_props, int R_total,
+                                    float spatial_scale, void* stream);
 
 /* CustomRoIHeads.get_top_region_features_detections_class_detected
  * (custom_roi_heads.py:63-208), eval: pred [R, ldp] holds 30 class logits then 120
@@ -269,6 +275,17 @@ int rgrg_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* 
 /* fp32 -> bf16 (round to nearest even), and Y = act(bf16(A) Wb^T + shift + R) on v_mfma_f32_32x32x16_bf16
  * (A fp32 [M,K], Wb bf16 [N,K], K % 64 == 0). */
 int rgrg_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
+int rgrg_bf16_to_f32(const uint16_t* src, float* dst, int64_t n, void* stream);   /* exact widening */
+/* Replaces nn.Conv2d + eval BatchNorm2d (+ residual add) + ReLU of the ResNet-50 bottlenecks and the RPNHead convs
+ * (src/object_detector/object_detector.py:51-62,219; custom_rpn.py:61) WHEN THE CALLER RUNS UNDER torch.autocast
+ * (generate_reports_for_images.py:108: the reference's detector then computes in half precision): implicit GEMM on
+ * v_mfma_f32_32x32x16_bf16, fp32 accumulation and epilogue.
+ *   X16 [B,H,W,Cin] bf16 NHWC, Cin % 64 == 0, with 128 ZERO elements in front of it in memory (X16[-128..-1] == 0:
+ *       the line padding taps read); Wb [Cout][KH][KW][Cin] bf16 with the BatchNorm scale folded in; shift f32 [Cout] or
+ *       NULL; R16 bf16 [B,OH,OW,Cout] or NULL; the result goes to Y (f32) or Y16 (bf16), exactly one non-NULL. */
+int rgrg_conv2d_nhwc_bf16(const uint16_t* X16, const uint16_t* Wb, const float* shift, const uint16_t* R16, float* Y,
+                          uint16_t* Y16, int B, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                          int act, void* stream);
 int rgrg_linear_bf16w_f32(const float* A, const uint16_t* Wb, const float* shift, const float* R, float* Y, int M,
                           int N, int K, int ldy, int act, void* stream);
 /* The same product with BOTH operands already bf16 in device memory (A16 [M,K], Wb [N,K], K % 256 == 0): the

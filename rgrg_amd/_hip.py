@@ -16,7 +16,7 @@ c_float_p = C.c_void_p  # device pointers travel as void*
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p
 
 ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
-ABI_VERSION = 6  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
+ABI_VERSION = 7  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
 
 
 class RgrgHipError(RuntimeError):
@@ -45,6 +45,7 @@ SIGNATURES = {
     "rgrg_maxpool3x3s2_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "rgrg_rpn_proposals_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p]),
     "rgrg_roi_align_avgpool_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "rgrg_roi_align_avgpool_bf16maps": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "rgrg_top1_per_class_f32": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p]),
     "rgrg_select_regions_f32": (_i, [_p, _p, _f, _p, _p, _p, _i, _p]),
     "rgrg_bce_with_logits_masked_f32": (_i, [_p, _p, _p, C.c_float, _i, _p, _p]),
@@ -68,6 +69,8 @@ SIGNATURES = {
     "rgrg_bce_with_logits_masked_backward_f32": (_i, [_p, _p, _p, C.c_float, _i, C.c_float, _p, _i, _p]),
     "rgrg_adamw_step_f32": (_i, [_p, _p, _p, _p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _p]),
     "rgrg_f32_to_bf16": (_i, [_p, _p, C.c_int64, _p]),
+    "rgrg_bf16_to_f32": (_i, [_p, _p, C.c_int64, _p]),
+    "rgrg_conv2d_nhwc_bf16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rgrg_linear_bf16w_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rgrg_linear_bf16_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rgrg_debug_linear_bf16_tile": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -315,9 +315,18 @@ struct RoiTables {
     f32x4 y[16];
     f32x4 x[16];
 };
+__device__ __forceinline__ unsigned roi_bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
 constexpr int ROI_THREADS = 1024;  // 16 waves per CU hide the LDS latency of the 16-tap gathers
 constexpr int ROI_SUB = 32;        // RoIs per sub-chunk = 32-lane groups per workgroup: all processed concurrently
 
+// OUT16: the [roi][bin][channel] maps are stored as bf16 (round to nearest even) - under torch.autocast the box head
+// runs in reduced precision, and fc6 (81 % of the detector's FLOPs) then reads its A operand through the LDS-DMA GEMM at
+// half the bytes; the 8x8 average (top_region_features) is still formed from the unrounded values.
+template <bool OUT16>
 __global__ __launch_bounds__(ROI_THREADS) void roi_align_avg_kernel(const float* __restrict__ feat,
                                                             const float* __restrict__ proposals,
                                                             const int* __restrict__ offsets, float* __restrict__ out,
@@ -371,7 +380,9 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_avg_kernel(const float*
         for (int rr = grp; rr < ns; rr += ROI_THREADS / 32) {
             const RoiTables& T = tabs[rr];
             const int r = s0 + rr;
-            float* obase = out + (size_t)(off + r) * 64 * C + slab_i * 128 + c4 * 4;
+            const size_t oidx = (size_t)(off + r) * 64 * C + slab_i * 128 + c4 * 4;
+            float* obase = out + oidx;
+            unsigned short* obase16 = reinterpret_cast<unsigned short*>(out) + oidx;
             f32x4 total = {0.f, 0.f, 0.f, 0.f};
             for (int ph = 0; ph < 8; ++ph) {
                 f32x4 psum = {0.f, 0.f, 0.f, 0.f};
@@ -403,7 +414,14 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_avg_kernel(const float*
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { acc[e] = acc[e] / 4.0f; psum[e] += acc[e]; }
-                    *reinterpret_cast<f32x4*>(obase + (size_t)(ph * 8 + pw) * C) = acc;
+                    if constexpr (OUT16) {
+                        uint2 pk;
+                        pk.x = roi_bf16_rne(acc[0]) | (roi_bf16_rne(acc[1]) << 16);
+                        pk.y = roi_bf16_rne(acc[2]) | (roi_bf16_rne(acc[3]) << 16);
+                        *reinterpret_cast<uint2*>(obase16 + (size_t)(ph * 8 + pw) * C) = pk;
+                    } else {
+                        *reinterpret_cast<f32x4*>(obase + (size_t)(ph * 8 + pw) * C) = acc;
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) total[e] += psum[e];  // row sums added in row order (same association as before)
@@ -694,16 +712,18 @@ extern "C" int rgrg_rpn_proposals_f32(const float* head_out, const float* anchor
     return RGRG_OK;
 }
 
-extern "C" int rgrg_roi_align_avgpool_f32(const float* feat, const float* proposals, const int32_t* offsets, float* out,
-                                          float* pooled, int B, int FH, int FW, int C, int max_props, int R_total,
-                                          float spatial_scale, void* stream) {
+static int roi_align_launch(const float* feat, const float* proposals, const int32_t* offsets, void* out, bool out16,
+                            float* pooled, int B, int FH, int FW, int C, int max_props, int R_total,
+                            float spatial_scale, void* stream) {
     RGRG_CHECK_ARG(feat && proposals && offsets && out && pooled && B > 0 && C % 128 == 0);
     const size_t lds = (size_t)FH * FW * 128 * 4 + ROI_SUB * sizeof(RoiTables);
     RGRG_CHECK_ARG(lds <= 160 * 1024);
     if (R_total <= 0) return RGRG_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_avg_kernel),
+        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_avg_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_avg_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -711,10 +731,26 @@ extern "C" int rgrg_roi_align_avgpool_f32(const float* feat, const float* propos
     // chunks of <= 32 RoIs (one per 32-lane group); chunks beyond an image's RoI count exit immediately
     int nchunk = (max_props + ROI_SUB - 1) / ROI_SUB;
     if (nchunk < 1) nchunk = 1;
-    hipLaunchKernelGGL(roi_align_avg_kernel, dim3(slabs, nchunk, B), dim3(ROI_THREADS), lds, as_stream(stream), feat, proposals,
-                       offsets, out, pooled, FH, FW, C, max_props, spatial_scale);
+    if (out16)
+        hipLaunchKernelGGL(roi_align_avg_kernel<true>, dim3(slabs, nchunk, B), dim3(ROI_THREADS), lds, as_stream(stream), feat, proposals,
+                           offsets, reinterpret_cast<float*>(out), pooled, FH, FW, C, max_props, spatial_scale);
+    else
+        hipLaunchKernelGGL(roi_align_avg_kernel<false>, dim3(slabs, nchunk, B), dim3(ROI_THREADS), lds, as_stream(stream), feat, proposals,
+                           offsets, reinterpret_cast<float*>(out), pooled, FH, FW, C, max_props, spatial_scale);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
+}
+
+extern "C" int rgrg_roi_align_avgpool_f32(const float* feat, const float* proposals, const int32_t* offsets, float* out,
+                                          float* pooled, int B, int FH, int FW, int C, int max_props, int R_total,
+                                          float spatial_scale, void* stream) {
+    return roi_align_launch(feat, proposals, offsets, out, false, pooled, B, FH, FW, C, max_props, R_total, spatial_scale, stream);
+}
+
+extern "C" int rgrg_roi_align_avgpool_bf16maps(const float* feat, const float* proposals, const int32_t* offsets, uint16_t* out16,
+                                               float* pooled, int B, int FH, int FW, int C, int max_props, int R_total,
+                                               float spatial_scale, void* stream) {
+    return roi_align_launch(feat, proposals, offsets, out16, true, pooled, B, FH, FW, C, max_props, R_total, spatial_scale, stream);
 }
 
 extern "C" int rgrg_top1_per_class_f32(const float* pred, int ldp, const float* proposals, const int32_t* offsets,

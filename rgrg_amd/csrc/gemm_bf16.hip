@@ -28,6 +28,10 @@ struct GemmBf16Params {
     u16* Y16;          // non-null: the result is stored as bf16 [M, ldy] instead of fp32 (feeds the next GEMM only)
     int M, N, K, ldy, act;
     int lda = 0, ldw = 0;  // row pitch of A16 / Wb in elements (0 = K); LDS-DMA kernel only
+    // LDS-DMA kernel, implicit-GEMM convolution (CONV instantiation): A16 = X [B,H,W,Cin] bf16 NHWC, PRECEDED IN MEMORY BY
+    // 128 ZERO ELEMENTS (the line padding taps read); row m = output pixel (b, oy, ox), K = KH * KW * Cin (tap major)
+    int cH = 0, cW = 0, cCin = 0, cKH = 0, cKW = 0, cStride = 1, cPad = 0, cOH = 0, cOW = 0;
+    const u16* R16 = nullptr;  // residual as bf16 [M, ldy] (CONV: the bottleneck's identity branch)
 };
 
 constexpr int BK16 = 64;                 // k per tile
@@ -274,14 +278,14 @@ __device__ __forceinline__ float apply_act_fast(float v, int act) {
 // are built here from the tile's base pointers - loop-invariant scalar work that hipcc hoists)
 template <int BM, int LA, int LB, int TAG>
 __device__ __forceinline__ void glds_issue(const u16* abase, const u16* wbase, unsigned char* sb,
-                                           const int (&va)[LA], const int (&vb)[LB], int koff) {
+                                           const int (&va)[LA], const int (&vb)[LB], int koff_a, int koff_w) {
     const __amdgpu_buffer_rsrc_t ra = bf16_rsrc(abase), rb = bf16_rsrc(wbase);
 #pragma unroll
     for (int j = 0; j < LA; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(sb + j * 4096), 16, va[j], koff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(sb + j * 4096), 16, va[j], koff_a, 0, 0);
 #pragma unroll
     for (int j = 0; j < LB; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(sb + BM * 128 + j * 4096), 16, vb[j], koff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(sb + BM * 128 + j * 4096), 16, vb[j], koff_w, 0, 0);
 }
 
 // the MFMAs of one wave on one staged K tile (4 K steps of 16): sa / sw = the wave's first A / W row in the stage
@@ -319,7 +323,11 @@ __device__ __forceinline__ void glds_compute(const unsigned char* sa, const unsi
     __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
 }
 
-template <int BM, int BN, int NST>
+// CONV: the A operand is the im2col view of an NHWC bf16 image - row m of a K tile = 64 channels [c0, c0 + 64) of input pixel
+// (oy * stride + kh - pad, ox * stride + kw - pad): still one contiguous 128-byte line per row, so the LDS-DMA path is
+// unchanged; only the per-lane source offset is recomputed per K tile (tap = kt * 64 / Cin, a handful of integer
+// instructions), and taps outside the image read the zero line that precedes the tensor.
+template <int BM, int BN, int NST, bool CONV>
 __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Params p, const int mtiles, const int ntiles) {
     constexpr int BK = 64;
     constexpr int MI = BM / 64, NI = BN / 64;   // 32x32 MFMA blocks per wave
@@ -341,23 +349,50 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
     const int m0 = tm * BM, n0 = tn * BN;
     const int nk = p.K / BK;
     const int lda = p.lda ? p.lda : p.K, ldw = p.ldw ? p.ldw : p.K;
-    const u16* abase = p.A16 + (size_t)m0 * lda;   // buffer descriptors are rebased to the tile
+    // buffer descriptors are rebased to the tile; CONV: to the zero line in front of the image (offsets are absolute)
+    const u16* abase = CONV ? p.A16 - 128 : p.A16 + (size_t)m0 * lda;
     const u16* wbase = p.Wb + (size_t)n0 * ldw;
     // per-lane source offsets (bytes) of this wave's LDS-DMA instructions: lane -> (row = lane / 8, LDS chunk = lane % 8)
     const int lrow = lane >> 3, lch = lane & 7;
     int va[LA], vb[LB];
+    int cy0[LA], cx0[LA], cpix[LA], cswz[LA];   // CONV: top-left input coordinate, first pixel of the image, swizzled chunk
 #pragma unroll
     for (int j = 0; j < LA; ++j) {
         const int row = (j * 4 + wave) * 8 + lrow;
-        va[j] = min(row, p.M - 1 - m0) * lda * 2 + ((lch ^ ((row >> 1) & 7)) << 4);
+        if constexpr (CONV) {
+            const int m = min(m0 + row, p.M - 1);
+            const int b = m / (p.cOH * p.cOW), rem = m - b * (p.cOH * p.cOW);
+            const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
+            cy0[j] = oy * p.cStride - p.cPad;
+            cx0[j] = ox * p.cStride - p.cPad;
+            cpix[j] = b * p.cH * p.cW;
+            cswz[j] = (lch ^ ((row >> 1) & 7)) << 4;
+            va[j] = 0;
+        } else {
+            va[j] = min(row, p.M - 1 - m0) * lda * 2 + ((lch ^ ((row >> 1) & 7)) << 4);
+        }
     }
 #pragma unroll
     for (int j = 0; j < LB; ++j) {
         const int row = (j * 4 + wave) * 8 + lrow;
         vb[j] = min(row, p.N - 1 - n0) * ldw * 2 + ((lch ^ ((row >> 1) & 7)) << 4);
     }
-#define RGRG_GLDS_ISSUE(STAGE_, KT_) \
-    glds_issue<BM, LA, LB, NST>(abase, wbase, glds_smem + (STAGE_) * STAGE + wave * 1024, va, vb, (KT_) * (BK * 2))
+#define RGRG_GLDS_ISSUE(STAGE_, KT_)                                                                                   \
+    {                                                                                                                  \
+        if constexpr (CONV) {                                                                                          \
+            const int kbeg_ = (KT_) * BK, tap_ = kbeg_ / p.cCin, c0_ = kbeg_ - tap_ * p.cCin;                          \
+            const int kh_ = tap_ / p.cKW, kw_ = tap_ - kh_ * p.cKW;                                                    \
+            _Pragma("unroll") for (int j = 0; j < LA; ++j) {                                                           \
+                const int iy_ = cy0[j] + kh_, ix_ = cx0[j] + kw_;                                                      \
+                const bool in_ = (unsigned)iy_ < (unsigned)p.cH && (unsigned)ix_ < (unsigned)p.cW;                     \
+                va[j] = (in_ ? 256 + (cpix[j] + iy_ * p.cW + ix_) * p.cCin * 2 + c0_ * 2 : 0) + cswz[j];               \
+            }                                                                                                          \
+            glds_issue<BM, LA, LB, NST * 2 + 1>(abase, wbase, glds_smem + (STAGE_) * STAGE + wave * 1024, va, vb, 0, (KT_) * (BK * 2)); \
+        } else {                                                                                                       \
+            glds_issue<BM, LA, LB, NST * 2>(abase, wbase, glds_smem + (STAGE_) * STAGE + wave * 1024, va, vb, (KT_) * (BK * 2),       \
+                                            (KT_) * (BK * 2));                                                         \
+        }                                                                                                              \
+    }
     // fragment read offsets: lane -> (row = lane & 31, k half = lane >> 5) of a 32-row block; 4 K steps of 16
     const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 1) & 7;
     int foff[4];
@@ -425,6 +460,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
                     rv[r] = p.R[(size_t)row * p.ldy + colc];
                 }
             }
+            if (p.R16) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+                    rv[r] = __uint_as_float((unsigned)p.R16[(size_t)row * p.ldy + colc] << 16);
+                }
+            }
             if (col < p.N) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -469,7 +511,9 @@ static int bf16_attr() {
 
 template <int BM, int BN, int NST>
 static int glds_attr() {
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST>),
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, NST * (BM + BN) * 128));
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, NST * (BM + BN) * 128));
     return RGRG_OK;
 }
@@ -493,8 +537,12 @@ int init_gemm_bf16_attrs() {
 template <int BM, int BN, int NST>
 static int launch_glds_cfg(const GemmBf16Params& p, hipStream_t st) {
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, NST>), dim3(mtiles * ntiles), dim3(256), NST * (BM + BN) * 128, st, p, mtiles,
-                       ntiles);
+    if (p.cCin)
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, NST, true>), dim3(mtiles * ntiles), dim3(256), NST * (BM + BN) * 128, st, p,
+                           mtiles, ntiles);
+    else
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, NST, false>), dim3(mtiles * ntiles), dim3(256), NST * (BM + BN) * 128, st, p,
+                           mtiles, ntiles);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
@@ -519,7 +567,8 @@ static int launch_glds(const GemmBf16Params& p, int tile, hipStream_t st) {
     int shape = tile & 15, nst = tile >> 4;
     if (shape == 0) {
         const long tiles_big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-        if (tiles_big >= 1024) { shape = 1; nst = 2; }
+        if (p.N <= 64) { shape = 3; nst = 2; }            // a 64-channel conv: no point in a 128-wide column tile
+        else if (tiles_big >= 1024) { shape = 1; nst = 2; }
         else if (p.K > 1024) { shape = 2; nst = 4; }
         else if (tiles_big >= 256) { shape = 3; nst = 3; }
         else if (tiles_big >= 128) { shape = 2; nst = 3; }
@@ -554,6 +603,11 @@ int launch_gemm_bf16w(const float* A, const void* Wb, const float* shift, const 
     return launch_gemm_bf16w_ex(A, nullptr, Wb, shift, R, Y, nullptr, M, N, K, ldy, act, st);
 }
 
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const u16* __restrict__ src, float* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = __uint_as_float((unsigned)src[i] << 16);
+}
+
 int convert_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st) {
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, st, src, reinterpret_cast<u16*>(dst), n);
@@ -568,6 +622,14 @@ using namespace rgrg;
 extern "C" int rgrg_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream) {
     RGRG_CHECK_ARG(src && dst && n > 0);
     return convert_f32_to_bf16(src, dst, (size_t)n, as_stream(stream));
+}
+
+extern "C" int rgrg_bf16_to_f32(const uint16_t* src, float* dst, int64_t n, void* stream) {
+    RGRG_CHECK_ARG(src && dst && n > 0);
+    const int blocks = (int)(((size_t)n + 255) / 256 < 4096 ? ((size_t)n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, (size_t)n);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
 }
 
 extern "C" int rgrg_linear_bf16w_f32(const float* A, const uint16_t* Wb, const float* shift, const float* R, float* Y,
@@ -593,4 +655,28 @@ extern "C" int rgrg_debug_linear_bf16_tile(const uint16_t* A16, const uint16_t* 
     RGRG_CHECK_ARG((lda == 0 || lda >= K) && (ldw == 0 || ldw >= K));
     GemmBf16Params p{nullptr, A16, Wb, shift, R, Y, nullptr, M, N, K, ldy, act, lda, ldw};
     return launch_glds(p, tile, as_stream(stream));
+}
+
+// nn.Conv2d (+ folded eval BatchNorm + residual + ReLU) as an implicit GEMM on the bf16 matrix core, for the detector
+// under torch.autocast (the reference runs trunk / RPN in half precision there, generate_reports_for_images.py:108).
+//   X16 [B,H,W,Cin] bf16 NHWC with 128 zero elements in front of it (X16[-128 .. -1] == 0), Cin % 64 == 0
+//   Wb  [Cout][KH][KW][Cin] bf16 (BatchNorm scale folded in), shift [Cout] f32 (bias / folded BatchNorm shift) or NULL
+//   R16 [B,OH,OW,Cout] bf16 or NULL; exactly one of Y (f32) / Y16 (bf16) [B,OH,OW,Cout]
+extern "C" int rgrg_conv2d_nhwc_bf16(const uint16_t* X16, const uint16_t* Wb, const float* shift, const uint16_t* R16, float* Y,
+                                     uint16_t* Y16, int B, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                     int act, void* stream) {
+    int rc = init_gemm_bf16_attrs();
+    if (rc) return rc;
+    RGRG_CHECK_ARG(X16 && Wb && ((Y != nullptr) != (Y16 != nullptr)) && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cin % 64 == 0);
+    RGRG_CHECK_ARG(Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+    RGRG_CHECK_ARG((size_t)B * H * Wd * Cin * 2 + 256 < ((size_t)1 << 31));   // 32-bit byte offsets into the image
+    GemmBf16Params p{};
+    p.A16 = X16; p.Wb = Wb; p.shift = shift; p.R16 = R16; p.Y = Y; p.Y16 = Y16;
+    p.cH = H; p.cW = Wd; p.cCin = Cin; p.cKH = KH; p.cKW = KW; p.cStride = stride; p.cPad = pad;
+    p.cOH = (H + 2 * pad - KH) / stride + 1;
+    p.cOW = (Wd + 2 * pad - KW) / stride + 1;
+    RGRG_CHECK_ARG(p.cOH > 0 && p.cOW > 0);
+    p.M = B * p.cOH * p.cOW; p.N = Cout; p.K = KH * KW * Cin; p.ldy = Cout; p.act = act;
+    RGRG_CHECK_ARG((size_t)128 * p.K * 2 < ((size_t)1 << 31));
+    return launch_glds(p, 0, as_stream(stream));
 }

@@ -288,12 +288,71 @@ class HipEngine:
             x = self.conv(o, blk["c3"], _hip.ACT_RELU, residual=idt)
         return x
 
-    def rpn(self, feat: Tensor, return_head: bool = False):
+    # ------------------------------------------------------------------ detector under torch.autocast (bf16 matrix core)
+    def _act16(self, shape) -> Tensor:
+        """bf16 activation buffer (int16 bits) with the 128 zero elements in front of it that rgrg_conv2d_nhwc_bf16 reads
+        for padding taps; the returned view keeps the whole allocation alive."""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        buf = torch.empty((n + 128,), dtype=torch.int16, device=self.device)
+        buf[:128].zero_()
+        return buf[128:].view(*shape)
+
+    def _conv16_weights(self, c: _Conv):
+        """[Cout][KH][KW][Cin] bf16 with the eval-BatchNorm scale folded in (alpha o W, then rounded once) + the f32 shift."""
+        if getattr(c, "w16", None) is None:
+            w = c.w if c.scale is None else c.w * c.scale.view(-1, 1, 1, 1)
+            c.w16 = torch.empty(w.shape, dtype=torch.int16, device=w.device)
+            _hip.check(self.lib.rgrg_f32_to_bf16(_hip.ptr(w.contiguous()), _hip.ptr(c.w16), w.numel(), self._s()), "rgrg_f32_to_bf16")
+        return c.w16
+
+    def conv16(self, x16: Tensor, c: _Conv, act: int, residual16: Optional[Tensor] = None, out_f32: bool = False) -> Tensor:
+        """nn.Conv2d + eval BatchNorm2d + residual + ReLU on bf16 NHWC activations (rgrg_conv2d_nhwc_bf16)."""
+        B, H, W, Cin = x16.shape
+        assert Cin == c.cin and Cin % 64 == 0
+        OH = (H + 2 * c.pad - c.kh) // c.stride + 1
+        OW = (W + 2 * c.pad - c.kw) // c.stride + 1
+        y = torch.empty((B, OH, OW, c.cout), dtype=torch.float32, device=x16.device) if out_f32 else self._act16((B, OH, OW, c.cout))
+        _hip.check(self.lib.rgrg_conv2d_nhwc_bf16(_hip.ptr(x16), _hip.ptr(self._conv16_weights(c)), _hip.ptr(c.shift), _hip.ptr(residual16),
+                                                  _hip.ptr(y) if out_f32 else None, None if out_f32 else _hip.ptr(y), B, H, W, Cin, c.cout,
+                                                  c.kh, c.kw, c.stride, c.pad, act, self._s()), "rgrg_conv2d_nhwc_bf16")
+        return y
+
+    def backbone16(self, images: Tensor):
+        """The trunk under autocast: stem + max-pool in fp32 (one input channel: 1 % of the FLOPs), the 16 bottlenecks as
+        bf16 implicit GEMMs with fp32 accumulation, activations stored as bf16 -> (feat16 [B,16,16,2048] bf16,
+        feat fp32 NHWC for RoIAlign / the caller)."""
+        B, Cc, H, W = images.shape
+        assert Cc == 1
+        x = images.reshape(B, H, W).contiguous()
+        y = torch.empty((B, H // 2, W // 2, 64), dtype=torch.float32, device=x.device)
+        _hip.check(self.lib.rgrg_stem_conv7x7_f32(_hip.ptr(x), _hip.ptr(self.stem_w), _hip.ptr(self.stem_scale),
+                                                  _hip.ptr(self.stem_shift), _hip.ptr(y), B, H, W, self._s()), "stem")
+        p = torch.empty((B, H // 4, W // 4, 64), dtype=torch.float32, device=x.device)
+        _hip.check(self.lib.rgrg_maxpool3x3s2_nhwc_f32(_hip.ptr(y), _hip.ptr(p), B, H // 2, W // 2, 64, self._s()), "maxpool")
+        x16 = self._act16(p.shape)
+        _hip.check(self.lib.rgrg_f32_to_bf16(_hip.ptr(p), _hip.ptr(x16), p.numel(), self._s()), "rgrg_f32_to_bf16")
+        del y, p
+        for blk in self.blocks:
+            o = self.conv16(x16, blk["c1"], _hip.ACT_RELU)
+            o = self.conv16(o, blk["c2"], _hip.ACT_RELU)
+            idt = self.conv16(x16, blk["ds"], _hip.ACT_NONE) if "ds" in blk else x16
+            x16 = self.conv16(o, blk["c3"], _hip.ACT_RELU, residual16=idt)
+        feat = torch.empty(x16.shape, dtype=torch.float32, device=x16.device)
+        _hip.check(self.lib.rgrg_bf16_to_f32(_hip.ptr(x16), _hip.ptr(feat), x16.numel(), self._s()), "rgrg_bf16_to_f32")
+        return x16, feat
+
+    def rpn(self, feat: Tensor, return_head: bool = False, feat16: Optional[Tensor] = None):
         """RPN head + proposal filtering -> proposals [B,1000,4], counts [B], offsets [B+1] (device)
         (+ the raw head output [B,FH,FW,800] = objectness | deltas when ``return_head``: the RPN losses read it)."""
         B, FH, FW, _ = feat.shape
-        t = self.conv(feat, self.rpn_conv, _hip.ACT_RELU)
-        head = self.conv(t, self.rpn_head, _hip.ACT_NONE)  # [B,FH,FW,800]
+        if feat16 is not None:  # autocast: the 3x3 conv (20 GFLOP / image) and the fused 1x1 heads on the bf16 matrix core
+            t = self.conv16(feat16, self.rpn_conv, _hip.ACT_RELU)
+            head = self.conv16(t, self.rpn_head, _hip.ACT_NONE, out_f32=True)
+        else:
+            t = self.conv(feat, self.rpn_conv, _hip.ACT_RELU)
+            head = self.conv(t, self.rpn_head, _hip.ACT_NONE)  # [B,FH,FW,800]
         props = torch.empty((B, RPN_POST_NMS_TOP_N, 4), dtype=torch.float32, device=feat.device)
         counts = torch.empty((B,), dtype=torch.int32, device=feat.device)
         offsets = torch.empty((B + 1,), dtype=torch.int32, device=feat.device)
@@ -323,20 +382,26 @@ class HipEngine:
         boxes = torch.zeros((B, NUM_REGIONS, 4), dtype=torch.float32, device=dev)
         feats = torch.zeros((B, NUM_REGIONS, Cf), dtype=torch.float32, device=dev)
         if R > 0:
-            pooled_maps = torch.empty((R, 64, Cf), dtype=torch.float32, device=dev)
+            low = bf16 and R > 128
             pooled = torch.empty((R, Cf), dtype=torch.float32, device=dev)
             scale = 2.0 ** round(__import__("math").log2(FH / IMAGE_INPUT_SIZE))
-            _hip.check(self.lib.rgrg_roi_align_avgpool_f32(_hip.ptr(feat), _hip.ptr(props), _hip.ptr(offsets),
-                                                           _hip.ptr(pooled_maps), _hip.ptr(pooled), B, FH, FW, Cf,
-                                                           props.shape[1], R, scale, self._s()), "rgrg_roi_align")
-            if bf16 and R > 128:
-                # torch.autocast in the reference runs box_head in half precision: fc6 (81 % of the detector's FLOPs,
-                # custom_roi_heads.py:235) on the bf16 MFMA, fp32 accumulate / bias / ReLU
+            if low:
+                # torch.autocast in the reference runs box_head in half precision: RoIAlign stores its [R, 64, C] maps as
+                # bf16 (half of the 524 KB per RoI it writes and fc6 re-reads) and fc6 (81 % of the detector's FLOPs,
+                # custom_roi_heads.py:235) runs on the LDS-DMA bf16 GEMM, fp32 accumulate / bias / ReLU
+                pooled_maps = torch.empty((R, 64, Cf), dtype=torch.int16, device=dev)
+                _hip.check(self.lib.rgrg_roi_align_avgpool_bf16maps(_hip.ptr(feat), _hip.ptr(props), _hip.ptr(offsets),
+                                                                    _hip.ptr(pooled_maps), _hip.ptr(pooled), B, FH, FW, Cf,
+                                                                    props.shape[1], R, scale, self._s()), "rgrg_roi_align")
                 h = torch.empty((R, self.fc6_w.shape[0]), dtype=torch.float32, device=dev)
-                _hip.check(self.lib.rgrg_linear_bf16w_f32(_hip.ptr(pooled_maps), _hip.ptr(self._fc6_bf16()), _hip.ptr(self.fc6_b), None,
-                                                          _hip.ptr(h), R, self.fc6_w.shape[0], 64 * Cf, self.fc6_w.shape[0],
-                                                          _hip.ACT_RELU, self._s()), "rgrg_linear_bf16w_f32")
+                _hip.check(self.lib.rgrg_linear_bf16_f32(_hip.ptr(pooled_maps), _hip.ptr(self._fc6_bf16()), _hip.ptr(self.fc6_b), None,
+                                                         _hip.ptr(h), None, R, self.fc6_w.shape[0], 64 * Cf, self.fc6_w.shape[0],
+                                                         _hip.ACT_RELU, self._s()), "rgrg_linear_bf16_f32")
             else:
+                pooled_maps = torch.empty((R, 64, Cf), dtype=torch.float32, device=dev)
+                _hip.check(self.lib.rgrg_roi_align_avgpool_f32(_hip.ptr(feat), _hip.ptr(props), _hip.ptr(offsets),
+                                                               _hip.ptr(pooled_maps), _hip.ptr(pooled), B, FH, FW, Cf,
+                                                               props.shape[1], R, scale, self._s()), "rgrg_roi_align")
                 h = self.linear(pooled_maps.view(R, 64 * Cf), self.fc6_w, self.fc6_b, _hip.ACT_RELU)
             h = self.linear(h, self.fc7_w, self.fc7_b, _hip.ACT_RELU)
             pred = self.linear(h, self.pred_w, self.pred_b)  # [R,150]: 30 class logits | 120 deltas
@@ -375,18 +440,23 @@ class HipEngine:
         """ObjectDetector.forward in eval mode: -> (detections, top_region_features, class_detected) or, with
         ``targets`` (list of {"boxes" [n,4], "labels" [n]} per image), (losses, detections, top_region_features,
         class_detected) where - as in the reference - the RoI heads then run on the SAMPLED training proposals.
-        bf16 (opt-in through torch.autocast): fc6 on the bf16 MFMA; trunk, RPN, RoIAlign, post-processing stay fp32."""
+        bf16 (opt-in through torch.autocast, like the reference's scripts): bottlenecks, RPN convs and fc6 on the bf16 matrix core
+        with fp32 accumulation, RoIAlign maps stored as bf16; stem, proposals / NMS, fc7, predictor, post-processing stay fp32."""
         _require_gpu(images.device)
         images = images.to(torch.float32)
-        feat = self.backbone(images)
+        feat16 = None
+        if bf16:
+            feat16, feat = self.backbone16(images)
+        else:
+            feat = self.backbone(images)
         if targets is None:
-            props, counts, offsets = self.rpn(feat)
+            props, counts, offsets = self.rpn(feat, feat16=feat16)
             cd, scores, boxes, top = self.roi_heads(feat, props, offsets, taps, bf16)
             if taps is not None:
                 taps.update(features_nhwc=feat, proposals=props, counts=counts, offsets=offsets)
             return {"top_region_boxes": boxes, "top_scores": scores}, top, cd
         perm_fn = perm_fn or (lambda n, tag: torch.randperm(n, device=images.device))
-        props, counts, offsets, head = self.rpn(feat, return_head=True)
+        props, counts, offsets, head = self.rpn(feat, return_head=True, feat16=feat16)
         gt, gt_count, gt_labels = self._pad_targets(targets, images.device)
         loss_obj, loss_rpn_box = self._rpn_losses(head, gt, gt_count, perm_fn)
         props_s, offsets_s, labels_s, reg_s = self._select_training_samples(props, counts, gt, gt_count, gt_labels, perm_fn)

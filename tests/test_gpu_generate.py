@@ -10,7 +10,7 @@ import torch
 
 from conftest import REPO, gpu_model, load_golden, synth_sd
 from oracle import language_model as o_lm
-from rgrg_amd import synth
+from rgrg_amd import _hip, synth
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -611,22 +611,44 @@ def test_lm_training_pass_bf16_autocast_close_to_fp32():
     m.invalidate_engine()
 
 
-def test_detector_fc6_bf16_under_autocast_close_to_fp32():
-    """torch.autocast opts fc6 (81 % of the detector FLOPs) into the bf16 MFMA: box-head outputs (30 class logits + 120
-    deltas per RoI) within 2 % of their fp32 range; the per-region top-1 score (a softmax probability) moves by < 0.03
-    and the same classes are detected.  (WHICH of the 1000 random proposals wins a class is a near-tie with the
-    synthetic random-init heads, so the chosen boxes themselves are not compared.)"""
+def test_detector_under_autocast_close_to_fp32():
+    """torch.autocast (what the reference's scripts wrap generate() in, generate_reports_for_images.py:108) opts the detector
+    into the bf16 matrix core: the 16 bottlenecks and the RPN convs as implicit GEMMs, RoIAlign maps stored as bf16, fc6 on
+    the LDS-DMA GEMM; fp32 accumulation everywhere.  Stage by stage against the fp32 path: trunk features within 3 % of
+    their range after 49 bf16 layers, RPN objectness / deltas within 3 %, and - on the SAME proposals - the box head's 30
+    class logits + 120 deltas within 2 %.  End to end the same classes are detected and 90 % of the per-region top-1 scores
+    (softmax probabilities) move by < 0.05: WHICH of the ~1000 proposals wins a class is a near-tie with the synthetic
+    random-init heads and the proposal set itself changes with the RPN logits, so single scores / boxes may jump.  The
+    public module under autocast takes exactly this path."""
     m = gpu_model("bench")
-    images = synth.make_images(1, 1234).to(DEV)
+    images = synth.make_images(2, 1234).to(DEV)
     eng = m.engine()
     t32, t16 = {}, {}
     d32, f32_, cd32 = eng.detect(images, t32)
     d16, f16_, cd16 = eng.detect(images, t16, bf16=True)
-    span = t32["pred"].abs().max().item()
-    err = (t16["pred"] - t32["pred"]).abs().max().item()
-    assert 0.0 < err <= 2e-2 * span, (err, span)
+    span = t32["features_nhwc"].abs().max().item()
+    err = (t16["features_nhwc"] - t32["features_nhwc"]).abs().max().item()
+    assert 0.0 < err <= 3e-2 * span, (err, span)
+    # RPN on the same (fp32) feature map: fp32 convs vs bf16 convs
+    feat32 = t32["features_nhwc"]
+    feat16 = eng._act16(tuple(feat32.shape))
+    _hip.check(eng.lib.rgrg_f32_to_bf16(feat32.data_ptr(), feat16.data_ptr(), feat32.numel(), torch.cuda.current_stream().cuda_stream))
+    *_, head32 = eng.rpn(feat32, return_head=True)
+    *_, head16 = eng.rpn(feat32, return_head=True, feat16=feat16)
+    hspan = head32.abs().max().item()
+    assert (head16 - head32).abs().max().item() <= 3e-2 * hspan
+    # box head on the same proposals
+    p32, p16 = {}, {}
+    eng.roi_heads(feat32, t32["proposals"], t32["offsets"], p32)
+    eng.roi_heads(feat32, t32["proposals"], t32["offsets"], p16, bf16=True)
+    pspan = p32["pred"].abs().max().item()
+    perr = (p16["pred"] - p32["pred"]).abs().max().item()
+    assert 0.0 < perr <= 2e-2 * pspan, (perr, pspan)
+    assert p16["pooled_maps"].dtype == torch.int16 and torch.equal(p16["pooled"], p32["pooled"])   # the average stays fp32-exact
+    # end to end
     assert torch.equal(cd16, cd32)
-    assert (d16["top_scores"] - d32["top_scores"]).abs().max().item() <= 3e-2
+    diff = (d16["top_scores"] - d32["top_scores"]).abs().flatten()
+    assert torch.quantile(diff, 0.9).item() <= 5e-2, diff
     with torch.autocast("cuda", dtype=torch.bfloat16):
         _, det_a, _, cd_a = m.object_detector(images)
     assert torch.equal(cd_a, cd16) and torch.equal(det_a["top_region_boxes"], d16["top_region_boxes"])

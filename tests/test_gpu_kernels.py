@@ -90,6 +90,42 @@ def test_conv2d_nhwc_f32(eng, B, H, Cin, Cout, k, stride, pad, res):
     close(y.permute(0, 3, 1, 2), ref, 2e-5, 2e-6, f"conv k{k} s{stride}")
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride,pad,res", [
+    (2, 32, 64, 256, 1, 1, 0, True), (2, 16, 64, 64, 3, 1, 1, False), (1, 32, 128, 128, 3, 2, 1, False),
+    (2, 16, 256, 512, 1, 2, 0, False), (1, 16, 2048, 160, 1, 1, 0, False), (3, 16, 2048, 2048, 3, 1, 1, False),
+    (1, 24, 64, 64, 1, 1, 0, False), (2, 9, 128, 192, 3, 2, 1, True)])
+def test_conv2d_nhwc_bf16(eng, B, H, Cin, Cout, k, stride, pad, res):
+    """Implicit-GEMM convolution on the LDS-DMA bf16 kernel (the detector under torch.autocast): 1x1 / 3x3, stride 1 / 2,
+    padding through the zero line in front of the image, K = 64 (a single K tile) up to 18 432 (the RPN conv), bf16 residual,
+    ragged row / column tiles.  Against a float64 convolution of the SAME bf16-rounded operands (BatchNorm scale folded into
+    the weights before rounding, as the engine does): fp32 output to summation-order accuracy, bf16 output to one rounding."""
+    from rgrg_amd.engine import _Conv
+    g = torch.Generator().manual_seed(B * 100 + Cin + k + Cout)
+    x = torch.randn((B, Cin, H, H), generator=g).bfloat16()
+    w = torch.randn((Cout, Cin, k, k), generator=g) / math.sqrt(Cin * k * k)
+    scale = torch.rand((Cout,), generator=g) + 0.5
+    shift = torch.randn((Cout,), generator=g)
+    wf = (w * scale.view(-1, 1, 1, 1)).bfloat16()
+    ref = F.conv2d(x.double(), wf.double(), stride=stride, padding=pad) + shift.double().view(1, -1, 1, 1)
+    R = None
+    if res:
+        R = torch.randn(ref.shape, generator=g).bfloat16()
+        ref = ref + R.double()
+    ref = F.relu(ref)
+    conv = _Conv(w.to(DEV), scale.to(DEV), shift.to(DEV), stride, pad)
+    x16 = eng._act16((B, H, H, Cin))
+    x16.copy_(x.permute(0, 2, 3, 1).contiguous().view(torch.int16).to(DEV))
+    r16 = None
+    if res:
+        r16 = eng._act16(tuple(R.permute(0, 2, 3, 1).shape))
+        r16.copy_(R.permute(0, 2, 3, 1).contiguous().view(torch.int16).to(DEV))
+    y32 = eng.conv16(x16, conv, _hip.ACT_RELU, r16, out_f32=True)
+    close(y32.permute(0, 3, 1, 2), ref, 2e-5, 4e-6, f"bf16 conv k{k} s{stride} (fp32 out)")
+    y16 = eng.conv16(x16, conv, _hip.ACT_RELU, r16)
+    got = y16.view(torch.bfloat16).float().permute(0, 3, 1, 2)
+    close(got, ref, 2 ** -8, 4e-6, f"bf16 conv k{k} s{stride} (bf16 out)")
+
+
 def test_stem_and_maxpool(eng):
     g = torch.Generator().manual_seed(3)
     x = torch.randn((2, 1, 64, 96), generator=g)

@@ -174,14 +174,11 @@ def test_configs2_full_size_properties_batch32_bf16():
     col = torch.arange(ids.shape[1] - 1, device=ids.device)[None, :]
     assert ((ids[:, 1:] == 50256) | (col < first[:, None])).all()       # nothing but PAD after the first EOS
     assert bool((~sel | cd).all())                                       # selected => detected
-    # fp32 run: fc6 is the only detector op on the bf16 MFMA under autocast.  The 'ragged' weights put every third
-    # class and the selection logits right at their thresholds on purpose, so a few of the 928 decisions may flip;
-    # boxes of classes detected in both runs come from the same proposals
+    # fp32 run.  Under autocast the bottlenecks, the RPN and fc6 run on the bf16 matrix core (round 3).  The 'ragged'
+    # weights put every third class and the selection logits right at their thresholds on purpose, so some of the 928
+    # decisions flip; the proposal set changes with the RPN logits, so the boxes themselves are not comparable
     ids32, sel32, det32, cd32 = m.generate(images, max_length=128)
-    assert (cd == cd32).float().mean().item() >= 0.97 and (sel == sel32).float().mean().item() >= 0.95
-    both = cd & cd32
-    same_box = ((det["top_region_boxes"] - det32["top_region_boxes"]).abs().amax(-1) <= 0.5)[both]
-    assert same_box.float().mean().item() >= 0.95
+    assert (cd == cd32).float().mean().item() >= 0.93 and (sel == sel32).float().mean().item() >= 0.90
     # permutation of the images permutes the blocks of rows
     g = torch.Generator().manual_seed(5)
     perm = torch.randperm(32, generator=g).to(DEV)
