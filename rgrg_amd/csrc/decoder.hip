@@ -1370,6 +1370,8 @@ struct rgrg_decoder {
     int bf16_gemms = 0;  // 1: bf16-weight MFMA GEMMs on the many-sequence path (not bit-exact; opt-in)
     unsigned short *xn16 = nullptr, *att16 = nullptr, *ff16 = nullptr;  // bf16 activations of that path (GEMM inputs)
     int gemm_launches_per_step = 0;
+    void* a16_scratch = nullptr;   // bf16 copy of an fp32 GEMM input (teacher-forced / training passes under autocast)
+    size_t a16_bytes = 0;
 };
 
 namespace rgrg {
@@ -1813,6 +1815,7 @@ extern "C" void rgrg_decoder_destroy(rgrg_decoder* d) {
     for (void* p : d->allocs) (void)hipFree(p);
     tf_free(d);
     tr_free(d);
+    if (d->a16_scratch) (void)hipFree(d->a16_scratch);
     if (d->h_done) (void)hipHostFree(d->h_done);
     for (hipEvent_t e : d->ev_poll)
         if (e) (void)hipEventDestroy(e);
@@ -2132,9 +2135,27 @@ static int tf_reserve(rgrg_decoder* d, size_t rows) {
 }
 
 // tiled GEMM for the M = S*T token rows (never the skinny path: its buffers are sized for decode rows)
+// bf16-weight GEMM of the teacher-forced / training passes on an fp32 activation matrix: X is rounded to bf16 ONCE into a
+// scratch buffer (the same round-to-nearest-even the register-staged kernel applied tile by tile, so the operands are
+// identical) and the product runs on the LDS-DMA kernel - at M = S x T token rows it reaches 2-3x the register-staged rate.
+static int bf16_linear_f32in(rgrg_decoder* d, const float* X, const void* Wb, const float* b, const float* R, float* Y, int M, int N,
+                             int K, int ldy, int act) {
+    const size_t need = (size_t)M * K * sizeof(unsigned short);
+    if (need > d->a16_bytes) {
+        RGRG_HIP(hipStreamSynchronize(d->stream));  // the old buffer may still be read by a queued GEMM
+        if (d->a16_scratch) (void)hipFree(d->a16_scratch);
+        d->a16_scratch = nullptr; d->a16_bytes = 0;
+        RGRG_HIP(hipMalloc(&d->a16_scratch, need));
+        d->a16_bytes = need;
+    }
+    int rc = convert_f32_to_bf16(X, d->a16_scratch, (size_t)M * K, d->stream);
+    if (rc) return rc;
+    return launch_gemm_bf16w_ex(nullptr, d->a16_scratch, Wb, b, R, Y, nullptr, M, N, K, ldy, act, d->stream);
+}
+
 static int tf_linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R, float* Y, int M, int ldy, int act) {
     if (d->bf16_gemms && l.wb && l.K % 256 == 0 && M > skinny_max_rows())
-        return launch_gemm_bf16w(X, l.wb, l.b, R, Y, M, l.N, l.K, ldy, act, d->stream);
+        return bf16_linear_f32in(d, X, l.wb, l.b, R, Y, M, l.N, l.K, ldy, act);
     return launch_gemm_dense(X, l.w, l.b, R, Y, M, l.N, l.K, ldy, act, d->tf_ws, d->tf_ws_floats, d->stream);
 }
 }  // namespace rgrg
@@ -2299,7 +2320,7 @@ static int tr_lin(rgrg_decoder* d, const Lin& l, bool transposed, const float* X
     const void* Wb = transposed ? l.wTb : l.wb;
     const float* b = transposed ? nullptr : l.b;
     if (d->bf16_gemms && Wb && K % 256 == 0 && M > skinny_max_rows())
-        return launch_gemm_bf16w(X, Wb, b, R, Y, M, N, K, ldy, act, d->stream);
+        return bf16_linear_f32in(d, X, Wb, b, R, Y, M, N, K, ldy, act);
     return launch_gemm_dense(X, W, b, R, Y, M, N, K, ldy, act, d->tf_ws, d->tf_ws_floats, d->stream);
 }
 }  // namespace rgrg
