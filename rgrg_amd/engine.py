@@ -35,6 +35,8 @@ def _on_engine_device(cls):
     def wrap(fn):
         @functools.wraps(fn)
         def inner(self, *a, **k):
+            if torch.cuda.current_device() == self.device.index:   # the common case: no hipGetDevice / hipSetDevice pair
+                return fn(self, *a, **k)
             with torch.cuda.device(self.device):
                 return fn(self, *a, **k)
         return inner
@@ -462,12 +464,15 @@ class HipEngine:
         props_s, offsets_s, labels_s, reg_s = self._select_training_samples(props, counts, gt, gt_count, gt_labels, perm_fn)
         t2 = {} if taps is None else taps
         cd, scores, boxes, top = self.roi_heads(feat, props_s, offsets_s, t2, bf16)
-        out2 = torch.empty((2,), dtype=torch.float32, device=images.device)
         R = int(labels_s.shape[0])
         pred = t2.get("pred")
-        _hip.check(self.lib.rgrg_fastrcnn_loss_f32(None if pred is None else _hip.ptr(pred), 150 if pred is None else pred.shape[1], 30,
-                                                   _hip.ptr(labels_s), _hip.ptr(reg_s), R if pred is not None else 0, _hip.ptr(out2),
-                                                   self._s()), "rgrg_fastrcnn_loss_f32")
+        if pred is None or R == 0:
+            # no sampled RoI at all: cross_entropy / smooth_l1 over empty tensors are nan in the reference as well
+            out2 = torch.full((2,), float("nan"), dtype=torch.float32, device=images.device)
+        else:
+            out2 = torch.empty((2,), dtype=torch.float32, device=images.device)
+            _hip.check(self.lib.rgrg_fastrcnn_loss_f32(_hip.ptr(pred), pred.shape[1], 30, _hip.ptr(labels_s), _hip.ptr(reg_s), R,
+                                                       _hip.ptr(out2), self._s()), "rgrg_fastrcnn_loss_f32")
         # the reference's dict order: RoI-head losses, then the RPN's (object_detector.py:240-242)
         losses = {"loss_classifier": out2[0], "loss_box_reg": out2[1], "loss_objectness": loss_obj, "loss_rpn_box_reg": loss_rpn_box}
         if taps is not None:

@@ -179,16 +179,30 @@ class ObjectDetector(EngineOwner):
         return ImageList(images), OrderedDict([("0", features)])
 
     def _check_targets(self, targets) -> None:
-        """object_detector.py:133-162: every box needs positive width and height."""
-        for t in targets:
+        """object_detector.py:133-162 (torch._assert -> AssertionError, same messages) plus what torchvision's
+        RoIHeads.check_targets and the losses enforce later in the reference's call: float boxes / int64 labels (TypeError)
+        and class labels inside the 30 logits (torch's cross entropy: "Target N is out of bounds")."""
+        for target_idx, t in enumerate(targets):
             boxes = t["boxes"]
-            if not isinstance(boxes, torch.Tensor) or boxes.dim() != 2 or boxes.shape[-1] != 4:
-                raise ValueError(f"Expected target boxes to be a tensor of shape [N, 4], got {getattr(boxes, 'shape', type(boxes))}.")
+            if not isinstance(boxes, torch.Tensor):
+                raise AssertionError(f"Expected target boxes to be of type Tensor, got {type(boxes)}.")
+            if boxes.dim() != 2 or boxes.shape[-1] != 4:
+                raise AssertionError(f"Expected target boxes to be a tensor of shape [N, 4], got {boxes.shape}.")
             degenerate = boxes[:, 2:] <= boxes[:, :2]
             if degenerate.any():
                 bb_idx = torch.where(degenerate.any(dim=1))[0][0]
-                raise ValueError("All bounding boxes should have positive height and width."
-                                 f" Found invalid box {boxes[bb_idx].tolist()}.")
+                raise AssertionError("All bounding boxes should have positive height and width."
+                                     f" Found invalid box {boxes[bb_idx].tolist()} for target at index {target_idx}.")
+            if boxes.dtype not in (torch.float, torch.double, torch.half):
+                raise TypeError("target boxes must of float type")
+            labels = t["labels"]
+            if not isinstance(labels, torch.Tensor) or labels.dtype != torch.int64:
+                raise TypeError("target labels must of int64 type")
+            if labels.numel() != boxes.shape[0]:
+                raise AssertionError(f"{boxes.shape[0]} boxes but {labels.numel()} labels for target at index {target_idx}")
+            if labels.numel() and (int(labels.min()) < 0 or int(labels.max()) >= 30):
+                bad = int(labels.max()) if int(labels.max()) >= 30 else int(labels.min())
+                raise IndexError(f"Target {bad} is out of bounds.")
 
     def forward(self, images: Tensor, targets: Optional[List[Dict[str, Tensor]]] = None):
         """Eval-mode ``ObjectDetector.forward`` (object_detector.py:184-261).  ``targets=None``: inference, losses = {}.

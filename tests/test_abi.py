@@ -117,10 +117,17 @@ def test_generation_mode_errors_match_reference(model):
 def test_image_targets_are_validated_like_the_reference(model):
     """object_detector.py:133-162: boxes must be [N, 4] tensors with positive width and height (checked before any GPU work)."""
     images = torch.zeros(1, 1, 512, 512)
-    with pytest.raises(ValueError, match="positive height and width"):
+    with pytest.raises(AssertionError, match="positive height and width"):   # torch._assert in the reference
         model.object_detector(images, [{"boxes": torch.tensor([[10.0, 10.0, 10.0, 50.0]]), "labels": torch.tensor([1])}])
-    with pytest.raises(ValueError, match="shape"):
+    with pytest.raises(AssertionError, match="shape"):
         model.object_detector(images, [{"boxes": torch.zeros(4), "labels": torch.tensor([1])}])
+    ok = torch.tensor([[10.0, 10.0, 40.0, 50.0]])
+    with pytest.raises(TypeError, match="float type"):                          # torchvision RoIHeads.check_targets
+        model.object_detector(images, [{"boxes": ok.to(torch.int32), "labels": torch.tensor([1])}])
+    with pytest.raises(TypeError, match="int64"):
+        model.object_detector(images, [{"boxes": ok, "labels": torch.tensor([1], dtype=torch.int32)}])
+    with pytest.raises(IndexError, match="out of bounds"):                      # the class logits have 30 columns
+        model.object_detector(images, [{"boxes": ok, "labels": torch.tensor([30])}])
 
 
 def test_no_cpu_fallback(model):
