@@ -366,7 +366,7 @@ def test_eval_forward_matches_reference_fixture():
     assert torch.equal(out[5].cpu(), e["class_detected"]) and torch.equal(out[6].cpu(), e["selected_regions"])
     assert torch.equal(out[7].cpu(), e["predicted_abnormal_regions"])
     assert (out[4]["top_region_boxes"].cpu() - e["top_region_boxes"]).abs().max().item() <= 1e-2
-    with pytest.raises(ValueError):  # image_targets are supported (tests/test_gpu_detector_losses.py) but validated first
+    with pytest.raises(AssertionError):  # image_targets are supported (tests/test_gpu_detector_losses.py) but validated first
         m(images, [{"boxes": None, "labels": None}], None, None, None, None)
     m.pretrain_without_lm_model = True
     assert len(m(images, None, None, None, i["region_has_sentence"].to(DEV), i["region_is_abnormal"].to(DEV))) == 7
