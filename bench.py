@@ -62,7 +62,7 @@ def rooflines(eng, S_dec, dtype, max_length):
     cfg = f"S{S_dec}_{dtype}"
     if S_dec <= 128:
         ach = p["gemm_weight_bytes"] / (p["ms_gemm"] * 1e-3) / 1e9
-        gemm = {"bound": "hbm", "kernel": "rgrg_skinny_direct_f32 (+ _wide)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        gemm = {"bound": "hbm", "kernel": "rgrg_skinny_direct_f32 (+ _half, rgrg_lm_head_wave_f32)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(f"gemm_{cfg}"), "launches_per_decode_step": n,
                 "avg_launch_us": 1e3 * p["ms_gemm"] / n, "algorithmic_bytes_per_launch": p["gemm_weight_bytes"] / n,
                 "note": "achieved = fp32 weight bytes of the GEMM launches of one decode step (each weight read once) / their duration "
@@ -70,7 +70,7 @@ def rooflines(eng, S_dec, dtype, max_length):
     else:
         peak = MFMA_PEAK_TFS[dtype]
         ach = p["gemm_flops"] / (p["ms_gemm"] * 1e-3) / 1e12
-        gemm = {"bound": "mfma", "kernel": "gemm_bf16w_kernel" if dtype == "bf16" else "gemm_f32_kernel", "achieved": ach, "peak": peak,
+        gemm = {"bound": "mfma", "kernel": "gemm_bf16_glds_kernel" if dtype == "bf16" else "gemm_f32_kernel", "achieved": ach, "peak": peak,
                 "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic(f"gemm_{cfg}"), "launches_per_decode_step": n,
                 "avg_launch_us": 1e3 * p["ms_gemm"] / n, "algorithmic_flops_per_launch": p["gemm_flops"] / n,
                 "note": "achieved = 2 M N K of the GEMM launches of one decode step / their duration between two HIP events on the decoder stream"}

@@ -14,7 +14,8 @@ import os
 import sys
 from collections import defaultdict
 
-FAMILIES = {"gemm": ("rgrg_skinny_direct", "gemm_bf16w_kernel", "rgrg_skinny_gemm_f32"), "attn": ("attn_decode",)}
+FAMILIES = {"gemm": ("rgrg_skinny_direct", "rgrg_lm_head_wave", "gemm_bf16_glds_kernel", "gemm_bf16w_kernel", "rgrg_skinny_gemm_f32"),
+            "attn": ("attn_decode",)}
 
 
 def per_kernel(d, counter):
