@@ -217,12 +217,12 @@ int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, const int64_t* 
  *                 attn_dropout on the probabilities :116, resid_dropout :178, the MLP's dropout) with a counter-based
  *                 generator: mask = f(dropout_seed, layer*4 + site, element index) (Philox4x32-10), recomputed by the
  *                 backward pass; torch's generator stream cannot be reproduced, so the masks differ from the
- *                 reference's (rgrg_dropout_mask_f32 exports them for checks).  Needs T <= 159.
+ *                 reference's (rgrg_dropout_mask_f32 exports them for checks).
  *   dropout_seed  a fresh value per call
  *   loss_out      one f32, the unscaled loss
  *   grad_ukv_w    f32 [n_layer*2*1024, 1024]  rows = [uk_0; uv_0; uk_1; uv_1; ...]      grad_ukv_b  f32 [n_layer*2*1024]
  *   grad_fst0_w/b, grad_fst2_w/b   f32 [1024,1024] / [1024]  (Linear 0 and 2 of feature_space_transformation_nn)
- * Gradients are WRITTEN (not accumulated).  T <= 160.  Allocates work space on demand (~0.9 MB per token row). */
+ * Gradients are WRITTEN (not accumulated).  T <= 1023 (the reference's own limit).  Allocates work space on demand (~0.9 MB per token row). */
 int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, const int64_t* input_ids, const float* attention_mask,
                               int S, int T, float loss_scale, float dropout_p, uint64_t dropout_seed, float* loss_out,
                               float* grad_ukv_w, float* grad_ukv_b, float* grad_fst0_w, float* grad_fst0_b, float* grad_fst2_w,

@@ -1751,6 +1751,10 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
         TRY(make_lin(d, t.c_fc, s.c_fc_w, s.c_fc_b, 4 * D, D, true, true, s.ln2_g, s.ln2_b));
         TRY(make_lin(d, t.mlp_proj, s.mlp_proj_w, s.mlp_proj_b, D, 4 * D, true, true));
     }
+    if (const char* e = getenv("RGRG_PROBE_ALIAS_LAYERS")) {  // TEMPORARY probe: layers cycle through the first n weight sets
+        const int n = atoi(e);
+        if (n > 0) for (int l = n; l < w->n_layer; ++l) d->layers[l] = d->layers[l % n];
+    }
     const size_t R = d->rows;
     d->ld_logits = d->lm_head.NT * d->lm_head.ntile;
     d->ld_ukv = d->ukv.N;
@@ -2232,7 +2236,6 @@ int launch_ce_backward(float* logits, size_t ld, int V, int row0, int rows, cons
                        const float* row_lse, const int* n_scored, float scale, const int* id_error, hipStream_t st);
 int launch_transpose_pad(const float* src, float* dst, int R, int Cc, int Rp, hipStream_t st);
 int launch_colsum(const float* src, float* out, int R, int Cc, hipStream_t st);
-int attn_backward_max_t();
 int launch_attn_backward(const float* qkv, const float* ukv, int ld_ukv, int kcol, const float* am, const float* d_att,
                          const float* att, const float* lse, float* delta, float* d_qkv, float* d_ukv, int S, int H, int T,
                          DropoutParams drop, hipStream_t st);
@@ -2332,8 +2335,8 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
                                          float* grad_fst2_w, float* grad_fst2_b, void* stream) {
     RGRG_CHECK_ARG(d && feats && input_ids && loss_out && grad_ukv_w && grad_ukv_b && grad_fst0_w && grad_fst0_b && grad_fst2_w &&
                    grad_fst2_b);
-    RGRG_CHECK_ARG(S > 0 && S <= d->max_seqs && T >= 2 && T <= attn_backward_max_t());
-    RGRG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || T + 1 <= 160));  // dropout: matrix-core attention only
+    RGRG_CHECK_ARG(S > 0 && S <= d->max_seqs && T >= 2 && T <= TF_MAX_T);
+    RGRG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f);
     const int D = d->D, M = S * T, L = d->n_layer, V = d->V, VP = pad256(V), Sp = pad32(S), LD = d->ld_ukv;
     int rc;
     if ((rc = check_id_error(d))) return rc;

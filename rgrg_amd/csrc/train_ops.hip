@@ -137,147 +137,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ s
     out[c] = a;
 }
 
-// Backward of the pseudo self-attention of one layer (GPT2PseudoAttention._attn, :84-122, without cache).
-// One workgroup per (sequence, head).  K and V (image slot first) live in LDS; queries are processed in blocks of 32:
-//   phase 1 (a wave per query, a lane per key): recompute P, dP = dO . V, dS = P (dP - sum P dP), dS = 0 on the future
-//            (constant -1e4) branch, scaled by 1/8; P and dS of the block go to LDS;
-//   phase 2 (a lane per dim): dQ = dS K for the block's queries; every wave owns the keys c = wave (mod 4) and adds
-//            dK_c += dS[:,c] Q, dV_c += P[:,c] dO into registers.
-// The image key/value gradients (c == 0) are written to d_ukv, the token ones to d_qkv.
-constexpr int AB_QB = 32;    // queries per block
-constexpr int AB_KMAX = 48;  // keys per wave: T + 1 <= 4 * AB_KMAX
-__global__ __launch_bounds__(256) void attn_backward_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
-                                                            int kcol, const float* __restrict__ am, const float* __restrict__ d_att,
-                                                            float* __restrict__ d_qkv, float* __restrict__ d_ukv, int H, int T) {
-    extern __shared__ __attribute__((aligned(16))) float ab_sm[];
-    const int NK = T + 1, D = H * 64;
-    float* Ks = ab_sm;                  // [NK][65]
-    float* Vs = Ks + NK * 65;           // [NK][65]
-    float* Qb = Vs + NK * 65;           // [32][64]
-    float* dOb = Qb + AB_QB * 64;       // [32][64]
-    float* Pm = dOb + AB_QB * 64;       // [32][NK]
-    float* dSm = Pm + AB_QB * NK;       // [32][NK]
-    float* addm = dSm + AB_QB * NK;     // [NK]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = blockIdx.x / H, hd = blockIdx.x - s * H;
-    for (int idx = tid; idx < NK * 64; idx += 256) {
-        const int c = idx >> 6, e = idx & 63;
-        float k, v;
-        if (c == 0) {
-            k = ukv[(size_t)s * ld_ukv + kcol + hd * 64 + e];
-            v = ukv[(size_t)s * ld_ukv + kcol + D + hd * 64 + e];
-        } else {
-            const float* r = qkv + ((size_t)s * T + c - 1) * 3 * D + hd * 64 + e;
-            k = r[D];
-            v = r[2 * D];
-        }
-        Ks[c * 65 + e] = k;
-        Vs[c * 65 + e] = v;
-    }
-    for (int c = tid; c < NK; c += 256) addm[c] = (c == 0 || !am) ? 0.f : (1.0f - am[(size_t)s * T + c - 1]) * -10000.0f;
-    float dKa[AB_KMAX], dVa[AB_KMAX];
-#pragma unroll
-    for (int k = 0; k < AB_KMAX; ++k) { dKa[k] = 0.f; dVa[k] = 0.f; }
-    for (int i0 = 0; i0 < T; i0 += AB_QB) {
-        __syncthreads();  // previous block fully consumed (also orders the K/V fill before the first block)
-        for (int idx = tid; idx < AB_QB * 64; idx += 256) {
-            const int j = idx >> 6, e = idx & 63, i = i0 + j;
-            float q = 0.f, g = 0.f;
-            if (i < T) {
-                q = qkv[((size_t)s * T + i) * 3 * D + hd * 64 + e];
-                g = d_att[((size_t)s * T + i) * D + hd * 64 + e];
-            }
-            Qb[idx] = q;
-            dOb[idx] = g;
-        }
-        __syncthreads();
-        // phase 1
-        for (int j = wave; j < AB_QB; j += 4) {
-            const int i = i0 + j;
-            if (i >= T) break;
-            float w[3], dp[3];
-            bool allowed[3];
-            float m = -INFINITY;
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int c = lane + 64 * u;
-                w[u] = -INFINITY;
-                dp[u] = 0.f;
-                allowed[u] = false;
-                if (c < NK) {
-                    float dot = 0.f, dv = 0.f;
-#pragma unroll 16
-                    for (int e = 0; e < 64; ++e) {
-                        dot += Qb[j * 64 + e] * Ks[c * 65 + e];
-                        dv += dOb[j * 64 + e] * Vs[c * 65 + e];
-                    }
-                    allowed[u] = (c == 0) || (c - 1 <= i);
-                    w[u] = (allowed[u] ? dot / 8.0f : -1e4f) + addm[c];
-                    dp[u] = dv;
-                    m = fmaxf(m, w[u]);
-                }
-            }
-            m = wave_max(m);
-            float sum = 0.f;
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-                if (lane + 64 * u < NK) { w[u] = expf(w[u] - m); sum += w[u]; }
-            sum = wave_sum(sum);
-            float delta = 0.f;
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-                if (lane + 64 * u < NK) { w[u] = w[u] / sum; delta += w[u] * dp[u]; }
-            delta = wave_sum(delta);
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int c = lane + 64 * u;
-                if (c < NK) {
-                    Pm[j * NK + c] = w[u];
-                    dSm[j * NK + c] = allowed[u] ? w[u] * (dp[u] - delta) / 8.0f : 0.f;
-                }
-            }
-        }
-        __syncthreads();
-        // phase 2a: dQ of the block's queries (lane = dim)
-        for (int j = wave; j < AB_QB; j += 4) {
-            const int i = i0 + j;
-            if (i >= T) break;
-            float acc = 0.f;
-            for (int c = 0; c < NK; ++c) acc += dSm[j * NK + c] * Ks[c * 65 + lane];
-            d_qkv[((size_t)s * T + i) * 3 * D + hd * 64 + lane] = acc;
-        }
-        // phase 2b: dK / dV of this wave's keys
-        const int jn = min(AB_QB, T - i0);
-#pragma unroll 1
-        for (int j = 0; j < jn; ++j) {
-            const float q = Qb[j * 64 + lane], g = dOb[j * 64 + lane];
-            const float* dsr = dSm + j * NK + wave;
-            const float* pr = Pm + j * NK + wave;
-#pragma unroll
-            for (int k = 0; k < AB_KMAX; ++k) {
-                if (wave + 4 * k < NK) {  // wave-uniform
-                    dKa[k] += dsr[4 * k] * q;
-                    dVa[k] += pr[4 * k] * g;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < AB_KMAX; ++k) {
-        const int c = wave + 4 * k;
-        if (c < NK) {
-            if (c == 0) {
-                d_ukv[(size_t)s * ld_ukv + kcol + hd * 64 + lane] = dKa[k];
-                d_ukv[(size_t)s * ld_ukv + kcol + D + hd * 64 + lane] = dVa[k];
-            } else {
-                float* r = d_qkv + ((size_t)s * T + c - 1) * 3 * D + hd * 64 + lane;
-                r[D] = dKa[k];
-                r[2 * D] = dVa[k];
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------- attention backward on the fp32 matrix core
 // Same register-only structure as attn_prefill_kernel (decoder.hip).  The forward pass kept, per (token, head), the
 // row log-sum-exp; delta = rowsum(dO . O) (= sum_keys P dP) comes from attn_delta_kernel.  Two kernels, no atomics:
@@ -303,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 
 __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-template <int NT>  // key tiles: T + 1 <= 32 * NT
+// Key tiles are streamed (any T): dS^T of one 32-key tile is computed and consumed by dQ^T += K^T dS^T before the next.
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
                                                           int kcol, const float* __restrict__ am, const float* __restrict__ d_att,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
@@ -316,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
     const int NK = T + 1, D = H * 64;
     const int col = lane & 31, half = lane >> 5;
     const int iq = qt * 32 + col, iqc = min(iq, T - 1);
-    const int need = min(NK - 1, qt * 32 + 32) / 32 + 1;
+    const int need = min(NK - 1, qt * 32 + 32) / 32 + 1;  // key tiles a query of this tile can see
     auto krow = [&](int c) -> const float* {
         c = min(c, NK - 1);
         return c == 0 ? ukv + (size_t)s * ld_ukv + kcol + hd * 64 : qkv + ((size_t)s * T + c - 1) * 3 * D + D + hd * 64;
@@ -332,61 +191,53 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
         }
     }
     const float lse_q = lse[((size_t)s * T + iqc) * H + hd], delta_q = delta[((size_t)s * T + iqc) * H + hd];
-    f32x16 ds[NT];
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-        if (kt < need) {
-            f32x4 kf[8], vf[8];
-            const float* kp = krow(kt * 32 + col) + half * 32;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                kf[u] = *reinterpret_cast<const f32x4*>(kp + 4 * u);
-                vf[u] = *reinterpret_cast<const f32x4*>(kp + D + 4 * u);
-            }
-            f32x16 aS, aP;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { aS[r] = 0.f; aP[r] = 0.f; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    aS = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u][e], qf[u][e], aS, 0, 0, 0);
-                    aP = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[u][e], gf[u][e], aP, 0, 0, 0);
-                }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = kt * 32 + mfma_row(r, half);
-                float dsv = 0.f;
-                if (c < NK) {
-                    const bool allowed = (c == 0) || (c - 1 <= iq);
-                    const float addm = (c == 0 || !am) ? 0.f : (1.0f - am[(size_t)s * T + c - 1]) * -10000.0f;
-                    const float pr = expf((allowed ? aS[r] / 8.0f : -1e4f) + addm - lse_q);
-                    // attn_dropout: O = (P * mask) V  =>  dP = (dO . V) * mask ; delta = rowsum(dO . O) already includes it
-                    const float mk = dropout_mask(drop, (((unsigned long long)s * H + hd) * T + iqc) * NK + c);
-                    dsv = allowed ? pr * (aP[r] * mk - delta_q) / 8.0f : 0.f;
-                }
-                ds[kt][r] = dsv;
-            }
-        }
-    }
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    for (int kt = 0; kt < need; ++kt) {
+        f32x4 kf[8], vf[8];
+        const float* kp = krow(kt * 32 + col) + half * 32;
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-        if (kt < need) {
-            float k0[16], k1[16];
+        for (int u = 0; u < 8; ++u) {
+            kf[u] = *reinterpret_cast<const f32x4*>(kp + 4 * u);
+            vf[u] = *reinterpret_cast<const f32x4*>(kp + D + 4 * u);
+        }
+        float k0[16], k1[16];  // the same K rows again, a lane per dim: A operand of dQ^T = K^T dS^T
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float* kp = krow(kt * 32 + mfma_row(j, half));
-                k0[j] = kp[col];
-                k1[j] = kp[32 + col];
+        for (int j = 0; j < 16; ++j) {
+            const float* kr = krow(kt * 32 + mfma_row(j, half));
+            k0[j] = kr[col];
+            k1[j] = kr[32 + col];
+        }
+        f32x16 aS, aP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { aS[r] = 0.f; aP[r] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                aS = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u][e], qf[u][e], aS, 0, 0, 0);
+                aP = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[u][e], gf[u][e], aP, 0, 0, 0);
             }
+        f32x16 ds;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[j], ds[kt][j], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[j], ds[kt][j], o1, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) {
+            const int c = kt * 32 + mfma_row(r, half);
+            float dsv = 0.f;
+            if (c < NK) {
+                const bool allowed = (c == 0) || (c - 1 <= iq);
+                const float addm = (c == 0 || !am) ? 0.f : (1.0f - am[(size_t)s * T + c - 1]) * -10000.0f;
+                const float pr = expf((allowed ? aS[r] / 8.0f : -1e4f) + addm - lse_q);
+                // attn_dropout: O = (P * mask) V  =>  dP = (dO . V) * mask ; delta = rowsum(dO . O) already includes it
+                const float mk = dropout_mask(drop, (((unsigned long long)s * H + hd) * T + iqc) * NK + c);
+                dsv = allowed ? pr * (aP[r] * mk - delta_q) / 8.0f : 0.f;
             }
+            ds[r] = dsv;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[j], ds[j], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[j], ds[j], o1, 0, 0, 0);
         }
     }
     if (iq < T) {
@@ -587,40 +438,19 @@ int launch_colsum(const float* src, float* out, int R, int Cc, hipStream_t st) {
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
-int attn_backward_max_t() { return 4 * AB_KMAX - 1 < 160 ? 4 * AB_KMAX - 1 : 160; }
 int launch_attn_backward(const float* qkv, const float* ukv, int ld_ukv, int kcol, const float* am, const float* d_att,
                          const float* att, const float* lse, float* delta, float* d_qkv, float* d_ukv, int S, int H, int T,
                          DropoutParams drop, hipStream_t st) {
-    RGRG_CHECK_ARG(T >= 1 && T <= attn_backward_max_t());
-    const int NK = T + 1;
-    static const bool force_valu = [] { const char* e = getenv("RGRG_ATTN_BWD_VALU"); return e && atoi(e) != 0; }();
-    if (NK <= 160 && att && lse && delta && !force_valu) {
-        const int D = H * 64, M = S * T;
-        hipLaunchKernelGGL(attn_delta_kernel, dim3(M), dim3(256), 0, st, d_att, att, delta, D, H);
-        RGRG_LAUNCH_CHECK();
-        const int qitems = S * H * ((T + 31) / 32), kitems = S * H * ((NK + 31) / 32);
-        if (NK <= 96)
-            hipLaunchKernelGGL(attn_bwd_dq_kernel<3>, dim3((qitems + 3) / 4), dim3(256), 0, st, qkv, ukv, ld_ukv, kcol, am, d_att, lse,
-                               delta, d_qkv, S, H, T, drop);
-        else
-            hipLaunchKernelGGL(attn_bwd_dq_kernel<5>, dim3((qitems + 3) / 4), dim3(256), 0, st, qkv, ukv, ld_ukv, kcol, am, d_att, lse,
-                               delta, d_qkv, S, H, T, drop);
-        RGRG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((kitems + 3) / 4), dim3(256), 0, st, qkv, ukv, ld_ukv, kcol, am, d_att, lse, delta,
-                           d_qkv, d_ukv, S, H, T, drop);
-        RGRG_LAUNCH_CHECK();
-        return RGRG_OK;
-    }
-    RGRG_CHECK_ARG(drop.p == 0.f);  // the LDS fallback (161 keys, or forced) has no dropout
-    const size_t lds = ((size_t)NK * 65 * 2 + 2 * AB_QB * 64 + 2 * (size_t)AB_QB * NK + NK) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_backward_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
-    RGRG_CHECK_ARG(lds <= 160 * 1024);
-    hipLaunchKernelGGL(attn_backward_kernel, dim3(S * H), dim3(256), lds, st, qkv, ukv, ld_ukv, kcol, am, d_att, d_qkv, d_ukv, H, T);
+    RGRG_CHECK_ARG(T >= 1 && att && lse && delta);
+    const int NK = T + 1, D = H * 64, M = S * T;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(M), dim3(256), 0, st, d_att, att, delta, D, H);
+    RGRG_LAUNCH_CHECK();
+    const int qitems = S * H * ((T + 31) / 32), kitems = S * H * ((NK + 31) / 32);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((qitems + 3) / 4), dim3(256), 0, st, qkv, ukv, ld_ukv, kcol, am, d_att, lse, delta,
+                       d_qkv, S, H, T, drop);
+    RGRG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((kitems + 3) / 4), dim3(256), 0, st, qkv, ukv, ld_ukv, kcol, am, d_att, lse, delta,
+                       d_qkv, d_ukv, S, H, T, drop);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }

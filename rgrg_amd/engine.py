@@ -793,8 +793,8 @@ class HipEngine:
         S, T = input_ids.shape
         if feats.shape[0] != S:
             raise ValueError(f"image_hidden_states has {feats.shape[0]} rows, input_ids {S}")
-        if T > 160 or (dropout_p > 0 and T > 159):
-            raise NotImplementedError("the HIP training pass supports sequences of up to 160 tokens (159 with dropout)")
+        if T > 1023:  # T + 1 keys: the 1024 positions of GPT-2's causal-mask buffer bound the reference as well
+            raise NotImplementedError("the training pass supports sequences of up to 1023 tokens")
         # token ids are range-checked on the device (no host sync here): see embed_seq_ln_kernel
         dec = self._get_decoder(S, 2)
         self._raise_pending_id_error()

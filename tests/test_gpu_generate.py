@@ -464,10 +464,11 @@ def test_lm_training_pass_gradients_match_reference_fixture():
     m.invalidate_engine()
 
 
-@pytest.mark.parametrize("S,T", [(9, 40), (2, 100), (1, 160), (3, 32)])
+@pytest.mark.parametrize("S,T", [(9, 40), (2, 100), (1, 160), (3, 32), (2, 300), (1, 1023)])
 def test_lm_training_pass_vs_oracle_autograd_longer_sequences(S, T):
     """T = 40: two query / key tiles of the matrix-core attention backward with padding inside and across tiles;
-    T = 100: the 5-key-tile variant; T = 160: the LDS fallback (161 keys); T = 32: 33 keys = one key in the second tile."""
+    T = 100 / 160: 4 / 6 streamed key tiles; T = 32: 33 keys = one key in the second tile; T = 300: beyond 256 keys the
+    forward uses the streaming prefill attention; T = 1023: the reference's own limit (1024 keys)."""
     m = _lm_train_model()
     lm = m.language_model
     lm.train()
@@ -671,7 +672,8 @@ def test_dropout_masks_are_bernoulli_reproducible_and_stream_separated():
     assert abs(b.float().mean().item() - 0.81) < 0.005
 
 
-def test_lm_training_pass_with_dropout_matches_oracle_with_the_same_masks():
+@pytest.mark.parametrize("S,T", [(4, 40), (2, 200)])
+def test_lm_training_pass_with_dropout_matches_oracle_with_the_same_masks(S, T):
     """Train-mode dropout (p = 0.25 here so that it matters) at all four GPT-2 sites: the masks the HIP pass uses are
     exported (rgrg_dropout_mask_f32) and applied inside the oracle's forward; loss and all gradients must then agree
     as in the deterministic case - i.e. forward and BOTH attention-backward kernels recompute identical masks."""
@@ -680,7 +682,6 @@ def test_lm_training_pass_with_dropout_matches_oracle_with_the_same_masks():
     lm.train()
     lm.dropout_p = 0.25
     g = torch.Generator().manual_seed(77)
-    S, T = 4, 40
     ids = torch.randint(0, 50257, (S, T), generator=g)
     lens = torch.randint(2, T + 1, (S,), generator=g)
     lens[0] = T

@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--stages", default="2,3,4")
     ap.add_argument("--pads", default="0")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--vendor", action="store_true",
+                    help="also time torch.mm on the same bf16 operands (the vendor library GEMM, bf16 out, no bias / residual): "
+                         "a yardstick for what these shapes reach on this GPU, not a code path of the package")
     ap.add_argument("--cold", action="store_true",
                     help="cycle through enough weight copies (> 600 MB) that no launch finds its W in the 256 MB Infinity Cache: the "
                          "regime of a decode step, which streams 0.7 GB of weights between two uses of the same matrix")
@@ -75,6 +78,14 @@ def main():
         print(f"{name:9s} M={M} N={N} K={K}" + (f"  (cold: {ncopy} weight copies)" if args.cold else ""), flush=True)
         us = timed(lambda: _hip.check(lib.rgrg_linear_bf16w_f32(A.data_ptr(), wptr(Wb), b.data_ptr(), R, Y.data_ptr(), M, N, K, N, act, st)), args.iters)
         print(f"   reg-staged (fp32 A)          {us:7.1f} us {2.0 * M * N * K / us / 1e6:5.0f} TF/s", flush=True)
+        if args.vendor:
+            Ab, Wv, Yb = A16.view(torch.bfloat16), Wb.view(torch.bfloat16), torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+
+            def vendor():
+                it[0] += 1
+                torch.mm(Ab, Wv[it[0] % ncopy].t(), out=Yb)
+            us = timed(vendor, args.iters)
+            print(f"   vendor torch.mm (bf16 out)   {us:7.1f} us {2.0 * M * N * K / us / 1e6:5.0f} TF/s", flush=True)
         for pad in map(int, args.pads.split(",")):
             Ap = padded(A16, pad) if pad else A16
             Wp = torch.stack([padded(Wb[c], pad) for c in range(ncopy)]) if pad else Wb
