@@ -339,6 +339,12 @@ int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, int iters, f
  * microseconds per kernel of a dependent chain of n trivial kernels; mode 0 = eager on a
  * private stream, 1 = one hipGraph replay, 2 = eager on the null stream. */
 int rgrg_debug_chain(int n, int mode, int blocks, float* us_per_kernel);
+/* Measurement helper (tools/grid_barrier_bench.py): microseconds per grid-wide barrier among 256 resident workgroups of
+ * 512 threads, with a payload hand-off of `payload_floats` per workgroup around it.  variant: 0 one atomic counter with
+ * agent-scope fences, 1 without fences, 2 per-workgroup flags with fences, 3 flags with coherent payload accesses and no
+ * fences, 4 two-level counters with fences, 5 the fences alone.  stale_out[0] = hand-offs that read old data,
+ * stale_out[1] = 1 when a bounded spin gave up. */
+int rgrg_debug_grid_barrier(int variant, int iters, int payload_floats, float* us_per_barrier, unsigned* stale_out);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,7 @@ SIGNATURES = {
     "rgrg_decoder_time_step_parts": (_i, [_p, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "rgrg_debug_chain": (_i, [_i, _i, _i, C.POINTER(_f)]),
+    "rgrg_debug_grid_barrier": (_i, [_i, _i, _i, C.POINTER(_f), C.POINTER(C.c_uint)]),
 }
 
 _lib: Optional[C.CDLL] = None
