@@ -315,10 +315,12 @@ int rgrg_box_match_f32(const float* gt, const int* gt_count, int G, const float*
 int rgrg_box_encode_f32(const float* ref_boxes, const float* proposals, int n, float wx, float wy, float ww, float wh,
                         float* out, void* stream);
 /* RPN losses on the fused head output rpn_out [B * cells][ld] (anchors_per_cell objectness columns, then 4 deltas per
- * anchor); labels / reg_targets are per flat anchor index (image-major), pos_idx / sampled_idx the sampled flat
- * indices.  out2[0] = loss_objectness, out2[1] = loss_rpn_box_reg. */
+ * anchor); labels / reg_targets / sampled are per flat anchor index (image-major, `total` of them); sampled = the
+ * BalancedPositiveNegativeSampler's choice as a byte per anchor: 0 not sampled, 1 sampled positive, 2 sampled negative
+ * (a device mask: no index lists, no counts on the host).  out2[0] = loss_objectness (BCE over the sampled anchors, mean),
+ * out2[1] = loss_rpn_box_reg (smooth-L1 beta 1/9 over the sampled positives / #sampled); nan when nothing is sampled. */
 int rgrg_rpn_loss_f32(const float* rpn_out, int ld, int anchors_per_cell, const float* labels, const float* reg_targets,
-                      const int64_t* pos_idx, int n_pos, const int64_t* sampled_idx, int n_sampled, float* out2, void* stream);
+                      const uint8_t* sampled, int64_t total, float* out2, void* stream);
 /* fastrcnn_loss on pred [N][ld] = num_classes logits | num_classes x 4 deltas.  out2[0] = loss_classifier,
  * out2[1] = loss_box_reg. */
 int rgrg_fastrcnn_loss_f32(const float* pred, int ld, int num_classes, const int64_t* labels, const float* reg_targets, int N,

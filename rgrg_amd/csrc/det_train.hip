@@ -108,27 +108,30 @@ __device__ __forceinline__ float smooth_l1(float d, float beta) {
 // the sampled anchors, out[1] = smooth-L1 (beta 1/9) sum over the sampled positives / number of sampled anchors.
 __global__ __launch_bounds__(256) void rpn_loss_kernel(const float* __restrict__ rpn_out, int ld, int A_cell,
                                                        const float* __restrict__ labels, const float* __restrict__ reg,
-                                                       const long long* __restrict__ pos_idx, int n_pos,
-                                                       const long long* __restrict__ all_idx, int n_all, float* __restrict__ out) {
+                                                       const unsigned char* __restrict__ sampled, long long total,
+                                                       float* __restrict__ out) {
     __shared__ double sh[256];
-    double bce = 0.0, box = 0.0;
-    for (int j = threadIdx.x; j < n_all; j += 256) {
-        const long long i = all_idx[j];
-        const float x = rpn_out[(size_t)(i / A_cell) * ld + (i % A_cell)];
+    double bce = 0.0, box = 0.0, cnt = 0.0;
+    for (long long i = threadIdx.x; i < total; i += 256) {
+        const unsigned char sm = sampled[i];   // 0 not sampled, 1 sampled positive, 2 sampled negative
+        if (!sm) continue;
+        const size_t cell = (size_t)(i / A_cell);
+        const int a = (int)(i % A_cell);
+        const float x = rpn_out[cell * ld + a];
         const float z = labels[i];
         bce += (double)(fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x))));
-    }
-    for (int j = threadIdx.x; j < n_pos * 4; j += 256) {
-        const long long i = pos_idx[j >> 2];
-        const int c = j & 3;
-        const float p = rpn_out[(size_t)(i / A_cell) * ld + A_cell + (i % A_cell) * 4 + c];
-        box += (double)smooth_l1(p - reg[(size_t)i * 4 + c], 1.0f / 9.0f);
+        cnt += 1.0;
+        if (sm == 1) {
+            for (int c = 0; c < 4; ++c)
+                box += (double)smooth_l1(rpn_out[cell * ld + A_cell + a * 4 + c] - reg[(size_t)i * 4 + c], 1.0f / 9.0f);
+        }
     }
     bce = block_sum_d(bce, sh);
     box = block_sum_d(box, sh);
+    cnt = block_sum_d(cnt, sh);
     if (threadIdx.x == 0) {
-        out[0] = n_all ? (float)(bce / n_all) : nanf("");  // mean over an empty set is nan, like torch
-        out[1] = n_all ? (float)(box / n_all) : nanf("");
+        out[0] = cnt > 0.0 ? (float)(bce / cnt) : nanf("");  // mean over an empty set is nan, like torch
+        out[1] = cnt > 0.0 ? (float)(box / cnt) : nanf("");
     }
 }
 
@@ -192,13 +195,10 @@ extern "C" int rgrg_box_encode_f32(const float* ref_boxes, const float* proposal
 }
 
 extern "C" int rgrg_rpn_loss_f32(const float* rpn_out, int ld, int anchors_per_cell, const float* labels, const float* reg_targets,
-                                 const int64_t* pos_idx, int n_pos, const int64_t* sampled_idx, int n_sampled, float* out2,
-                                 void* stream) {
-    RGRG_CHECK_ARG(rpn_out && labels && reg_targets && out2 && n_pos >= 0 && n_sampled >= 0 && ld >= anchors_per_cell * 5);
-    RGRG_CHECK_ARG((n_pos == 0 || pos_idx) && (n_sampled == 0 || sampled_idx));
+                                 const uint8_t* sampled, int64_t total, float* out2, void* stream) {
+    RGRG_CHECK_ARG(rpn_out && labels && reg_targets && sampled && out2 && total >= 0 && ld >= anchors_per_cell * 5);
     hipLaunchKernelGGL(rpn_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), rpn_out, ld, anchors_per_cell, labels, reg_targets,
-                       reinterpret_cast<const long long*>(pos_idx), n_pos, reinterpret_cast<const long long*>(sampled_idx),
-                       n_sampled, out2);
+                       sampled, (long long)total, out2);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }

@@ -68,6 +68,77 @@ def pick_splitk(M: int, N: int, K: int) -> int:
     return grow(tiles, 256, 16)
 
 
+def balanced_sample_mask(labels: Tensor, keys: Tensor, batch: int, frac: float) -> Tensor:
+    """det_utils.BalancedPositiveNegativeSampler for a whole batch, on the device and without a host round trip:
+    labels [B,n] (>= 1 positive, 0 negative, < 0 ignored), keys [B,n] -> uint8 [B,n]: 1 sampled positive, 2 sampled negative.
+    Per image num_pos = min(#positive, int(batch * frac)), num_neg = min(#negative, batch - num_pos); taken are the
+    candidates with the smallest keys (stable sort: lower index first on ties) - for i.i.d. keys a uniformly random subset,
+    like torchvision's positive[randperm(|positive|)[:num_pos]]."""
+    B, n = labels.shape
+    pos, neg = labels >= 1, labels == 0
+    num_pos = pos.sum(1).clamp(max=int(batch * frac))
+    num_neg = torch.minimum(neg.sum(1), batch - num_pos)
+    ar = torch.arange(n, device=labels.device).expand(B, n)
+    big = torch.full_like(keys, float("inf"))
+
+    def pick(cand: Tensor, k: Tensor) -> Tensor:
+        order = torch.sort(torch.where(cand, keys, big), dim=1, stable=True).indices
+        rank = torch.empty_like(order).scatter_(1, order, ar)
+        return cand & (rank < k[:, None])
+    return pick(pos, num_pos).to(torch.uint8) + 2 * pick(neg, num_neg).to(torch.uint8)
+
+
+def select_training_samples_batched(props: Tensor, counts: Tensor, gt: Tensor, gt_count: Tensor, gt_labels: Tensor, keys: Tensor,
+                                    match_fn, encode_fn, K: int = 512):
+    """RoIHeads.select_training_samples (custom_roi_heads.py:225-226; object_detector.py:118-123: the ground-truth boxes
+    join the proposals, IoU 0.5, K = 512 per image, a quarter positive, BoxCoder weights (10,10,5,5)) for a whole batch with
+    static shapes and no host synchronisation.  props [B,P,4] with counts [B] valid rows, gt [B,G,4] / gt_labels [B,G] with
+    gt_count [B] valid rows, keys [B,P+G] (balanced_sample_mask); match_fn(boxes [B,N,4], box_count int32 [B]) -> matched
+    [B,N] (gt index, -1 below, -2 between; HIP: rgrg_box_match_f32), encode_fn(ref [n,4], proposals [n,4]) -> deltas (HIP:
+    rgrg_box_encode_f32).  -> proposals [B,K,4] (the sampled ones of an image first, in index order, zero padded), offsets
+    int32 [B+1] (device), labels int64 [B*K] and regression targets [B*K,4] in RoI order = image-major compaction (the first
+    offsets[B] rows are meaningful)."""
+    B, P = props.shape[:2]
+    G = gt.shape[1]
+    N = P + G
+    dev = props.device
+    j = torch.arange(N, device=dev)[None, :]
+    cnt, g = counts.to(torch.int64)[:, None], gt_count.to(torch.int64)[:, None]
+    # add_gt_proposals: slots [0, cnt) = proposals, [cnt, cnt + g) = ground truth, the rest unused
+    boxes = torch.zeros((B, N, 4), dtype=torch.float32, device=dev)
+    boxes[:, :P] = torch.where((j[:, :P] < cnt)[:, :, None], props.to(torch.float32), boxes[:, :P])
+    from_gt = (j >= cnt) & (j < cnt + g)
+    gsrc = torch.gather(gt, 1, (j - cnt).clamp(0, G - 1)[:, :, None].expand(B, N, 4))
+    boxes = torch.where(from_gt[:, :, None], gsrc, boxes).contiguous()
+    box_count = (cnt + g)[:, 0].to(torch.int32)
+    m = match_fn(boxes, box_count).to(torch.int64)
+    clamped = m.clamp(0, G - 1)
+    lab = torch.gather(gt_labels, 1, clamped)
+    lab = torch.where(m == -1, torch.zeros_like(lab), lab)       # below the threshold (and every box of an image without gt)
+    lab = torch.where(m == -2, torch.full_like(lab, -1), lab)    # between the thresholds: ignored
+    lab = torch.where(j >= box_count[:, None], torch.full_like(lab, -1), lab)   # unused slots are no candidates
+    smask = balanced_sample_mask(lab, keys, K, 0.25) != 0
+    ks = smask.sum(1)                                             # sampled per image (<= K)
+    jj = j.expand(B, N)
+    idx = torch.sort(torch.where(smask, jj, jj + N), dim=1).indices[:, :K]   # the sampled slots first, in index order
+    if idx.shape[1] < K:
+        idx = torch.cat([idx, idx.new_zeros((B, K - idx.shape[1]))], 1)
+    ar = torch.arange(K, device=dev)[None, :]
+    valid = ar < ks[:, None]
+    props_s = torch.gather(boxes, 1, idx[:, :, None].expand(B, K, 4)) * valid[:, :, None]
+    lab_s = torch.gather(lab, 1, idx)
+    ref_s = torch.gather(gt, 1, torch.gather(clamped, 1, idx)[:, :, None].expand(B, K, 4)) * (gt_count > 0)[:, None, None]
+    offsets_s = torch.cat([ks.new_zeros((1,)), torch.cumsum(ks, 0)])
+    # RoI order: row offsets[i] + k; the unused slots of every image are routed to one dummy row behind the end
+    dest = torch.where(valid, offsets_s[:-1, None] + ar, torch.full((1, 1), B * K, dtype=torch.int64, device=dev)).reshape(-1)
+    labels_flat = torch.zeros((B * K + 1,), dtype=torch.int64, device=dev).scatter_(0, dest, lab_s.reshape(-1))[:B * K]
+    d4 = dest[:, None].expand(-1, 4)
+    props_flat = torch.ones((B * K + 1, 4), dtype=torch.float32, device=dev).scatter_(0, d4, props_s.reshape(-1, 4))[:B * K]
+    ref_flat = torch.ones((B * K + 1, 4), dtype=torch.float32, device=dev).scatter_(0, d4, ref_s.reshape(-1, 4))[:B * K]
+    reg = encode_fn(ref_flat.contiguous(), props_flat.contiguous())
+    return props_s.contiguous(), offsets_s.to(torch.int32), labels_flat.contiguous(), reg
+
+
 def grid_anchors(image_size: int, grid: int) -> Tensor:
     """AnchorGenerator of object_detector.py:78-81 (torchvision 0.13.1 semantics):
     160 anchors per cell, index = (y*grid + x)*160 + ratio*10 + size, base anchors
@@ -438,7 +509,7 @@ class HipEngine:
                                                        _hip.ptr(pooled), B, FH, FW, Cf, maxn, R, scale, self._s()), "rgrg_roi_align")
         return maps, pooled
 
-    def detect(self, images: Tensor, taps: Optional[dict] = None, bf16: bool = False, targets=None, perm_fn=None):
+    def detect(self, images: Tensor, taps: Optional[dict] = None, bf16: bool = False, targets=None, keys_fn=None):
         """ObjectDetector.forward in eval mode: -> (detections, top_region_features, class_detected) or, with
         ``targets`` (list of {"boxes" [n,4], "labels" [n]} per image), (losses, detections, top_region_features,
         class_detected) where - as in the reference - the RoI heads then run on the SAMPLED training proposals.
@@ -457,16 +528,19 @@ class HipEngine:
             if taps is not None:
                 taps.update(features_nhwc=feat, proposals=props, counts=counts, offsets=offsets)
             return {"top_region_boxes": boxes, "top_scores": scores}, top, cd
-        perm_fn = perm_fn or (lambda n, tag: torch.randperm(n, device=images.device))
+        # The samplers' draws: keys_fn(stage, B, n) -> fp32 [B, n]; of an image's positives (negatives) the ones with the
+        # SMALLEST keys are taken, lower index first on ties - a uniformly random subset for i.i.d. keys, like
+        # torchvision's positive[randperm(|positive|)[:k]].  Default: torch.rand on the device.
+        keys_fn = keys_fn or (lambda stage, B, n: torch.rand((B, n), dtype=torch.float32, device=images.device))
         props, counts, offsets, head = self.rpn(feat, return_head=True, feat16=feat16)
         gt, gt_count, gt_labels = self._pad_targets(targets, images.device)
-        loss_obj, loss_rpn_box = self._rpn_losses(head, gt, gt_count, perm_fn)
-        props_s, offsets_s, labels_s, reg_s = self._select_training_samples(props, counts, gt, gt_count, gt_labels, perm_fn)
+        loss_obj, loss_rpn_box = self._rpn_losses(head, gt, gt_count, keys_fn)
+        props_s, offsets_s, labels_s, reg_s = self._select_training_samples(props, counts, gt, gt_count, gt_labels, keys_fn)
         t2 = {} if taps is None else taps
         cd, scores, boxes, top = self.roi_heads(feat, props_s, offsets_s, t2, bf16)
-        R = int(labels_s.shape[0])
         pred = t2.get("pred")
-        if pred is None or R == 0:
+        R = 0 if pred is None else int(pred.shape[0])   # known on the host since roi_heads sized its launches (its one sync)
+        if R == 0:
             # no sampled RoI at all: cross_entropy / smooth_l1 over empty tensors are nan in the reference as well
             out2 = torch.full((2,), float("nan"), dtype=torch.float32, device=images.device)
         else:
@@ -476,25 +550,25 @@ class HipEngine:
         # the reference's dict order: RoI-head losses, then the RPN's (object_detector.py:240-242)
         losses = {"loss_classifier": out2[0], "loss_box_reg": out2[1], "loss_objectness": loss_obj, "loss_rpn_box_reg": loss_rpn_box}
         if taps is not None:
-            taps.update(features_nhwc=feat, proposals=props_s, offsets=offsets_s, sampled_labels=labels_s, sampled_reg_targets=reg_s)
+            taps.update(features_nhwc=feat, proposals=props_s, offsets=offsets_s, sampled_labels=labels_s[:R], sampled_reg_targets=reg_s[:R])
         return losses, {"top_region_boxes": boxes, "top_scores": scores}, top, cd
 
     # ------------------------------------------------------------------ detector targets / losses (eval forward with image_targets)
     @staticmethod
     def _pad_targets(targets, dev):
-        """list of {"boxes", "labels"} -> gt [B,G,4] fp32 (zero padded), gt_count int32 [B], labels list (device int64)."""
+        """list of {"boxes", "labels"} -> gt [B,G,4] fp32 and labels [B,G] int64 (zero padded), gt_count int32 [B].  The sizes
+        come from the tensors' shapes (host metadata): one cat + one scatter, no device read-back."""
         B = len(targets)
-        G = max(1, max(int(t["boxes"].shape[0]) for t in targets))
+        sizes = [int(t["boxes"].shape[0]) for t in targets]
+        G = max(1, max(sizes))
         gt = torch.zeros((B, G, 4), dtype=torch.float32, device=dev)
-        cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
-        labels = []
-        for i, t in enumerate(targets):
-            n = int(t["boxes"].shape[0])
-            if n:
-                gt[i, :n] = t["boxes"].to(device=dev, dtype=torch.float32)
-            cnt[i] = n
-            labels.append(t["labels"].to(device=dev, dtype=torch.int64))
-        return gt, cnt, labels
+        lab = torch.zeros((B, G), dtype=torch.int64, device=dev)
+        if sum(sizes):
+            row = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes)).to(dev)
+            col = torch.cat([torch.arange(n) for n in sizes]).to(dev)
+            gt[row, col] = torch.cat([t["boxes"].to(device=dev, dtype=torch.float32).reshape(-1, 4) for t in targets])
+            lab[row, col] = torch.cat([t["labels"].to(device=dev, dtype=torch.int64).reshape(-1) for t in targets])
+        return gt, torch.tensor(sizes, dtype=torch.int32, device=dev), lab
 
     def _match(self, gt, gt_count, boxes, box_image_stride, box_count, N, high, low, allow_low_quality) -> Tensor:
         B, G = gt.shape[:2]
@@ -512,91 +586,30 @@ class HipEngine:
                                                 _hip.ptr(out), self._s()), "rgrg_box_encode_f32")
         return out
 
-    @staticmethod
-    def _balanced_sample(labels: Tensor, batch: int, frac: float, perm_fn, tag):
-        """det_utils.BalancedPositiveNegativeSampler for one image (index plumbing; the draws come from perm_fn)."""
-        positive = torch.where(labels >= 1)[0]
-        negative = torch.where(labels == 0)[0]
-        num_pos = min(positive.numel(), int(batch * frac))
-        num_neg = min(negative.numel(), batch - num_pos)
-        p1 = perm_fn(positive.numel(), (tag, "pos")).to(labels.device)[:num_pos]
-        p2 = perm_fn(negative.numel(), (tag, "neg")).to(labels.device)[:num_neg]
-        return positive[p1], negative[p2]
-
-    def _rpn_losses(self, head: Tensor, gt: Tensor, gt_count: Tensor, perm_fn):
+    def _rpn_losses(self, head: Tensor, gt: Tensor, gt_count: Tensor, keys_fn):
         """RegionProposalNetwork.assign_targets_to_anchors + encode + compute_loss (custom_rpn.py:74-83;
-        object_detector.py:84-96: fg 0.7 / bg 0.3, low-quality matches, 256 anchors per image, half positive)."""
+        object_detector.py:84-96: fg 0.7 / bg 0.3, low-quality matches, 256 anchors per image, half positive).  Matching,
+        encoding and the losses are HIP kernels; the sampler is a device-side mask (balanced_sample_mask) the loss kernel
+        reads directly - no index lists, no per-image loop, no host synchronisation."""
         B, FH, FW, ld = head.shape
         A = self.anchors.shape[0]
-        dev = head.device
         m = self._match(gt, gt_count, self.anchors, 0, None, A, 0.7, 0.3, True)
         labels = (m >= 0).to(torch.float32)
         labels[m == -2] = -1.0  # between the thresholds: ignored (BELOW_LOW_THRESHOLD already maps to 0)
         ref = torch.gather(gt, 1, m.clamp(min=0).to(torch.int64)[:, :, None].expand(B, A, 4))  # images without gt: zeros
         reg = self._encode(ref.reshape(B * A, 4), self.anchors.repeat(B, 1), (1.0, 1.0, 1.0, 1.0))
-        pos_masks, neg_masks = [], []
-        for i in range(B):
-            p, n = self._balanced_sample(labels[i], 256, 0.5, perm_fn, ("rpn", i))
-            pm = torch.zeros((A,), dtype=torch.bool, device=dev)
-            nm = torch.zeros((A,), dtype=torch.bool, device=dev)
-            pm[p] = True
-            nm[n] = True
-            pos_masks.append(pm)
-            neg_masks.append(nm)
-        pos_idx = torch.where(torch.cat(pos_masks))[0]
-        all_idx = torch.cat([pos_idx, torch.where(torch.cat(neg_masks))[0]]).contiguous()
-        out2 = torch.empty((2,), dtype=torch.float32, device=dev)
-        _hip.check(self.lib.rgrg_rpn_loss_f32(_hip.ptr(head), ld, self.num_anchors, _hip.ptr(labels), _hip.ptr(reg),
-                                              _hip.ptr(pos_idx) if pos_idx.numel() else None, pos_idx.numel(),
-                                              _hip.ptr(all_idx) if all_idx.numel() else None, all_idx.numel(), _hip.ptr(out2), self._s()),
-                   "rgrg_rpn_loss_f32")
+        sampled = balanced_sample_mask(labels, keys_fn("rpn", B, A), 256, 0.5).contiguous()
+        out2 = torch.empty((2,), dtype=torch.float32, device=head.device)
+        _hip.check(self.lib.rgrg_rpn_loss_f32(_hip.ptr(head), ld, self.num_anchors, _hip.ptr(labels.contiguous()), _hip.ptr(reg),
+                                              _hip.ptr(sampled), B * A, _hip.ptr(out2), self._s()), "rgrg_rpn_loss_f32")
         return out2[0], out2[1]
 
-    def _select_training_samples(self, props: Tensor, counts: Tensor, gt: Tensor, gt_count: Tensor, gt_labels, perm_fn):
-        """RoIHeads.select_training_samples (custom_roi_heads.py:225-226; object_detector.py:118-123: IoU 0.5, 512
-        per image, a quarter positive, BoxCoder weights (10,10,5,5)) -> proposals [B,maxK,4], offsets int32 [B+1],
-        labels int64 [sum K], regression targets [sum K,4]."""
-        B, G = gt.shape[:2]
-        dev = props.device
-        cnt, gcnt = counts.tolist(), gt_count.tolist()
-        N = max(c + g for c, g in zip(cnt, gcnt))
-        boxes = torch.zeros((B, N, 4), dtype=torch.float32, device=dev)
-        for i in range(B):  # add_gt_proposals
-            boxes[i, :cnt[i]] = props[i, :cnt[i]]
-            boxes[i, cnt[i]:cnt[i] + gcnt[i]] = gt[i, :gcnt[i]]
-        box_count = torch.tensor([c + g for c, g in zip(cnt, gcnt)], dtype=torch.int32, device=dev)
-        m = self._match(gt, gt_count, boxes, N * 4, box_count, N, 0.5, 0.5, False)
-        out_props, out_labels, out_ref = [], [], []
-        for i in range(B):
-            n = cnt[i] + gcnt[i]
-            mi = m[i, :n].to(torch.int64)
-            clamped = mi.clamp(min=0)
-            if gcnt[i]:
-                lab = gt_labels[i][clamped]
-                lab = torch.where(mi == -1, torch.zeros_like(lab), lab)
-                lab = torch.where(mi == -2, torch.full_like(lab, -1), lab)
-            else:
-                lab = torch.zeros((n,), dtype=torch.int64, device=dev)
-            p, q = self._balanced_sample(lab, 512, 0.25, perm_fn, ("roi", i))
-            mask = torch.zeros((n,), dtype=torch.bool, device=dev)
-            mask[p] = True
-            mask[q] = True
-            inds = torch.where(mask)[0]
-            out_props.append(boxes[i, inds])
-            out_labels.append(lab[inds])
-            out_ref.append(gt[i][clamped[inds]] if gcnt[i] else torch.zeros((inds.numel(), 4), dtype=torch.float32, device=dev))
-        ks = [int(p.shape[0]) for p in out_props]
-        maxk = max(1, max(ks))
-        props_s = torch.zeros((B, maxk, 4), dtype=torch.float32, device=dev)
-        for i, p in enumerate(out_props):
-            props_s[i, :ks[i]] = p
-        offs = [0]
-        for k in ks:
-            offs.append(offs[-1] + k)
-        offsets_s = torch.tensor(offs, dtype=torch.int32, device=dev)
-        allp = torch.cat(out_props) if sum(ks) else torch.zeros((0, 4), dtype=torch.float32, device=dev)
-        reg = self._encode(torch.cat(out_ref), allp, (10.0, 10.0, 5.0, 5.0)) if sum(ks) else allp
-        return props_s, offsets_s, torch.cat(out_labels).contiguous(), reg
+    def _select_training_samples(self, props: Tensor, counts: Tensor, gt: Tensor, gt_count: Tensor, gt_labels: Tensor, keys_fn):
+        B, N = props.shape[0], props.shape[1] + gt.shape[1]
+        return select_training_samples_batched(
+            props, counts, gt, gt_count, gt_labels, keys_fn("roi", B, N),
+            lambda boxes, box_count: self._match(gt, gt_count, boxes, N * 4, box_count, N, 0.5, 0.5, False),
+            lambda ref, pr: self._encode(ref, pr, (10.0, 10.0, 5.0, 5.0)))
 
     # ------------------------------------------------------------------ selection
     def classifier_logits(self, mlp, x: Tensor) -> Tensor:

@@ -1,7 +1,9 @@
 """ObjectDetector.forward / ReportGenerationModel.forward in eval mode WITH image_targets (the
 call of the reference's validation loop, evaluate_model.py:413): target assignment, sampling and the four detector
-losses on the HIP path against the CPU oracle.  torchvision's samplers draw with torch.randperm; both sides get the
-same draws through an injected permutation function.  Match codes are compared bit-exactly, losses to 5e-4 relative."""
+losses on the HIP path against the CPU oracle.  torchvision's samplers draw with torch.randperm: the oracle (like the
+real reference behind the fixture) gets a seeded permutation, its samplers' choices are recorded and replayed on the HIP
+path as per-element keys (chosen: 0, everything else: 1 - the device-side sampler takes the smallest keys), so both sides
+score the same anchors / proposals.  Match codes are compared bit-exactly, losses to 5e-4 relative."""
 import ctypes as C
 
 import pytest
@@ -20,6 +22,35 @@ DEV = "cuda:0"
 def _perm(seed):
     g = torch.Generator().manual_seed(seed)
     return lambda n, tag: torch.randperm(n, generator=g)
+
+
+class _RecordedDraws:
+    """Context manager around an oracle run: records which indices tv013.balanced_sample took per (stage, image);
+    keys_fn replays them on the HIP path (ObjectDetector.sampler_keys)."""
+
+    def __init__(self):
+        self.rec = {}
+
+    def __enter__(self):
+        self._orig = tv013.balanced_sample
+
+        def wrap(labels, batch, frac, perm_fn, tag):
+            p, q = self._orig(labels, batch, frac, perm_fn, tag)
+            self.rec[tag] = (p.clone(), q.clone())
+            return p, q
+        tv013.balanced_sample = wrap
+        return self
+
+    def __exit__(self, *exc):
+        tv013.balanced_sample = self._orig
+
+    def keys_fn(self, stage, B, n):
+        keys = torch.ones((B, n))
+        for b in range(B):
+            p, q = self.rec[(stage, b)]
+            keys[b, p] = 0.0
+            keys[b, q] = 0.0
+        return keys.to(DEV)
 
 
 def _targets(sd, images):
@@ -73,13 +104,14 @@ def test_detector_eval_forward_with_targets_matches_oracle():
     images = torch.cat([synth.make_images(1, 1234), synth.make_images(1, 77)], 0)
     targets = _targets(sd, images)
     targets[1] = {"boxes": targets[1]["boxes"][:5], "labels": targets[1]["labels"][:5]}
-    ref_losses, ref_det, ref_top, ref_cd = o_det.object_detector_forward(sd, images, targets=targets, perm_fn=_perm(3))
+    with _RecordedDraws() as draws:
+        ref_losses, ref_det, ref_top, ref_cd = o_det.object_detector_forward(sd, images, targets=targets, perm_fn=_perm(3))
     det = m.object_detector
-    det.sampler_perm = _perm(3)
+    det.sampler_keys = draws.keys_fn
     try:
         losses, dets, top, cd = det(images.to(DEV), [{k: v.to(DEV) for k, v in t.items()} for t in targets])
     finally:
-        det.sampler_perm = None
+        det.sampler_keys = None
     assert list(losses) == list(ref_losses) == ["loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg"]
     for k in losses:  # 5e-4 relative: the class logits come out of fc6 (K = 131072, fp32, different summation order)
         a, b = float(losses[k]), float(ref_losses[k])
@@ -92,12 +124,16 @@ def test_detector_eval_forward_with_targets_matches_oracle():
     assert err <= 1e-3 * ref_top.abs().max().item() + 1e-4, err
     # an image without any ground truth: every sampled proposal is background, box losses of that image vanish
     empty = [{"boxes": torch.zeros((0, 4)), "labels": torch.zeros((0,), dtype=torch.int64)} for _ in range(2)]
-    ref_e, _, _, _ = o_det.object_detector_forward(sd, images, targets=empty, perm_fn=_perm(4))
-    det.sampler_perm = _perm(4)
+    with _RecordedDraws() as draws:
+        ref_e, _, _, _ = o_det.object_detector_forward(sd, images, targets=empty, perm_fn=_perm(4))
+    det.sampler_keys = draws.keys_fn
     try:
         le, _, _, _ = det(images.to(DEV), [{k: v.to(DEV) for k, v in t.items()} for t in empty])
     finally:
-        det.sampler_perm = None
+        det.sampler_keys = None
+    # the default draws (torch.rand keys on the device): a valid run with finite classification losses
+    ld, _, _, _ = det(images.to(DEV), [{k: v.to(DEV) for k, v in t.items()} for t in targets])
+    assert all(torch.isfinite(v) for v in ld.values()) and abs(float(ld["loss_objectness"]) - float(ref_losses["loss_objectness"])) < 0.5
     assert float(le["loss_box_reg"]) == 0.0 and float(le["loss_rpn_box_reg"]) == 0.0
     for k in le:
         assert abs(float(le[k]) - float(ref_e[k])) <= 5e-4 * max(1.0, abs(float(ref_e[k]))), k
@@ -116,21 +152,21 @@ def test_full_model_eval_forward_accepts_image_targets_like_the_validation_loop(
     attention_mask = torch.ones((29, T))
     has_sentence = torch.rand((1, 29), generator=g) > 0.3
     abnormal = torch.rand((1, 29), generator=g) > 0.6
-    m.object_detector.sampler_perm = _perm(6)
+    with _RecordedDraws() as draws:   # the same call through the oracle first: its draws are replayed below
+        ref = o_full.forward_eval(sd, images, input_ids, attention_mask, has_sentence, abnormal, image_targets=targets, perm_fn=_perm(6))
+    m.object_detector.sampler_keys = draws.keys_fn
     was = m.pretrain_without_lm_model   # the shared test model is built with it set (7-tuple, no LM loss): full model here
     m.pretrain_without_lm_model = False
     try:
         out = m(images.to(DEV), [{k: v.to(DEV) for k, v in t.items()} for t in targets], input_ids.to(DEV), attention_mask.to(DEV),
                 has_sentence.to(DEV), abnormal.to(DEV))
     finally:
-        m.object_detector.sampler_perm = None
+        m.object_detector.sampler_keys = None
         m.pretrain_without_lm_model = was
     assert isinstance(out, tuple) and len(out) == 8
     loss_dict, l_sel, l_abn, l_lm, dets, cd, sel, pred_abn = out
     assert sorted(loss_dict) == ["loss_box_reg", "loss_classifier", "loss_objectness", "loss_rpn_box_reg"]
     assert all(torch.isfinite(v) for v in loss_dict.values()) and torch.isfinite(l_lm)
-    # the same call through the oracle with the same draws
-    ref = o_full.forward_eval(sd, images, input_ids, attention_mask, has_sentence, abnormal, image_targets=targets, perm_fn=_perm(6))
     for k in loss_dict:
         assert abs(float(loss_dict[k]) - float(ref[0][k])) <= 5e-4 * max(1.0, abs(float(ref[0][k]))), k
     assert torch.equal(cd.cpu(), ref[5]) and torch.equal(sel.cpu(), ref[6]) and torch.equal(pred_abn.cpu(), ref[7])
@@ -144,14 +180,18 @@ def test_full_model_eval_forward_with_targets_matches_reference_fixture():
     m = gpu_model(fx["meta"]["profile"])
     images = torch.cat([synth.make_images(1, s) for s in fx["meta"]["image_seeds"]], 0)
     i, e = fx["inputs"], fx["expected"]
-    m.object_detector.sampler_perm = _perm(fx["meta"]["perm_seed"])
+    # the samplers' choices of the reference run = the oracle's with the same seeded permutation (the oracle reproduces the
+    # fixture, tests/test_oracle_golden.py): recorded from the oracle's detector pass, replayed as keys
+    with _RecordedDraws() as draws:
+        o_det.object_detector_forward(synth_sd(fx["meta"]["profile"]), images, targets=i["targets"], perm_fn=_perm(fx["meta"]["perm_seed"]))
+    m.object_detector.sampler_keys = draws.keys_fn
     was = m.pretrain_without_lm_model
     m.pretrain_without_lm_model = False
     try:
         out = m(images.to(DEV), [{k: v.to(DEV) for k, v in t.items()} for t in i["targets"]], i["input_ids"].to(DEV),
                 i["attention_mask"].to(DEV), i["region_has_sentence"].to(DEV), i["region_is_abnormal"].to(DEV))
     finally:
-        m.object_detector.sampler_perm = None
+        m.object_detector.sampler_keys = None
         m.pretrain_without_lm_model = was
     assert list(out[0]) == list(e["obj_detector_loss_dict"])
     for k, v in e["obj_detector_loss_dict"].items():
