@@ -34,19 +34,28 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 MFMA_PEAK_TFS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md dense peaks (no sparsity)
 
 
-def pmc_traffic(key):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json,
-    written by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as the gfx950
-    note of MI355X_MICROARCH.md prescribes): counters cannot be collected from inside the timed process, so the last
-    committed measurement of the same command is quoted; None when there is none for this configuration."""
+def pmc_traffic(family, S_dec, dtype):
+    """HBM bytes per launch of a kernel family ("gemm" / "attn") from the committed rocprofv3 PMC passes
+    (profiles/rNN_pmc_traffic.json, written by tools/pmc_traffic.py / tools/pmc_gemm_step_traffic.py from separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as the gfx950 note of MI355X_MICROARCH.md prescribes): counters cannot
+    be collected from inside the timed process, so the last committed measurement of the same configuration is quoted -
+    key <family>_S<sequences>_<dtype>, matched on the dtype and a sequence count within 1 % (the number of regions the
+    detector finds on the synthetic batch moves by one or two between builds); None when there is none."""
+    import re
     for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # newest committed measurement that has the key
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
-                v = json.load(f).get(key)
-            if v is not None:
-                return float(v)
+                table = json.load(f)
         except Exception:  # noqa: BLE001
-            pass
+            continue
+        best = None
+        for k, v in table.items():
+            m = re.fullmatch(rf"{family}_S(\d+)_{dtype}", k)
+            if m and isinstance(v, (int, float)) and abs(int(m.group(1)) - S_dec) <= max(0.01 * S_dec, 0):
+                if best is None or abs(int(m.group(1)) - S_dec) < best[0]:
+                    best = (abs(int(m.group(1)) - S_dec), float(v))
+        if best is not None:
+            return best[1]
     return None
 
 
@@ -59,11 +68,10 @@ def rooflines(eng, S_dec, dtype, max_length):
     nkeys = (2 + (max_length + 1)) // 2
     p = eng.time_step_parts(S_dec, nkeys, iters=3)
     n = max(p["gemm_launches"], 1)
-    cfg = f"S{S_dec}_{dtype}"
     if S_dec <= 128:
         ach = p["gemm_weight_bytes"] / (p["ms_gemm"] * 1e-3) / 1e9
         gemm = {"bound": "hbm", "kernel": "rgrg_skinny_direct_f32 (+ _half, rgrg_lm_head_wave_f32)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(f"gemm_{cfg}"), "launches_per_decode_step": n,
+                "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("gemm", S_dec, dtype), "launches_per_decode_step": n,
                 "avg_launch_us": 1e3 * p["ms_gemm"] / n, "algorithmic_bytes_per_launch": p["gemm_weight_bytes"] / n,
                 "note": "achieved = fp32 weight bytes of the GEMM launches of one decode step (each weight read once) / their duration "
                         "between two HIP events on the decoder stream, launched back to back in step order"}
@@ -71,12 +79,12 @@ def rooflines(eng, S_dec, dtype, max_length):
         peak = MFMA_PEAK_TFS[dtype]
         ach = p["gemm_flops"] / (p["ms_gemm"] * 1e-3) / 1e12
         gemm = {"bound": "mfma", "kernel": "gemm_bf16_glds_kernel" if dtype == "bf16" else "gemm_f32_kernel", "achieved": ach, "peak": peak,
-                "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic(f"gemm_{cfg}"), "launches_per_decode_step": n,
+                "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic("gemm", S_dec, dtype), "launches_per_decode_step": n,
                 "avg_launch_us": 1e3 * p["ms_gemm"] / n, "algorithmic_flops_per_launch": p["gemm_flops"] / n,
                 "note": "achieved = 2 M N K of the GEMM launches of one decode step / their duration between two HIP events on the decoder stream"}
     ach = p["kv_bytes"] / (p["ms_attn"] * 1e-3) / 1e9
     attn = {"bound": "hbm", "kernel": "attn_decode_kv16_wave_kernel" if (dtype == "bf16" and S_dec > 128) else "attn_decode_kernel",
-            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(f"attn_{cfg}"),
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("attn", S_dec, dtype),
             "launches_per_decode_step": 24, "avg_launch_us": 1e3 * p["ms_attn"] / 24, "algorithmic_bytes_per_launch": p["kv_bytes"] / 24,
             "keys_per_sequence": nkeys,
             "note": "achieved = K/V cache bytes of the 24 attention launches of one step at the mid-sequence key count / their duration "
