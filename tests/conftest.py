@@ -10,6 +10,12 @@ if REPO not in sys.path:
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
+# The CPU oracle is small-GEMV work: on the GPU box's 128 cores torch's default (one thread per core) makes it ~6x SLOWER
+# than 8 threads (bench.py cpu_baseline: 0.010 vs 0.066 images/s), and the golden fixtures were generated with 8 threads (the
+# build container) - pin that at import (the child processes of some GPU tests import this module too), for speed and for
+# an identical summation order in the oracle's GEMMs.
+torch.set_num_threads(min(8, os.cpu_count() or 8))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
