@@ -555,6 +555,47 @@ def test_two_training_steps_follow_the_oracle():
     m.invalidate_engine()
 
 
+def test_training_steps_under_fp16_autocast_with_gradscaler_like_the_reference_loop():
+    """The reference's loop (train_full_model.py:172-237): `with torch.autocast(fp16)` around the forward,
+    `scaler.scale(loss).backward()`, `scaler.step(optimizer)`, `scaler.update()`.  The HIP backward multiplies its
+    gradients by the incoming (scaled) gradient, GradScaler unscales them in place and drives the HIP AdamW.  The scale
+    is a power of two, so scaling and unscaling are exact: two scaler-driven steps reproduce two plain steps bit for
+    bit (66 token rows: the pass stays fp32 under autocast), no step is skipped and the scale is not backed off."""
+    from rgrg_amd import optim
+    fx = load_golden("lm_grads.pt")
+    ids, am, feats = fx["input_ids"], fx["attention_mask"], fx["feats"]
+
+    def run(with_scaler):
+        m = _lm_train_model()
+        lm = m.language_model
+        lm.train()
+        hopt = optim.AdamW(lm.trainable_parameters(), lr=2e-3, weight_decay=0.01)
+        scaler = torch.amp.GradScaler("cuda", init_scale=65536.0) if with_scaler else None
+        losses = []
+        for _ in range(2):
+            hopt.zero_grad()
+            if with_scaler:
+                with torch.autocast("cuda", dtype=torch.float16):
+                    loss = lm(ids.clone().to(DEV), am.to(DEV), feats.to(DEV), return_loss=True)
+                scaler.scale(loss).backward()
+                scaler.step(hopt)
+                scaler.update()
+            else:
+                loss = lm(ids.clone().to(DEV), am.to(DEV), feats.to(DEV), return_loss=True)
+                loss.backward()
+                hopt.step()
+            losses.append(loss.item())
+        params = [q.detach().clone() for q in lm.trainable_parameters()]
+        scale = scaler.get_scale() if with_scaler else None
+        m.invalidate_engine()
+        return losses, params, scale
+    l_plain, p_plain, _ = run(False)
+    l_amp, p_amp, scale = run(True)
+    assert scale == 65536.0
+    assert l_amp == l_plain and abs(l_plain[0] - l_plain[1]) > 1e-2
+    assert all(torch.equal(a, b) for a, b in zip(p_amp, p_plain))
+
+
 def test_full_training_forward_losses_and_gradients_vs_oracle():
     """ReportGenerationModel.forward in train() mode (frozen detector): the 4-tuple of the reference's training branch,
     losses and every trainable tensor's gradient against torch autograd through the oracle on the same images."""
