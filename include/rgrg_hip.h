@@ -163,7 +163,7 @@ typedef struct rgrg_decoder rgrg_decoder;
  * <=32-sequence path - LayerNorm gains folded in -, workspace for max_seqs sequences x max_len
  * positions).  SYNCHRONISES THE DEVICE on entry and before returning: the weights are packed on the
  * decoder's own stream and this entry has no stream argument, so it first waits for whatever is still
- * producing them on the caller's streams.  Not on the hot loop. */
+ * producing them on the caller's streams.  Not on the hot loop.   max_seqs < 65536 (16-bit row tickets of the arg-max bookkeeping). */
 int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, int max_len, rgrg_decoder** out);
 void rgrg_decoder_destroy(rgrg_decoder* d);
 /* feats [S,1024] (selected region features); out_ids int64 [S,max_length] is filled

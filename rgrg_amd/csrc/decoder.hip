@@ -713,10 +713,14 @@ __global__ __launch_bounds__(256) void kv_slot0_kernel(const float* __restrict__
 }
 
 // First-occurrence arg-max over the vocabulary (torch.argmax) fused with the greedy_search
-// bookkeeping (:629-650).  The lm_head GEMM already reduced every 32-column tile to one
-// (max, index) candidate (ties: lower index), so a row is NT ~ 1571 candidates; the LAST
-// workgroup to arrive (integer ticket -> deterministic) records the first length at which
-// every row is finished and advances the step counter.  sync[0] = unfinished rows, sync[1] = tickets.
+// bookkeeping (:629-650).  The lm_head GEMM already reduced every 16- / 32-column tile to one
+// (max, index) candidate (ties: lower index), so a row is NT <= 3142 candidates: a thread requests its
+// (up to 13) candidates up front with clamped indices - one memory latency instead of one per loop trip.
+// The LAST workgroup to arrive records the first length at which every row is finished and advances the
+// step counter: arrival and "this row is still unfinished" travel in ONE packed atomic (low 16 bits: tickets,
+// high 16 bits: unfinished rows; S < 65536), so no fence and no second atomic order the two - the integer
+// ticket keeps the result deterministic.  sync[0] = the packed word.
+constexpr int ARGMAX_U = 13;
 __global__ __launch_bounds__(256) void argmax_update_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
                                                             int NT, long long* __restrict__ ids, int ld_ids,
                                                             int* __restrict__ finished, int* __restrict__ step,
@@ -725,12 +729,25 @@ __global__ __launch_bounds__(256) void argmax_update_kernel(const float* __restr
     __shared__ int bi[4];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = *step;
+    const float* cv = cand_val + (size_t)row * NT;
+    const int* cx = cand_idx + (size_t)row * NT;
+    float v[ARGMAX_U];
+    int ci[ARGMAX_U];
+#pragma unroll
+    for (int u = 0; u < ARGMAX_U; ++u) {
+        const int i = min(tid + 256 * u, NT - 1);
+        v[u] = cv[i];
+        ci[u] = cx[i];
+    }
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int i = tid; i < NT; i += 256) {
-        const float v = cand_val[(size_t)row * NT + i];
-        const int ci = cand_idx[(size_t)row * NT + i];
-        if (v > best || (v == best && ci < idx)) { best = v; idx = ci; }
+#pragma unroll
+    for (int u = 0; u < ARGMAX_U; ++u)
+        if (tid + 256 * u < NT && (v[u] > best || (v[u] == best && ci[u] < idx))) { best = v[u]; idx = ci[u]; }
+    for (int i = tid + 256 * ARGMAX_U; i < NT; i += 256) {   // more than 3328 candidates per row: not a shape of this model
+        const float w = cv[i];
+        const int wi = cx[i];
+        if (w > best || (w == best && wi < idx)) { best = w; idx = wi; }
     }
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o, 64);
@@ -748,16 +765,13 @@ __global__ __launch_bounds__(256) void argmax_update_kernel(const float* __restr
         ids[(size_t)row * ld_ids + t + 1] = tok;
         if (tok == EOS_ID) fin = 1;
         finished[row] = fin;
-        if (!fin) atomicAdd(&sync[0], 1);
-        __threadfence();
-        const int ticket = atomicAdd(&sync[1], 1);
-        if (ticket == S - 1) {  // every row has been recorded
-            __threadfence();
-            const int unfinished = atomicAdd(&sync[0], 0);
+        const unsigned mine = fin ? 0u : 0x10000u;
+        const unsigned old = atomicAdd(reinterpret_cast<unsigned*>(sync), 1u + mine);
+        if ((old & 0xffffu) == (unsigned)(S - 1)) {  // every row has been recorded
+            const unsigned unfinished = (old >> 16) + (mine >> 16);
             if (unfinished == 0 && *done_len == 0) *done_len = t + 2;
             *step = t + 1;
             sync[0] = 0;
-            sync[1] = 0;
         }
     }
 }
@@ -1708,7 +1722,7 @@ static int enqueue_prefill(rgrg_decoder* d, const float* feats, int S, int row_m
 }  // namespace rgrg
 
 extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, int max_len, rgrg_decoder** out) {
-    RGRG_CHECK_ARG(w && out && max_seqs > 0 && max_len >= 2 && max_len <= 1024);
+    RGRG_CHECK_ARG(w && out && max_seqs > 0 && max_seqs < 65536 && max_len >= 2 && max_len <= 1024);  // 16-bit row tickets (argmax_update_kernel)
     RGRG_CHECK_ARG(w->d_model == 1024 && w->n_head == 16 && w->n_layer > 0 && w->vocab > 0 && w->layers);
     int rc = init_gemm_attrs();
     if (rc) return rc;
