@@ -378,9 +378,16 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
-    f32x4 v[4];
+    f32x4 v[4], gg[4], bb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = xr[j * 64 + lane];
+    // gain and bias are requested right behind the row (not after the two reductions): one memory latency per launch
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        gg[j] = reinterpret_cast<const f32x4*>(g)[j * 64 + lane];
+        bb[j] = reinterpret_cast<const f32x4*>(b)[j * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
@@ -394,10 +401,9 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
     const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) / (float)D + LN_EPS);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[j * 64 + lane], bb = reinterpret_cast<const f32x4*>(b)[j * 64 + lane];
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = v[j][e] * rstd * gg[e] + bb[e];
+        for (int e = 0; e < 4; ++e) o[e] = v[j][e] * rstd * gg[j][e] + bb[j][e];
         if (xn16) store_bf16x4(xn16 + (size_t)row * D + 4 * (j * 64 + lane), o);
         else reinterpret_cast<f32x4*>(xn + (size_t)row * D)[j * 64 + lane] = o;
     }
