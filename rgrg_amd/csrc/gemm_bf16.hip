@@ -407,6 +407,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+    // Epilogue operands requested NOW, ahead of the operand stream: the per-column shift of every block and - for a 64 x 64
+    // tile, where it is 16 registers - the fp32 residual of this lane's outputs.  Loaded in the epilogue they add a cold
+    // L2 / HBM round trip to the tail of every launch.  (Vector loads return in order and these are the oldest ones, so the
+    // counted vmcnt waits of the pipeline below are unaffected.  In-place residual (R == Y) is fine: an element is read and
+    // written by the same thread only.)
+    const int ccol = lane & 31, crow4 = 4 * (lane >> 5);
+    float sh_pre[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int colc = min(n0 + wn * (BN / 2) + ni * 32 + ccol, p.N - 1);
+            sh_pre[mi][ni] = p.shift ? p.shift[colc] : 0.f;
+        }
+    constexpr bool PRE_R = MI * NI == 1;
+    float rv_pre[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rv_pre[r] = 0.f;
+    if constexpr (PRE_R) {
+        if (p.R) {
+            const int colc = min(n0 + wn * (BN / 2) + ccol, p.N - 1);
+            const int rbase = m0 + wm * (BM / 2) + crow4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+                rv_pre[r] = p.R[(size_t)row * p.ldy + colc];
+            }
+        }
+    }
+
 #define RGRG_GLDS_COMPUTE(STAGE_)                                                                         \
     glds_compute<MI, NI>(glds_smem + (STAGE_) * STAGE + wm * (BM / 2) * 128,                              \
                          glds_smem + (STAGE_) * STAGE + BM * 128 + wn * (BN / 2) * 128, foff, acc)
@@ -441,7 +471,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
 
     // epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  Residual reads use
     // clamped rows and are issued together; only the stores are predicated.  Offsets are 32-bit inside the tile's rows.
-    const int ccol = lane & 31, crow4 = 4 * (lane >> 5);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -449,11 +478,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
             const int col = n0 + wn * (BN / 2) + ni * 32 + ccol;
             const int colc = min(col, p.N - 1);
             const int rbase = m0 + wm * (BM / 2) + mi * 32 + crow4;
-            const float sh = p.shift ? p.shift[colc] : 0.f;
+            const float sh = sh_pre[mi][ni];
             float rv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-            if (p.R) {
+            for (int r = 0; r < 16; ++r) rv[r] = rv_pre[r];   // 64 x 64 tiles: the residual prefetched above (zeros otherwise)
+            if (!PRE_R && p.R) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
