@@ -902,3 +902,27 @@ def test_incremental_forward_with_use_cache_reproduces_the_oracles_cached_steps(
         if unfinished.max() == 0 or ids.shape[1] >= 10:
             break
     assert torch.equal(ids, ref)
+
+
+def test_incremental_forward_with_use_cache_matches_reference_fixture():
+    """The same three calls as tests/golden/lm_cached_steps.pt recorded from the REAL reference's
+    forward(use_cache=True[, past_key_values]): logits of every call and the final presents of layers 0 / 11 / 23 within
+    2e-3 (the tolerance of the oracle comparison above; the oracle reproduces this fixture exactly)."""
+    fx = load_golden("lm_cached_steps.pt")
+    m = gpu_model(fx["meta"]["profile"])
+    lm = m.language_model
+    feats = fx["feats"].to(DEV)
+    presents, ntok = None, 0
+    for c in fx["calls"]:
+        T = c["input_ids"].shape[1]
+        am = torch.ones((3, ntok + T), device=DEV)
+        logits, presents = lm(c["input_ids"].to(DEV), am, feats, return_loss=False, past_key_values=presents,
+                              position_ids=c["position_ids"], use_cache=True)
+        assert logits.shape == (3, T, 50257)
+        assert (logits[:, -1].cpu() - c["logits_last"]).abs().max().item() <= 2e-3
+        if "logits_first_probe" in c:
+            assert (logits[:, 0, ::97].cpu() - c["logits_first_probe"]).abs().max().item() <= 2e-3
+        ntok += T
+    for l, (k, v) in fx["presents"].items():
+        assert presents[l][0].shape == k.shape
+        assert (presents[l][0].cpu() - k).abs().max().item() <= 2e-3 and (presents[l][1].cpu() - v).abs().max().item() <= 2e-3

@@ -150,3 +150,21 @@ def test_eval_forward_with_image_targets_oracle_matches_reference(sd_bench):
         assert abs(got.item() - e[key].item()) <= 1e-5, key
     assert torch.equal(out[5], e["class_detected"]) and torch.equal(out[6], e["selected_regions"])
     assert torch.equal(out[7], e["predicted_abnormal_regions"]) and torch.equal(out[4]["top_region_boxes"], e["top_region_boxes"])
+
+
+def test_incremental_forward_oracle_matches_reference_cached_steps(sd_ragged):
+    """lm_cached_steps.pt: the REAL reference's forward(use_cache=True) on a prompt and two single-token calls fed with its
+    own presents (tests/golden/make_golden_lm_cached.py) - the oracle's lm_forward reproduces logits and presents exactly."""
+    fx = load_golden("lm_cached_steps.pt")
+    assert fx["meta"]["oracle_matches_reference"] is True
+    feats, past, ntok = fx["feats"], None, 0
+    for c in fx["calls"]:
+        T = c["input_ids"].shape[1]
+        am = torch.ones((3, ntok + T), dtype=torch.int64)
+        logits, past = o_lm.lm_forward(sd_ragged, c["input_ids"], am, feats, past, c["position_ids"])
+        assert torch.equal(logits[:, -1], c["logits_last"])
+        if "logits_first_probe" in c:
+            assert torch.equal(logits[:, 0, ::97], c["logits_first_probe"])
+        ntok += T
+    for l, (k, v) in fx["presents"].items():
+        assert torch.equal(past[l][0], k) and torch.equal(past[l][1], v)
