@@ -42,6 +42,22 @@ def main():
     out["meta"]["oracle_matches_reference"] = bool(ok_all)
     torch.save(out, os.path.join(HERE, "lm_beam4.pt"))
     print("saved lm_beam4.pt; oracle matches reference:", ok_all)
+    # round 3: 16 beams (the widest the HIP path ranks), 3 regions, also with several returned hypotheses per region
+    wide = {"meta": dict(out["meta"], num_beams=16), "cases": {}}
+    ok_wide = True
+    for name, max_length, early, nret in (("beams16_len14_early", 14, True, 1), ("beams16_len10_ret4", 10, False, 4)):
+        with torch.no_grad():
+            ref = model.language_model.generate(feats[:3], max_length=max_length, num_beams=16, early_stopping=early,
+                                                num_return_sequences=nret)
+        ora = o_lm.beam_generate(sd, feats[:3], max_length, 16, early_stopping=early, num_return_sequences=nret)
+        ok = ref.shape == ora.shape and torch.equal(ref, ora)
+        ok_wide &= ok
+        print(f"{name}: reference {tuple(ref.shape)} oracle {tuple(ora.shape)} match={ok}")
+        wide["cases"][name] = {"max_length": max_length, "early_stopping": early, "num_return_sequences": nret, "sequences": ref}
+    wide["meta"]["oracle_matches_reference"] = bool(ok_wide)
+    torch.save(wide, os.path.join(HERE, "lm_beam16.pt"))
+    print("saved lm_beam16.pt; oracle matches reference:", ok_wide)
+    ok_all &= ok_wide
     return 0 if ok_all else 1
 
 

@@ -74,6 +74,19 @@ def test_beam_search_oracle_matches_reference_loop(sd_ragged):
     assert torch.equal(seq, c["sequences"])
 
 
+def test_beam_search_oracle_matches_reference_loop_at_16_beams(sd_ragged):
+    """lm_beam16.pt (round 3: the HIP path ranks up to 16 beams): the reference's loop with num_beams=16, with early stopping
+    and with 4 returned hypotheses per region."""
+    fx = load_golden("lm_beam16.pt")
+    assert fx["meta"]["oracle_matches_reference"] is True and fx["meta"]["num_beams"] == 16
+    g = torch.Generator().manual_seed(99)
+    feats = torch.randn((5, 1024), generator=g)[:3]
+    for c in fx["cases"].values():
+        seq = o_lm.beam_generate(sd_ragged, feats, c["max_length"], 16, early_stopping=c["early_stopping"],
+                                 num_return_sequences=c["num_return_sequences"])
+        assert torch.equal(seq, c["sequences"])
+
+
 def test_beam_scorer_hand_case():
     """Known-answer test of the restated BeamHypotheses (third-party semantics, unpinned otherwise)."""
     from oracle.beam_scorer import BeamHypotheses
