@@ -181,3 +181,22 @@ def test_incremental_forward_oracle_matches_reference_cached_steps(sd_ragged):
         ntok += T
     for l, (k, v) in fx["presents"].items():
         assert torch.equal(past[l][0], k) and torch.equal(past[l][1], v)
+
+
+def test_bf16_oracle_is_within_quantisation_noise_of_the_reference_under_autocast(sd_bench):
+    """lm_autocast_bf16.pt: the REAL reference's LanguageModel.forward under torch.autocast(bfloat16) (CPU: the closest the
+    real code runs here to the fp16 autocast its scripts use).  The bf16 mode of the oracle - the parity target of the HIP
+    bf16 path - is a different set of rounding points, so the check is statistical: it is as close to the reference's
+    autocast run as that run is to the reference's own fp32 run (both ~1 % of the logit range, arg-max agreement >= 95 %)."""
+    fx = load_golden("lm_autocast_bf16.pt")
+    ids, mask, feats = fx["input_ids"], fx["attention_mask"], fx["feats"]
+    T = ids.shape[1]
+    o16, _ = o_lm.lm_forward(sd_bench, ids, mask, feats, None, torch.arange(T)[None, :], bf16=True)
+    rng = fx["meta"]["logit_range"]
+    d = (o16[:, -1] - fx["ref16_logits_last"]).abs().max().item() / rng
+    agree16 = (o16.argmax(-1) == fx["ref16_argmax"]).float().mean().item()
+    agree32 = (o16.argmax(-1) == fx["ref32_argmax"]).float().mean().item()
+    ref_self = (fx["ref16_argmax"] == fx["ref32_argmax"]).float().mean().item()
+    assert d <= 2e-2, d
+    assert agree16 >= 0.95 and agree32 >= 0.95 and ref_self >= 0.95, (agree16, agree32, ref_self)
+    assert abs(fx["meta"]["oracle16_vs_ref16"][0] - fx["meta"]["ref16_vs_ref32"][0]) <= 1e-2   # same noise level
