@@ -35,13 +35,8 @@ def probe(t):
     return t[::37, ::41].clone() if t.dim() == 2 else t[::7].clone()
 
 
-def main():
-    model = ref_harness.reference_model()
-    sd = synth.make_state_dict(0, "ragged")
-    model.load_state_dict(synth.to_reference_state_dict(sd), strict=True)
-    lm = model.language_model
-    lm.eval()
-    ids, mask, feats = make_batch(3, 6, 11, True)
+def one_case(lm, sd, batch_args, fname):
+    ids, mask, feats = make_batch(*batch_args)
     trainable = {k: p for k, p in lm.named_parameters() if p.requires_grad}
     assert sorted("language_model." + k for k in trainable) == sorted(o_lm.trainable_keys()), "trainable set differs"
     for p in trainable.values():
@@ -58,14 +53,28 @@ def main():
         worst = max(worst, rel)
         norms["language_model." + k] = g.norm().item()
     ok &= worst <= 1e-4
-    print(f"loss {loss.item():.6f} oracle {o_loss.item():.6f}; worst relative gradient difference oracle vs reference {worst:.2e}")
+    print(f"{fname}: loss {loss.item():.6f} oracle {o_loss.item():.6f}; worst relative gradient difference oracle vs reference {worst:.2e}")
     out = {"meta": {"torch": str(torch.__version__), "reference": "ttanida/rgrg @ /root/reference", "weights_seed": 0,
-                    "profile": "ragged", "batch": "make_golden_lm_loss.make_batch(3, 6, 11, True)", "dropout": "off (eval mode)",
+                    "profile": "ragged", "batch": f"make_golden_lm_loss.make_batch{batch_args}", "dropout": "off (eval mode)",
                     "oracle_matches_reference": bool(ok)},
            "input_ids": ids, "attention_mask": mask, "feats": feats, "loss": loss.detach().clone(),
            "grad_norms": norms, "probes": {k: probe(trainable[k[len("language_model."):]].grad) for k in PROBES}}
-    torch.save(out, os.path.join(HERE, "lm_grads.pt"))
-    print("saved lm_grads.pt; oracle matches reference:", ok)
+    torch.save(out, os.path.join(HERE, fname))
+    print(f"saved {fname}; oracle matches reference:", ok)
+    return ok
+
+
+def main():
+    model = ref_harness.reference_model()
+    sd = synth.make_state_dict(0, "ragged")
+    model.load_state_dict(synth.to_reference_state_dict(sd), strict=True)
+    lm = model.language_model
+    lm.eval()
+    ok = True
+    if "--long-only" not in sys.argv:
+        ok &= one_case(lm, sd, (3, 6, 11, True), "lm_grads.pt")
+    # round 3: a long sequence (more than 256 keys: the HIP pass streams its attention forward and backward there)
+    ok &= one_case(lm, sd, (8, 2, 300, True), "lm_grads_t300.pt")
     return 0 if ok else 1
 
 

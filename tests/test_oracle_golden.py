@@ -1,6 +1,7 @@
 """CPU oracle vs the golden fixtures produced by the REAL reference
 (tests/golden/make_golden.py).  Bit-exact: both are torch-CPU fp32 running the same
 operation sequence, so any drift of the restatement shows up here."""
+import pytest
 import torch
 
 from conftest import load_golden
@@ -200,3 +201,19 @@ def test_bf16_oracle_is_within_quantisation_noise_of_the_reference_under_autocas
     assert d <= 2e-2, d
     assert agree16 >= 0.95 and agree32 >= 0.95 and ref_self >= 0.95, (agree16, agree32, ref_self)
     assert abs(fx["meta"]["oracle16_vs_ref16"][0] - fx["meta"]["ref16_vs_ref32"][0]) <= 1e-2   # same noise level
+
+
+@pytest.mark.parametrize("name", ["lm_grads.pt", "lm_grads_t300.pt"])
+def test_lm_gradients_oracle_matches_reference_autograd(sd_ragged, name):
+    """The REAL reference's loss.backward() through the language model (tests/golden/make_golden_lm_grads.py; T = 11 and,
+    round 3, T = 300): the oracle's autograd gives the same loss, gradient norms and probe slices."""
+    fx = load_golden(name)
+    assert fx["meta"]["oracle_matches_reference"] is True
+    loss, grads = o_lm.lm_loss_and_grads(sd_ragged, fx["input_ids"], fx["attention_mask"], fx["feats"])
+    assert abs(loss.item() - fx["loss"].item()) <= 1e-5
+    for k, v in fx["grad_norms"].items():
+        assert abs(grads[k].norm().item() - v) <= 1e-4 * v + 1e-9, k
+    for k, ref in fx["probes"].items():
+        g = grads[k]
+        got = g[::37, ::41] if g.dim() == 2 else g[::7]
+        assert (got - ref).abs().max().item() <= 1e-5 * g.abs().max().item() + 1e-9, k
