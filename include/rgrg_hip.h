@@ -344,9 +344,14 @@ int rgrg_debug_chain(int n, int mode, int blocks, float* us_per_kernel);
 /* Measurement helper (tools/grid_barrier_bench.py): microseconds per grid-wide barrier among 256 resident workgroups of
  * 512 threads, with a payload hand-off of `payload_floats` per workgroup around it.  variant: 0 one atomic counter with
  * agent-scope fences, 1 without fences, 2 per-workgroup flags with fences, 3 flags with coherent payload accesses and no
- * fences, 4 two-level counters with fences, 5 the fences alone.  stale_out[0] = hand-offs that read old data,
- * stale_out[1] = 1 when a bounded spin gave up. */
+ * fences, 4 two-level counters with fences, 5 the fences alone; round 4 (write-through sc1 payload stores, every workgroup
+ * reads the slices of 64 producers): 6 XCD-hierarchical counters + one agent-scope acquire per workgroup, 7 the same with
+ * sc1 consumer loads instead of the acquire, 8 one flat relaxed counter + sc1 loads; `variant | 0x100` = uneven load (stale-read
+ * check).  payload_floats % 4 == 0.  stale_out[0] = hand-offs that read old data, stale_out[1] = 1 when a bounded spin gave up. */
 int rgrg_debug_grid_barrier(int variant, int iters, int payload_floats, float* us_per_barrier, unsigned* stale_out);
+/* Measurement helper: the XCD (0..7) every workgroup of `launches` back-to-back launches of `blocks` workgroups ran on,
+ * out_host[launch * blocks + b] (host memory) - the placement the decode plan's L2 prefetch workgroups count on. */
+int rgrg_debug_xcc_map(int blocks, int launches, int* out_host);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ c_float_p = C.c_void_p  # device pointers travel as void*
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p
 
 ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
-ABI_VERSION = 9  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
+ABI_VERSION = 10  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
 
 
 class RgrgHipError(RuntimeError):
@@ -83,6 +83,7 @@ SIGNATURES = {
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "rgrg_debug_chain": (_i, [_i, _i, _i, C.POINTER(_f)]),
     "rgrg_debug_grid_barrier": (_i, [_i, _i, _i, C.POINTER(_f), C.POINTER(C.c_uint)]),
+    "rgrg_debug_xcc_map": (_i, [_i, _i, C.POINTER(_i)]),
 }
 
 _lib: Optional[C.CDLL] = None

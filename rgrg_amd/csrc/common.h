@@ -66,6 +66,13 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     v += dpp_get<0x143, 0xc>(v);  // row_bcast31 -> rows 2, 3: row 3 holds the wave sum
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// XCD (accelerator complex die, 0..7) this wave runs on: every XCD has its own 4 MiB L2
+__device__ __forceinline__ int xcc_id() {
+    int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+    return x;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
