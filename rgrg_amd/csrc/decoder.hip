@@ -838,6 +838,8 @@ __global__ __launch_bounds__(256) void decode_reset_kernel(long long* __restrict
     }
 }
 
+#include "persistent.inc"
+
 // ------------------------------------------------------------------ beam search kernels
 constexpr int BEAM_K = 32;  // max 2*num_beams candidates per row (num_beams <= 16)
 
@@ -1392,6 +1394,13 @@ struct rgrg_decoder {
     int gemm_launches_per_step = 0;
     void* a16_scratch = nullptr;   // bf16 copy of an fp32 GEMM input (teacher-forced / training passes under autocast)
     size_t a16_bytes = 0;
+    // persistent decode kernel (persistent.inc), greedy decode of <= 32 rows.  pk_mode: 0 = the launch chain, 1 = c_fc' + mlp_proj
+    // of a layer in one launch, 2 = attn_proj' .. mlp_proj, 3 = attention .. mlp_proj, 4 = one launch per layer, 5 = one
+    // launch per decode step (all layers + lm_head' + arg-max).  RGRG_PERSISTENT overrides the default.
+    int pk_mode = 0;
+    std::vector<PkLayer> pk_layers;   // per-layer pointer table (copied into the kernel arguments)
+    unsigned* pk_bar = nullptr;     // barrier state (persistent.inc), zeroed at creation
+    unsigned long long* pk_dbg = nullptr;   // RGRG_PK_TRACE=<file>: cycle stamps of the last persistent launch, dumped at destruction
 };
 
 namespace rgrg {
@@ -1600,7 +1609,7 @@ static int direct_linear(rgrg_decoder* d, const Lin& l, DirectArgs a, int mode, 
 // The GEMMs of layer l of the fused plan (everything but the attention); `cur` holds x_mid of the previous layer in
 // fragment-major order with its mlp_proj partial sums pending in d->part, `nxt` receives this layer's residual stream.
 static int enqueue_layer_gemms(rgrg_decoder* d, int l, int S, bool count, const int* tok_override, const float* cur, float* nxt,
-                               int part) {  // part: 0 = c_attn', 1 = attn_proj' .. mlp_proj
+                               int part) {  // part: 0 = c_attn', 1 = attn_proj' .. mlp_proj, 2 = attn_proj' only
     const LayerW& w = d->layers[l];
     const int D = d->D;
     int rc;
@@ -1621,12 +1630,42 @@ static int enqueue_layer_gemms(rgrg_decoder* d, int l, int S, bool count, const 
     p.Xf = d->att; p.Rf = nxt; p.Yf = nxt; p.act = RGRG_ACT_NONE;  // its epilogue also zeroes mlp_proj's accumulators
     p.zero_acc = d->part;
     if ((rc = direct_linear(d, w.attn_proj, p, DX_PLAIN, S, count))) return rc;
+    if (part == 2) return RGRG_OK;   // attn_proj' alone (c_fc' + mlp_proj follow as one persistent launch)
     DirectArgs f{};  // c_fc': gelu_new(ln_2(x) W^T + b)
     f.Xf = nxt; f.Yf = d->ff; f.act = RGRG_ACT_GELU_NEW;
     if ((rc = direct_linear(d, w.c_fc, f, DX_PLAIN, S, count))) return rc;
     DirectArgs m{};  // mlp_proj: 4 K slices accumulate pairwise into d->part (slice 0 carries the bias)
     m.Xf = d->ff; m.act = RGRG_ACT_NONE;
     return direct_linear(d, w.mlp_proj, m, DX_PLAIN, S, count);
+}
+
+static PkArgs pk_args(rgrg_decoder* d, int S, int l0, int l1) {
+    PkArgs a{};
+    for (size_t l = 0; l < d->pk_layers.size(); ++l) a.layers[l] = d->pk_layers[l];
+    a.x = d->x; a.x2 = d->x2; a.qkv = d->qkv; a.att = d->att; a.ff = d->ff; a.part = d->part;
+    a.wte = d->wte; a.ids = d->ids; a.ld_ids = d->max_len; a.step = d->step;
+    a.lm_P = d->lm_head.packed; a.lm_c1 = d->lm_head.c1; a.lm_c2 = d->lm_head.c2;
+    a.logits = d->logits; a.ld_logits = d->ld_logits; a.cand_val = d->cand_val; a.cand_idx = d->cand_idx;
+    a.lm_NT = d->lm_head.NT; a.V = d->V;
+    a.finished = d->finished; a.done_len = d->done_len; a.sync = d->sync;
+    a.bar = d->pk_bar;
+    a.S = S; a.H = d->H; a.T = d->T; a.n_layer = d->n_layer; a.l0 = l0; a.l1 = l1;
+    a.dbg = d->pk_dbg;
+    return a;
+}
+
+template <int K0, bool FULL>
+static int pk_launch(rgrg_decoder* d, int S, int l0, int l1) {
+    const PkArgs a = pk_args(d, S, l0, l1);
+    const size_t lds = FULL ? LMH_LDS : (size_t)(SK_WAVES * 8 * 64 + SK_WAVES * 32 * 2 + 512) * sizeof(float);
+    hipLaunchKernelGGL((rgrg_persistent_decode_f32<K0, 5, FULL>), dim3(PK_WGS), dim3(512), lds, d->stream, a);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+static void pk_count(rgrg_decoder* d, int S, const Lin& l) {   // bookkeeping of the roofline figures (bytes / flops per step)
+    d->gemm_bytes_per_step += (size_t)l.N * l.K * sizeof(float);
+    d->gemm_flops_per_step += 2.0 * S * l.N * l.K;
 }
 
 // One decode step of the fused plan (<= 128 token rows): 24 * 5 + 2 = 122 launches
@@ -1640,10 +1679,52 @@ static int enqueue_step_fused(rgrg_decoder* d, int S, bool count, const int* tok
     int rc;
     float* cur = d->x;
     float* nxt = d->x2;
+    const int pk = (S <= PAD_ROWS && !beam && !tok_override && !src && !d->pk_layers.empty()) ? d->pk_mode : 0;
+    if (pk >= 4) {   // persistent.inc: one launch per layer, or one per step
+        if (count) {
+            for (int l = 0; l < d->n_layer; ++l) {
+                const LayerW& w = d->layers[l];
+                pk_count(d, S, w.c_attn); pk_count(d, S, w.attn_proj); pk_count(d, S, w.c_fc); pk_count(d, S, w.mlp_proj);
+            }
+            pk_count(d, S, d->lm_head);
+        }
+        if (pk == 5) {
+            if (count) d->gemm_launches_per_step = 1;
+            return pk_launch<0, true>(d, S, 0, d->n_layer);
+        }
+        for (int l = 0; l < d->n_layer; ++l)
+            if ((rc = pk_launch<0, false>(d, S, l, l + 1))) return rc;
+        if (count) d->gemm_launches_per_step = d->n_layer + 1;
+        cur = (d->n_layer & 1) ? d->x2 : d->x;
+        DirectArgs h{};
+        h.Xf = cur; h.part = d->part; h.Y = d->logits; h.ldy = d->ld_logits; h.act = RGRG_ACT_NONE;
+        if ((rc = direct_linear(d, d->lm_head, h, DX_COMBINE4, S, false, true))) return rc;
+        hipLaunchKernelGGL(argmax_update_kernel, dim3(S), dim3(256), 0, st, d->cand_val, d->cand_idx, d->lm_head.NT, d->ids,
+                           d->max_len, d->finished, d->step, d->done_len, d->sync, S);
+        RGRG_LAUNCH_CHECK();
+        return RGRG_OK;
+    }
     for (int l = 0; l < d->n_layer; ++l) {
         if ((rc = enqueue_layer_gemms(d, l, S, count, tok_override, cur, nxt, 0))) return rc;
-        if ((rc = launch_attention(d, l, S, src, nullptr, 1))) return rc;
-        if ((rc = enqueue_layer_gemms(d, l, S, count, tok_override, cur, nxt, 1))) return rc;
+        if (pk == 3) {          // attention .. mlp_proj in one launch
+            if ((rc = pk_launch<1, false>(d, S, l, l + 1))) return rc;
+        } else {
+            if ((rc = launch_attention(d, l, S, src, nullptr, 1))) return rc;
+            if (pk == 2) {      // attn_proj' .. mlp_proj
+                if ((rc = pk_launch<2, false>(d, S, l, l + 1))) return rc;
+            } else if (pk == 1) {   // c_fc' + mlp_proj
+                if ((rc = enqueue_layer_gemms(d, l, S, count, tok_override, cur, nxt, 2))) return rc;
+                if ((rc = pk_launch<3, false>(d, S, l, l + 1))) return rc;
+            } else {
+                if ((rc = enqueue_layer_gemms(d, l, S, count, tok_override, cur, nxt, 1))) return rc;
+            }
+        }
+        if (pk && count) {
+            const LayerW& w = d->layers[l];
+            if (pk >= 2) pk_count(d, S, w.attn_proj);
+            pk_count(d, S, w.c_fc); pk_count(d, S, w.mlp_proj);
+            d->gemm_launches_per_step += 1;
+        }
         float* tmp = cur; cur = nxt; nxt = tmp;
     }
     DirectArgs h{};
@@ -1814,6 +1895,33 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     TRY(dmalloc(d, (void**)&d->cand_score, R * BEAM_K * 4, true));
     TRY(dmalloc(d, (void**)&d->cand_tok, R * BEAM_K * 4, true));
     TRY(dmalloc(d, (void**)&d->cand_beam, R * BEAM_K * 4, true));
+    {   // persistent decode kernel (persistent.inc): per-layer pointer table + barrier state
+        std::vector<PkLayer> tab(w->n_layer <= PK_MAX_LAYERS ? w->n_layer : 0);
+        for (int l = 0; l < (int)tab.size(); ++l) {
+            const LayerW& t = d->layers[l];
+            PkLayer& p = tab[l];
+            p.attn_P = t.c_attn.packed; p.attn_c1 = t.c_attn.c1; p.attn_c2 = t.c_attn.c2;
+            p.proj_P = t.attn_proj.packed; p.proj_b = t.attn_proj.b;
+            p.fc_P = t.c_fc.packed; p.fc_c1 = t.c_fc.c1; p.fc_c2 = t.c_fc.c2;
+            p.mlp_P = t.mlp_proj.packed; p.mlp_b = t.mlp_proj.b;
+            p.kc = d->kv + (size_t)l * d->kv_layer_stride;
+            p.vc = p.kc + d->kv_kv_stride;
+        }
+        d->pk_layers = tab;
+        TRY(dmalloc(d, (void**)&d->pk_bar, (size_t)PK_BAR_SLOTS * 16 * sizeof(unsigned), true));
+        hipDeviceProp_t prop;
+        int dev = 0;
+        d->pk_mode = 0;
+        if (const char* e = getenv("RGRG_PERSISTENT")) d->pk_mode = atoi(e);
+        if (getenv("RGRG_PK_TRACE")) TRY(dmalloc(d, (void**)&d->pk_dbg, (size_t)PK_WGS * 64 * sizeof(unsigned long long), true));
+        // one workgroup per CU, all resident: needs the 256 CUs of an MI355X and a D = 1024 / 16-head model
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < PK_WGS ||
+            d->D != DK_SLICE || d->H != 16)
+            d->pk_mode = 0;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rgrg_persistent_decode_f32<0, 5, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LMH_LDS) != hipSuccess)
+            d->pk_mode = d->pk_mode == 5 ? 0 : d->pk_mode;
+    }
     d->gemm_ws_floats = (d->max_seqs > 32) ? (size_t)16 * R * 4 * D : 0;  // split-K partials of the tiled GEMM
     d->gemm_ws = nullptr;
     if (d->gemm_ws_floats) TRY(dmalloc(d, (void**)&d->gemm_ws, d->gemm_ws_floats * 4, false));
@@ -1835,6 +1943,15 @@ static void tr_free(rgrg_decoder* d);
 
 extern "C" void rgrg_decoder_destroy(rgrg_decoder* d) {
     if (!d) return;
+    if (d->pk_dbg) {   // measurement aid (tools/persistent_trace.py): the stamps of the last persistent launch
+        if (const char* path = getenv("RGRG_PK_TRACE")) {
+            std::vector<unsigned long long> h((size_t)PK_WGS * 64);
+            if (hipDeviceSynchronize() == hipSuccess &&
+                hipMemcpy(h.data(), d->pk_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+            }
+        }
+    }
     for (auto& g : d->graphs) (void)hipGraphExecDestroy(g.exec);
     for (void* p : d->allocs) (void)hipFree(p);
     tf_free(d);
@@ -1905,9 +2022,17 @@ extern "C" int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S,
         }
     }
     RGRG_HIP(hipMemcpyAsync(d->h_done, d->done_len, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    d->h_done[3] = 0;
+    if (d->pk_mode && d->pk_bar)   // persistent.inc: a bounded barrier spin gave up (a workgroup was not resident in time)
+        RGRG_HIP(hipMemcpyAsync(d->h_done + 3, d->pk_bar + 16 * PK_BAR_ERR, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     RGRG_HIP(hipMemcpy2DAsync(out_ids, (size_t)out_ld * sizeof(int64_t), d->ids, (size_t)d->max_len * sizeof(long long),
                               (size_t)limit * sizeof(int64_t), S, hipMemcpyDeviceToDevice, d->stream));
     RGRG_HIP(hipStreamSynchronize(d->stream));
+    if (d->h_done[3]) {
+        (void)hipMemset(d->pk_bar, 0, (size_t)PK_BAR_SLOTS * 16 * sizeof(unsigned));
+        set_error("decoder: the persistent decode kernel's grid barrier timed out (its 256 workgroups were not all resident); results discarded");
+        return RGRG_EHIP;
+    }
     done = *d->h_done;
     *out_len = (done > 0 && done < limit) ? done : limit;
     return RGRG_OK;

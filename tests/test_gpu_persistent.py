@@ -1,0 +1,72 @@
+"""The persistent decode kernel (csrc/persistent.inc; opt-in through RGRG_PERSISTENT - measured slower than the launch chain,
+DESIGN.md section 5, so never the default) against the same reference-generated fixtures and the launch chain itself:
+the phases repeat the launch plan's arithmetic per workgroup, so token ids are bit-exact and logits agree to fp32 rounding
+of differently contracted epilogues (<= 1e-5 on logits of O(1)).  Modes: 3 = attention .. mlp_proj of a layer in one
+launch (three grid barriers), 5 = a whole decode step in one launch (24 x 5 + 1 barriers, lm_head' and arg-max inside)."""
+import pytest
+import torch
+
+from conftest import gpu_model, load_golden
+from rgrg_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _with_mode(eng, mode, monkeypatch):
+    """The mode is read when the decoder is created: drop the current decoder so that the next call creates one."""
+    if mode is None:
+        monkeypatch.delenv("RGRG_PERSISTENT", raising=False)
+    else:
+        monkeypatch.setenv("RGRG_PERSISTENT", str(mode))
+    eng.close()
+    eng._decoder_caps = (0, 0)
+
+
+def _lm_feats():
+    g = torch.Generator().manual_seed(99)
+    return torch.randn((5, 1024), generator=g)
+
+
+@pytest.mark.parametrize("mode", [3, 5])
+def test_persistent_modes_reproduce_the_reference_fixtures(mode, monkeypatch):
+    m = gpu_model("ragged")
+    eng = m.engine()
+    try:
+        _with_mode(eng, mode, monkeypatch)
+        # decoder alone: 5 rows, 12 tokens; early exit when every row has emitted EOS (L' = 16 < 40)
+        ids = m.language_model.generate(_lm_feats().to(DEV), max_length=12)
+        assert torch.equal(ids.cpu(), load_golden("lm_only_len12.pt")["output_ids"])
+        fx = load_golden("lm_only_allfinish.pt")
+        ids = m.language_model.generate(_lm_feats().to(DEV), max_length=40)
+        assert ids.shape[1] == fx["output_ids"].shape[1] < 40 and torch.equal(ids.cpu(), fx["output_ids"])
+        # two images, 30 selected regions, rows finishing at different steps (PAD after EOS)
+        fx = load_golden("ragged_b2_len24.pt")
+        images = torch.cat([synth.make_images(1, s) for s in fx["meta"]["image_seeds"]], 0)
+        out = m.generate(images.to(DEV), max_length=24)
+        assert torch.equal(out[0].cpu(), fx["generate"]["output_ids"])
+    finally:
+        _with_mode(eng, None, monkeypatch)
+
+
+@pytest.mark.parametrize("mode", [3, 5])
+def test_persistent_modes_equal_the_launch_chain_at_the_bench_size(mode, monkeypatch):
+    """BASELINE configs[1] (29 regions x 128 tokens): ids equal the reference fixture AND the launch chain's; the last
+    step's logits within 1e-5; graph replay == eager launches; repeated calls reuse the barrier state (epochs advance)."""
+    m = gpu_model("bench")
+    eng = m.engine()
+    images = synth.make_images(1, 1234).to(DEV)
+    try:
+        _with_mode(eng, None, monkeypatch)
+        ref = m.generate(images, max_length=128)
+        ref_logits = eng.last_logits(29).clone()
+        _with_mode(eng, mode, monkeypatch)
+        for _ in range(3):
+            out = m.generate(images, max_length=128)
+            assert torch.equal(out[0], ref[0])
+        assert torch.equal(out[0].cpu(), load_golden("bench_b1_len128.pt")["generate"]["output_ids"])
+        assert (eng.last_logits(29) - ref_logits).abs().max().item() <= 1e-5
+        feats = _lm_feats().to(DEV)
+        assert torch.equal(eng.greedy_decode(feats, 24, use_graph=True), eng.greedy_decode(feats, 24, use_graph=False))
+    finally:
+        _with_mode(eng, None, monkeypatch)
