@@ -40,9 +40,10 @@ def pmc_traffic(family, S_dec, dtype):
     FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as the gfx950 note of MI355X_MICROARCH.md prescribes): counters cannot
     be collected from inside the timed process, so the last committed measurement of the same configuration is quoted -
     key <family>_S<sequences>_<dtype>, matched on the dtype and a sequence count within 1 % (the number of regions the
-    detector finds on the synthetic batch moves by one or two between builds); None when there is none."""
+    detector finds on the synthetic batch moves by one or two between builds).  -> (bytes per launch, "file:key") or
+    (None, None) when there is none: the quoted number always names the profile it comes from."""
     import re
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # newest committed measurement that has the key
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # newest committed measurement that has the key
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 table = json.load(f)
@@ -53,10 +54,11 @@ def pmc_traffic(family, S_dec, dtype):
             m = re.fullmatch(rf"{family}_S(\d+)_{dtype}", k)
             if m and isinstance(v, (int, float)) and abs(int(m.group(1)) - S_dec) <= max(0.01 * S_dec, 0):
                 if best is None or abs(int(m.group(1)) - S_dec) < best[0]:
-                    best = (abs(int(m.group(1)) - S_dec), float(v))
+                    best = (abs(int(m.group(1)) - S_dec), float(v), k)
         if best is not None:
-            return best[1]
-    return None
+            note = table.get(best[2] + "_note")
+            return best[1], f"profiles/{name}:{best[2]}" + (f" ({note})" if note else "")
+    return None, None
 
 
 def rooflines(eng, S_dec, dtype, max_length):
@@ -68,10 +70,12 @@ def rooflines(eng, S_dec, dtype, max_length):
     nkeys = (2 + (max_length + 1)) // 2
     p = eng.time_step_parts(S_dec, nkeys, iters=3)
     n = max(p["gemm_launches"], 1)
+    g_traffic, g_src = pmc_traffic("gemm", S_dec, dtype)
+    a_traffic, a_src = pmc_traffic("attn", S_dec, dtype)
     if S_dec <= 128:
         ach = p["gemm_weight_bytes"] / (p["ms_gemm"] * 1e-3) / 1e9
         gemm = {"bound": "hbm", "kernel": "rgrg_skinny_direct_f32 (+ _half, rgrg_lm_head_wave_f32)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("gemm", S_dec, dtype), "launches_per_decode_step": n,
+                "frac": ach / HBM_PEAK_GBS, "traffic": g_traffic, "traffic_source": g_src, "launches_per_decode_step": n,
                 "avg_launch_us": 1e3 * p["ms_gemm"] / n, "algorithmic_bytes_per_launch": p["gemm_weight_bytes"] / n,
                 "note": "achieved = fp32 weight bytes of the GEMM launches of one decode step (each weight read once) / their duration "
                         "between two HIP events on the decoder stream, launched back to back in step order"}
@@ -79,12 +83,12 @@ def rooflines(eng, S_dec, dtype, max_length):
         peak = MFMA_PEAK_TFS[dtype]
         ach = p["gemm_flops"] / (p["ms_gemm"] * 1e-3) / 1e12
         gemm = {"bound": "mfma", "kernel": "gemm_bf16_glds_kernel" if dtype == "bf16" else "gemm_f32_kernel", "achieved": ach, "peak": peak,
-                "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic("gemm", S_dec, dtype), "launches_per_decode_step": n,
+                "unit": "TFLOP/s", "frac": ach / peak, "traffic": g_traffic, "traffic_source": g_src, "launches_per_decode_step": n,
                 "avg_launch_us": 1e3 * p["ms_gemm"] / n, "algorithmic_flops_per_launch": p["gemm_flops"] / n,
                 "note": "achieved = 2 M N K of the GEMM launches of one decode step / their duration between two HIP events on the decoder stream"}
     ach = p["kv_bytes"] / (p["ms_attn"] * 1e-3) / 1e9
     attn = {"bound": "hbm", "kernel": "attn_decode_kv16_wave_kernel" if (dtype == "bf16" and S_dec > 128) else "attn_decode_kernel",
-            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("attn", S_dec, dtype),
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": a_traffic, "traffic_source": a_src,
             "launches_per_decode_step": 24, "avg_launch_us": 1e3 * p["ms_attn"] / 24, "algorithmic_bytes_per_launch": p["kv_bytes"] / 24,
             "keys_per_sequence": nkeys,
             "note": "achieved = K/V cache bytes of the 24 attention launches of one step at the mid-sequence key count / their duration "
@@ -93,13 +97,14 @@ def rooflines(eng, S_dec, dtype, max_length):
     return (gemm, attn) if p["ms_gemm"] >= p["ms_attn"] else (attn, gemm)
 
 
-def cpu_baseline(sd, images, max_length, sample_steps=4):
-    """The CPU oracle (port of the reference's algorithm; oracle/) timed on this host on a BOUNDED sample of the same
-    workload: ONE image through detector + selection (full), then `sample_steps` greedy decode steps; the decode time
-    is scaled to the max_length-1 steps of the workload (the per-step cost of the reference's concat-KV decoder grows
-    slowly with length, so this slightly flatters the CPU).  As BASELINE.md section 3 prescribes: 1 warm-up + 3 timed
-    runs, median, on all PHYSICAL cores (count stated), and 3 more runs with 8 threads (comparable with the survey's
-    probe; small fp32 GEMVs do not scale with cores, so this is usually the faster one)."""
+def cpu_baseline(sd, images, max_length, sample_steps=4, full_runs=3):
+    """The CPU oracle (port of the reference's algorithm; oracle/) timed on this host on ONE image of the workload
+    (1 warm-up + 3 timed runs, median).  Two stages, so that the default run stays within minutes:
+      1. thread-count probe - one short run per candidate thread count (all physical cores, 32, 8): detector + selection in
+         full + `sample_steps` greedy decode steps, the decode time extrapolated to the max_length-1 steps; these figures are
+         listed as EXTRAPOLATED and only pick the thread count (small fp32 GEMVs do not scale with cores);
+      2. at the best thread count: 1 warm-up + `full_runs` FULL runs - detector, selection and all max_length-1 decode steps of
+         the 29 regions, nothing scaled - whose median is `value`."""
     from oracle import detector as o_det
     from oracle import full_model as o_full
     from oracle import language_model as o_lm
@@ -109,7 +114,8 @@ def cpu_baseline(sd, images, max_length, sample_steps=4):
     except Exception:  # noqa: BLE001
         phys = os.cpu_count() or 1
 
-    def one_run():
+    def one_run(steps):
+        """steps = None: the full max_length-1 steps; else that many, scaled."""
         t0 = time.perf_counter()
         _, _, top, cd = o_det.object_detector_forward(sd, images[:1])
         sel, feats, _ = o_full.region_selection(sd, top, cd)
@@ -117,32 +123,109 @@ def cpu_baseline(sd, images, max_length, sample_steps=4):
         S, t_dec = int(feats.shape[0]), 0.0
         if S:
             t0 = time.perf_counter()
-            o_lm.greedy_generate(sd, feats, sample_steps + 1)
-            t_dec = (time.perf_counter() - t0) * (max_length - 1) / sample_steps
+            if steps is None:
+                o_lm.greedy_generate(sd, feats, max_length)
+                t_dec = time.perf_counter() - t0
+            else:
+                o_lm.greedy_generate(sd, feats, steps + 1)
+                t_dec = (time.perf_counter() - t0) * (max_length - 1) / steps
         return t_det + t_dec, t_det, t_dec, S
 
-    def median_of(threads, warmup):
-        torch.set_num_threads(threads)
-        for _ in range(warmup):
-            one_run()
-        runs = sorted(one_run() for _ in range(3))
-        return runs[1]
+    probe = {}
+    best_n, best_t = None, None
+    for n in sorted({phys, min(32, phys), min(8, phys)}):
+        torch.set_num_threads(n)
+        tot = one_run(sample_steps)[0]
+        probe[str(n)] = 1.0 / tot
+        if best_t is None or tot < best_t:
+            best_n, best_t = n, tot
+    torch.set_num_threads(best_n)
+    one_run(None)  # warm-up, full
+    runs = sorted(one_run(None) for _ in range(full_runs))
+    tot, t_det, t_dec, S = runs[len(runs) // 2]
+    return {"value": 1.0 / tot, "unit": "images/sec", "cores": best_n, "kind": "port", "physical_cores": phys,
+            "runs": f"1 warm-up + {full_runs} full timed runs at {best_n} threads, median (all {max_length - 1} decode steps run, nothing extrapolated)",
+            "seconds_per_image": tot, "seconds_detector_and_selection": t_det, "seconds_decode": t_dec,
+            "images_per_sec_by_threads_extrapolated": probe,
+            "probe": f"one run per thread count with {sample_steps} of {max_length - 1} decode steps scaled: picks the thread count only",
+            "sample": f"1 image in full: detector + selection ({t_det:.1f} s) + {max_length - 1} greedy decode steps for {S} regions "
+                      f"({t_dec:.1f} s); torch-CPU fp32 oracle on {best_n} threads of {phys} physical cores"}
 
-    # thread counts: all physical cores, 32 and 8 (the survey's probe).  The small fp32 GEMVs of
-    # the decode loop do not scale with cores, so `value` is the BEST configuration and every figure is listed.
-    by_threads = {}
-    best = None
-    for i, n in enumerate(sorted({phys, min(32, phys), min(8, phys)}, reverse=True)):
-        tot, t_det, t_dec, S = median_of(n, 1 if i == 0 else 0)
-        by_threads[str(n)] = 1.0 / tot
-        if best is None or tot < best[0]:
-            best = (tot, t_det, t_dec, S, n)
-    tot, t_det, t_dec, S, n = best
-    return {"value": 1.0 / tot, "unit": "images/sec", "cores": n, "kind": "port", "physical_cores": phys,
-            "images_per_sec_by_threads": by_threads, "runs": "1 warm-up + 3 timed per thread count, median",
-            "sample": f"1 image: detector+selection in full ({t_det:.1f} s) + {sample_steps} of {max_length - 1} greedy decode steps "
-                      f"for {S} regions scaled to {max_length - 1} ({t_dec:.1f} s); torch-CPU fp32 oracle; value = the best of "
-                      f"the listed thread counts ({n} threads on {phys} physical cores)"}
+
+def detector_rooflines(eng, images, bf16):
+    """rooflines of the detector's MFMA work and of RoIAlign, timed live with HIP events on the stream the
+    kernels are launched on (the detector runs on torch's current stream, so torch.cuda.Event brackets exactly those
+    launches).  MFMA: ResNet-50 trunk + RPN 3x3 + fc6 (99 % of the detector's 332.9 GFLOP / image at 1000 proposals);
+    RoIAlign + avg-pool: algorithmic bytes = feature map read once + [R, 64, 2048] maps and [R, 2048] pooled rows written."""
+    from rgrg_amd import _hip
+    B = images.shape[0]
+
+    def timed(fn, iters=3):
+        out = None
+        for _ in range(2):
+            out = None
+            out = fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            out = None
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters, out
+
+    st = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
+    if bf16:
+        peak, dt = MFMA_PEAK_TFS["bf16"], "bf16"
+        ms_trunk, (feat16, feat) = timed(lambda: eng.backbone16(images))
+        ms_rpn, _ = timed(lambda: eng.conv16(feat16, eng.rpn_conv, _hip.ACT_RELU))
+        props, counts, offsets = eng.rpn(feat, feat16=feat16)
+    else:
+        peak, dt = MFMA_PEAK_TFS["f32"], "f32"
+        ms_trunk, feat = timed(lambda: eng.backbone(images))
+        ms_rpn, _ = timed(lambda: eng.conv(feat, eng.rpn_conv, _hip.ACT_RELU))
+        props, counts, offsets = eng.rpn(feat)
+    R = int(offsets[-1].item())
+    Cf = feat.shape[-1]
+    low = bf16 and R > 128
+    maps = torch.empty((R, 64, Cf), dtype=torch.int16 if low else torch.float32, device=feat.device)
+    pooled = torch.empty((R, Cf), dtype=torch.float32, device=feat.device)
+
+    def roi():
+        fn = eng.lib.rgrg_roi_align_avgpool_bf16maps if low else eng.lib.rgrg_roi_align_avgpool_f32
+        _hip.check(fn(feat.data_ptr(), props.data_ptr(), offsets.data_ptr(), maps.data_ptr(), pooled.data_ptr(), B, feat.shape[1], feat.shape[2],
+                      Cf, props.shape[1], R, 1.0 / 32, st()), "roi_align")
+
+    ms_roi, _ = timed(roi)
+    if low:
+        h6 = torch.empty((R, 1024), device=feat.device)
+        wb = eng._fc6_bf16()
+
+        def fc6():
+            _hip.check(eng.lib.rgrg_linear_bf16_f32(maps.data_ptr(), wb.data_ptr(), eng.fc6_b.data_ptr(), None, h6.data_ptr(), None, R, 1024,
+                                                    64 * Cf, 1024, _hip.ACT_RELU, st()), "fc6")
+        ms_fc6, _ = timed(fc6)
+    else:
+        if maps.dtype != torch.float32:
+            maps = maps.float()
+        x6 = maps.view(R, 64 * Cf)
+        ms_fc6, _ = timed(lambda: eng.linear(x6, eng.fc6_w, eng.fc6_b, _hip.ACT_RELU))
+    fl = {"trunk": 2 * 20.942e9 * B, "rpn_conv3x3": 2.0 * 256 * 2048 * 18432 * B, "fc6": 2.0 * R * 131072 * 1024}
+    ms = {"trunk": ms_trunk, "rpn_conv3x3": ms_rpn, "fc6": ms_fc6}
+    ach = sum(fl.values()) / (sum(ms.values()) * 1e-3) / 1e12
+    det = {"bound": "mfma", "kernel": ("gemm_bf16_glds_kernel (implicit-GEMM convolutions + fc6)" if bf16 else "gemm_f32_kernel (implicit-GEMM convolutions + fc6)"),
+           "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "dtype": dt, "images": B, "proposals": R,
+           "parts": {k: {"ms": ms[k], "tflops": fl[k] / (ms[k] * 1e-3) / 1e12, "frac": fl[k] / (ms[k] * 1e-3) / 1e12 / peak} for k in fl},
+           "note": "achieved = 2 M N K of trunk + RPN 3x3 + fc6 / the sum of their durations between HIP events on the launch stream "
+                   "(mean of 3 after 2 warm-ups, each stage timed back to back on resident inputs)"}
+    bytes_roi = B * Cf * feat.shape[1] * feat.shape[2] * 4 + R * (Cf * 64 * (2 if low else 4) + Cf * 4)
+    ach = bytes_roi / (ms_roi * 1e-3) / 1e9
+    ra = {"bound": "hbm", "kernel": "roi_align_avg_kernel" + ("<bf16 maps>" if low else "<fp32 maps>"), "achieved": ach, "peak": HBM_PEAK_GBS,
+          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "ms": ms_roi, "proposals": R, "algorithmic_bytes_per_launch": bytes_roi,
+          "note": "algorithmic bytes = feature map read once + [R, 64, 2048] maps + [R, 2048] pooled rows written, / the launch's duration "
+                  "between HIP events on its stream"}
+    return det, ra
 
 
 def _free_port() -> int:
@@ -187,31 +270,109 @@ class _StubModel:
         return cd.clone(), top.reshape(-1, 1024)
 
 
-def config2_line(model, synth, max_length):
-    """BASELINE configs[2] in the same process: batch 32 under bf16 autocast (bf16-weight MFMA decode GEMMs, bf16 K/V
-    cache, hipGraph-captured step), 1 warm-up + 2 timed generate() calls, with its own rooflines."""
-    images = synth.make_images(32, 1234).to(next(iter(model.parameters())).device)
+def _bracketed(fn, calls, use_dist, dev):
+    """`calls` calls of fn between two barriers (+ device synchronisation) on every rank; -> (seconds, MAX over ranks; last result)."""
+    def barrier():
+        if use_dist:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    out = None
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        out = fn()
+    barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, out
+
+
+def config2_line(model, synth, max_length, world=1, use_dist=False, dev=None, with_detector_rooflines=True):
+    """BASELINE configs[2] (world == 1) / configs[3] (world > 1: the same 32 images PER GPU, batch-sharded, ONE RCCL gather of
+    the token ids) in the same process: bf16 autocast (bf16-weight MFMA decode GEMMs, bf16 K/V cache, hipGraph-captured
+    step), 1 warm-up + 2 timed generate() calls between barriers, MAX over ranks, with its own rooflines."""
+    from rgrg_amd.dist import generate_sharded
+    dev = dev or next(iter(model.parameters())).device
+    images = synth.make_images(32, 1234).to(dev)
 
     def step():
         with torch.autocast("cuda", dtype=torch.bfloat16):
+            if use_dist:
+                return generate_sharded(model, images, max_length)
             return model.generate(images, max_length=max_length, num_beams=1)
 
-    out = step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(2):
-        out = step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    step()
+    dt, out = _bracketed(step, 2, use_dist, dev)
     S = 0 if isinstance(out, int) else int(out[0].shape[0])
-    res = {"workload": f"full_model.generate() batch=32, 29 regions, greedy max_len={max_length}, bf16 autocast (BASELINE configs[2])",
-           "value": 64 / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt / 2, "steps": 2, "warmup": 1, "dtype": "bf16",
+    which = ("batch=32, 29 regions, greedy max_len=%d, bf16 autocast (BASELINE configs[2])" % max_length) if world == 1 else \
+            ("batch=%d synthetic CXR sharded 32 / GPU over %d GPUs, bf16 autocast, one RCCL all_gather of the token ids "
+             "(BASELINE configs[3]%s)" % (32 * world, world, "" if world == 8 else ": the 8-GPU shape at this N"))
+    res = {"workload": "full_model.generate() " + which, "value": 2 * 32 * world / dt, "unit": "images/sec", "n_gpus": world,
+           "ms_per_step": 1e3 * dt / 2, "steps": 2, "warmup": 1, "dtype": "bf16", "scaling": "weak", "global_batch": 32 * world,
            "regions_generated": S, "tokens_per_region": 0 if isinstance(out, int) else int(out[0].shape[1])}
     try:
-        res["roofline"], res["roofline_secondary"] = rooflines(model.engine(), max(S, 1), "bf16", max_length)
+        res["roofline"], res["roofline_secondary"] = rooflines(model.engine(), max(S // max(world, 1), 1), "bf16", max_length)
+        if with_detector_rooflines:
+            res["roofline_detector"], res["roofline_roialign"] = detector_rooflines(model.engine(), images, True)
     except Exception as e:  # noqa: BLE001
         res["roofline"] = {"error": str(e)}
     return res
+
+
+def config4_line(model, synth, world=1, use_dist=False, dev=None, steps=3, T=64):
+    """BASELINE configs[4]: one end-to-end training step per call - 8 images per GPU, object detector frozen (its inference
+    branch runs), both region classifiers + the language model's trainable tensors (53.66 M values) - forward under bf16
+    autocast, HIP backward, gradients ALL-REDUCED over the ranks in place on flat buckets (rgrg_amd.dist.GradBuckets: RCCL
+    over xGMI at world > 1), HIP AdamW.  1 warm-up + `steps` timed steps between barriers, MAX over ranks.  Run LAST: it
+    updates the weights."""
+    from rgrg_amd import optim
+    from rgrg_amd.dist import GradBuckets
+    dev = dev or next(iter(model.parameters())).device
+    B = 8
+    S = 29 * B
+    g = torch.Generator().manual_seed(1000 + (torch.distributed.get_rank() if use_dist else 0))   # every rank its own shard
+    ids = torch.randint(0, 50257, (S, T), generator=g).to(dev)
+    lens = torch.randint(T // 2, T + 1, (S,), generator=g)
+    am = (torch.arange(T)[None, :] < lens[:, None]).to(torch.int64).to(dev)
+    images = synth.make_images(B, 4321).to(dev)
+    has = torch.ones((B, 29), dtype=torch.bool, device=dev)
+    abn = (torch.rand((B, 29), generator=g) < 0.2).to(dev)
+    was_pre, was_training = model.pretrain_without_lm_model, model.training
+    model.pretrain_without_lm_model = False
+    model.train()
+    try:
+        params = model.trainable_parameters()
+        opt = optim.AdamW(params, lr=5e-5)
+        buckets = GradBuckets(params)
+        n_buckets = len(buckets.buckets)
+
+        def step():
+            buckets.zero()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = model(images, None, ids.clone(), am, has, abn)
+            (5.0 * out[1] + 5.0 * out[2] + 2.0 * out[3]).backward()     # run_configurations.py:58-61 weights (detector frozen)
+            buckets.allreduce()
+            opt.step()
+            return out
+
+        step()
+        dt, out = _bracketed(step, steps, use_dist, dev)
+        n_values = sum(p.numel() for p in params)
+        return {"workload": f"end-to-end training step, detector frozen, LM + binary-classifier heads, per-GPU batch=8 (232 sentences x {T} tokens), "
+                            f"bf16 autocast, gradient all-reduce over {world} rank(s) on {n_buckets} flat buckets, HIP AdamW (BASELINE configs[4]"
+                            + ("" if world == 8 else ": the 8-GPU shape at this N") + ")",
+                "metric": "images/sec end-to-end training step", "value": B * world * steps / dt, "unit": "images/sec", "n_gpus": world,
+                "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": 1, "dtype": "bf16", "scaling": "weak", "global_batch": B * world,
+                "trainable_values": n_values, "allreduce_bytes_per_step": 4 * n_values if world > 1 else 0,
+                "losses_last_step": [float(o) for o in out[1:4]]}
+    finally:
+        for p in model.trainable_parameters():
+            p.grad = None
+        model.pretrain_without_lm_model = was_pre
+        model.train(was_training)
 
 
 def main():
@@ -222,7 +383,10 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (BASELINE configs[1]: 1)")
     ap.add_argument("--max-length", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-config2", action="store_true", help="skip the batch-32 bf16 leg (BASELINE configs[2]) of the default run")
+    ap.add_argument("--no-config2", action="store_true",
+                    help="skip the secondary legs of the default run: batch 32 / GPU under bf16 (BASELINE configs[2]; configs[3] at N > 1) "
+                         "and the training step (configs[4])")
+    ap.add_argument("--train", action="store_true", help="the headline line IS the training step (BASELINE configs[4]) instead of generate()")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="bf16: run generate() under torch.autocast(bfloat16) - bf16 MFMA decode GEMMs for > 128 sequences "
                          "(BASELINE configs[2]); not bit-exact, never the default")
@@ -283,6 +447,22 @@ def main():
 
     import contextlib
 
+    if args.train and not stub:
+        # BASELINE configs[4] as the line itself: `--steps` training steps of 8 images per GPU
+        res4 = config4_line(model, synth, world, use_dist, dev, steps=args.steps)
+        if rank == 0:
+            res = {"metric": res4["metric"] + " (BASELINE configs[4]; the headline metric is generate(): run without --train)",
+                   "value": res4["value"], "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": 1,
+                   "ms_per_step": res4["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                   "data": "synthetic", "config": {"workload": res4["workload"], "global_batch": res4["global_batch"],
+                                                   "parallelism": f"dp{world} (replicas, bucketed gradient all-reduce)" if use_dist else "single GPU",
+                                                   "weights": "seeded random init (rgrg_amd.synth, profile bench)"},
+                   "training": res4}
+            print(json.dumps(res), flush=True)
+        if use_dist:
+            torch.distributed.destroy_process_group()
+        return
+
     def step():
         ctx = torch.autocast("cuda", dtype=torch.bfloat16) if args.dtype == "bf16" and not stub else contextlib.nullcontext()
         with ctx:
@@ -310,41 +490,58 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
-    if rank == 0:
-        n_images = args.batch * world * args.steps
-        S = 0 if isinstance(out, int) else int(out[0].shape[0])
-        Lp = 0 if isinstance(out, int) else int(out[0].shape[1])
-        res = {
-            "metric": "images/sec full 29-region report gen, 512x512 CXR, greedy max_len=128",
-            "value": n_images / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"full_model.generate() batch={args.batch}/GPU, 29 regions, greedy max_len={args.max_length}, {'fp32' if args.dtype == 'f32' else 'bf16 decode GEMMs (fp32 detector/LN/attention)'}"
-                                   + (" (BASELINE configs[1])" if args.batch == 1 and args.max_length == 128 and args.dtype == "f32" else ""),
-                       "global_batch": args.batch * world, "regions_generated": S, "tokens_per_region": Lp,
-                       "parallelism": f"dp{world} (image shards, one RCCL all_gather of token ids)" if use_dist else "single GPU",
-                       "weights": "seeded random init (rgrg_amd.synth, profile bench)", "hipGraph_decode": True},
-        }
-        if stub:
+    n_images = args.batch * world * args.steps
+    S = 0 if isinstance(out, int) else int(out[0].shape[0])
+    Lp = 0 if isinstance(out, int) else int(out[0].shape[1])
+    res = {
+        "metric": "images/sec full 29-region report gen, 512x512 CXR, greedy max_len=128",
+        "value": n_images / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"full_model.generate() batch={args.batch}/GPU, 29 regions, greedy max_len={args.max_length}, {'fp32' if args.dtype == 'f32' else 'bf16 decode GEMMs (fp32 detector/LN/attention)'}"
+                               + (" (BASELINE configs[1])" if args.batch == 1 and args.max_length == 128 and args.dtype == "f32" else ""),
+                   "global_batch": args.batch * world, "regions_generated": S, "tokens_per_region": Lp,
+                   "parallelism": f"dp{world} (image shards, one RCCL all_gather of token ids)" if use_dist else "single GPU",
+                   "weights": "seeded random init (rgrg_amd.synth, profile bench)", "hipGraph_decode": True},
+    }
+    if stub:
+        if rank == 0:
             res["data"] = "stub (no GPU work: launcher / gather path only)"
             res["config"]["weights"] = "none (stub)"
             print(json.dumps(res), flush=True)
-        else:
-            # rooflines of the two kernel families of the decode loop, dominant one first (timed live, HIP events)
-            try:
-                S_dec = max(S // max(world, 1), 1)
-                res["roofline"], res["roofline_secondary"] = rooflines(model.engine(), S_dec, args.dtype, args.max_length)
-            except Exception as e:  # noqa: BLE001
-                res["roofline"] = {"bound": "hbm", "error": str(e)}
-            headline = world == 1 and args.batch == 1 and args.dtype == "f32"
-            if headline and not args.no_config2:
-                try:
-                    res["config2"] = config2_line(model, synth, args.max_length)
-                except Exception as e:  # noqa: BLE001
-                    res["config2"] = {"error": str(e)}
-            if world == 1 and not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(sd, images_cpu, args.max_length)
-            print(json.dumps(res), flush=True)
+        if use_dist:
+            torch.distributed.destroy_process_group()
+        return
+
+    default_workload = args.batch == 1 and args.dtype == "f32"
+    if world > 1 and default_workload:
+        res["config"]["note"] = ("the per-GPU work of this line is BASELINE configs[1] at every N, so that the driver's per-N values form ONE weak-"
+                                 "scaling curve; BASELINE configs[3] (32 images / GPU, bf16, one gather) and configs[4] (training step, gradient "
+                                 "all-reduce) ride in the same line as `config3` / `config4`, their N = 1 points are `config2` / `config4` of the "
+                                 "--gpus 1 line")
+    # rooflines of the two kernel families of the decode loop, dominant one first (timed live, HIP events), per rank 0
+    if rank == 0:
+        try:
+            S_dec = max(S // max(world, 1), 1)
+            res["roofline"], res["roofline_secondary"] = rooflines(model.engine(), S_dec, args.dtype, args.max_length)
+            res["roofline_detector"], res["roofline_roialign"] = detector_rooflines(model.engine(), images, args.dtype == "bf16")
+        except Exception as e:  # noqa: BLE001
+            res.setdefault("roofline", {"bound": "hbm", "error": str(e)})
+    if default_workload and not args.no_config2:   # every rank takes part: the legs below contain collectives at N > 1
+        key2 = "config2" if world == 1 else "config3"
+        try:
+            res[key2] = config2_line(model, synth, args.max_length, world, use_dist, dev, with_detector_rooflines=(rank == 0))
+        except Exception as e:  # noqa: BLE001
+            res[key2] = {"error": str(e)}
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(sd, images_cpu, args.max_length)
+    if default_workload and not args.no_config2:   # last: it updates the weights
+        try:
+            res["config4"] = config4_line(model, synth, world, use_dist, dev)
+        except Exception as e:  # noqa: BLE001
+            res["config4"] = {"error": str(e)}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     if use_dist:
         torch.distributed.destroy_process_group()
 

@@ -8,8 +8,11 @@ Same module-level constants and function names (``get_model``, ``get_image_tenso
     installed and cannot be downloaded, so they are imported lazily and are pluggable: pass
     your own ``tokenizer`` / ``sentence_tokenizer`` / ``bert_score`` objects (same duck types
     as the reference uses); without them the script still produces the token ids.
-  * generation runs in fp32 (the reference wraps it in fp16 autocast).  Beam search
-    (NUM_BEAMS = 4, max_length 300, early_stopping) runs on the HIP decoder like greedy does.
+  * like the reference (generate_reports_for_images.py:108), generation runs under
+    ``torch.autocast(device_type="cuda", dtype=AUTOCAST_DTYPE)`` with ``AUTOCAST_DTYPE = torch.float16``: the detector's
+    convolutions / fc6 and the many-row decode GEMMs then run on the 16-bit matrix core with fp32 accumulation (one image
+    with 4 beams = 116 decode rows stays on the exact-fp32 weight-streaming plan).  Set ``AUTOCAST_DTYPE = None`` for an
+    fp32 run.  Beam search (NUM_BEAMS = 4, max_length 300, early_stopping) runs on the HIP decoder like greedy does.
 """
 from __future__ import annotations
 
@@ -24,6 +27,7 @@ device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 MAX_NUM_TOKENS_GENERATE = 300
 NUM_BEAMS = 4
+AUTOCAST_DTYPE = torch.float16   # the reference's wrapper (:108); None = fp32
 
 
 def write_generated_reports_to_txt(images_paths, generated_reports, generated_reports_txt_path):
@@ -70,8 +74,11 @@ def convert_generated_sentences_to_report(generated_sents_for_selected_regions, 
 
 
 def get_report_for_image(model, image_tensor, tokenizer, bert_score, sentence_tokenizer):
-    output = model.generate(image_tensor.to(device, non_blocking=True), max_length=MAX_NUM_TOKENS_GENERATE,
-                            num_beams=NUM_BEAMS, early_stopping=True)
+    import contextlib
+    ctx = torch.autocast(device_type="cuda", dtype=AUTOCAST_DTYPE) if AUTOCAST_DTYPE is not None else contextlib.nullcontext()
+    with ctx:
+        output = model.generate(image_tensor.to(device, non_blocking=True), max_length=MAX_NUM_TOKENS_GENERATE,
+                                num_beams=NUM_BEAMS, early_stopping=True)
     if isinstance(output, int):  # -1: no region both detected and selected
         return ""
     output_ids, _, _, _ = output
