@@ -173,6 +173,25 @@ def _bn_affine(sd: Dict[str, Tensor], p: str) -> Tuple[Tensor, Tensor]:
     return alpha.contiguous(), beta.contiguous()
 
 
+class _DecoderOwner:
+    """Owns one ``rgrg_decoder``: destroyed when the last reference goes - the engine's, or that of the ``presents`` views
+    ``forward(use_cache=True)`` handed out (they alias the decoder's K/V cache: freeing it under a live view would be a
+    use-after-free on the GPU).  A decoder the engine has replaced therefore lives (memory included) as long as a caller keeps
+    its presents."""
+
+    def __init__(self, lib, handle, device):
+        self.lib, self.handle, self.device = lib, handle, device
+
+    def __del__(self):
+        try:
+            if self.handle is not None:
+                with torch.cuda.device(self.device):
+                    self.lib.rgrg_decoder_destroy(self.handle)
+                self.handle = None
+        except Exception:  # noqa: BLE001
+            pass
+
+
 @_on_engine_device
 class HipEngine:
     def __init__(self, state_dict: Dict[str, Tensor], device: torch.device):
@@ -182,6 +201,8 @@ class HipEngine:
         self.device = device
         self.lib = _hip.load()
         self._decoder = None
+        self._decoder_owner = None
+        self._cached = None
         self._init(state_dict)
 
     def _init(self, state_dict: Dict[str, Tensor]) -> None:
@@ -306,8 +327,10 @@ class HipEngine:
             pending = C.c_int(0)
             if self.lib.rgrg_decoder_take_id_error(self._decoder, C.byref(pending)) == 0 and pending.value:
                 self._pending_id_error = True
-            self.lib.rgrg_decoder_destroy(self._decoder)
+            # the decoder is destroyed when its last owner goes: now, unless presents of forward(use_cache=True) still alias its cache
             self._decoder = None
+            self._decoder_owner = None
+            self._cached = None
 
     def __del__(self):
         try:
@@ -717,6 +740,7 @@ class HipEngine:
             _hip.check(self.lib.rgrg_decoder_create(C.byref(self._dec_weights), cap_s, cap_l, C.byref(h)),
                        "rgrg_decoder_create")
             self._decoder, self._decoder_caps = h, (cap_s, cap_l)
+            self._decoder_owner = _DecoderOwner(self.lib, h, self.device)
         return self._decoder
 
     def greedy_decode(self, feats: Tensor, max_length: Optional[int], use_graph: bool = True, bf16: bool = False) -> Tensor:
@@ -726,6 +750,7 @@ class HipEngine:
         S = feats.shape[0]
         limit = int(max_length) if max_length else 1024  # reference has no bound when None; positions stop at 1024
         dec = self._get_decoder(S, limit)
+        self._cached = None   # the K/V cache and the step counter are rewritten: presents of an earlier forward(use_cache=True) are stale
         _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")
         feats = feats.to(torch.float32).contiguous()
         out = torch.empty((S, limit), dtype=torch.int64, device=feats.device)
@@ -742,6 +767,7 @@ class HipEngine:
         S = feats.shape[0]
         limit = int(max_length)
         dec = self._get_decoder(S * num_beams, limit)
+        self._cached = None   # as in greedy_decode
         _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")
         feats = feats.to(torch.float32).contiguous()
         out = torch.empty((S * int(num_return_sequences), limit), dtype=torch.int64, device=feats.device)
@@ -854,16 +880,36 @@ class HipEngine:
         if self._decoder is not None:
             _hip.check(self.lib.rgrg_decoder_refresh_trainable(self._decoder, self._s()), "rgrg_decoder_refresh_trainable")
 
+    def cache_tokens_that_fit(self, S: int, want: int, budget_fraction: float = 0.5) -> int:
+        """How many token slots a K/V cache for S rows may have so that the allocation (24 x 2 x rows x 16 x (L + 1) x 64 x 4 B)
+        stays within ``budget_fraction`` of the free device memory: the reference's 1024 positions for a few dozen rows (6.4 GB at
+        32 rows), fewer for hundreds of rows (928 rows x 1024 slots would be 187 GB, and the decoder never shrinks)."""
+        rows = max(32, ((S + 31) // 32) * 32)
+        per_slot = self.n_layer * 2 * rows * 16 * 64 * 4
+        free, _total = torch.cuda.mem_get_info(self.device)
+        fit = int(free * budget_fraction) // per_slot - 1
+        return max(2, min(int(want), fit))
+
     def forward_cached(self, feats: Optional[Tensor], input_ids: Tensor, past_len: int, cache_len: int = 1024):
         """LanguageModel.forward(use_cache=True[, past_key_values]) over the decoder's K/V cache (rgrg_decoder_forward_cached):
         feeds input_ids [S,T] at positions past_len .. past_len + T - 1 -> (logits f32 [S,T,V], presents) where presents is
-        the reference's tuple of 24 (key, value) pairs, each a VIEW [S,16,1 + past_len + T,64] of the cache."""
+        the reference's tuple of 24 (key, value) pairs, each a VIEW [S,16,1 + past_len + T,64] of the cache.  ``cache_len`` =
+        token slots to provide for when the cache is created (the first call): the reference's 1024 positions, clipped to what
+        half of the free device memory holds for this many rows."""
         S, T = input_ids.shape
+        # torch.nn.Embedding raises on an id outside the vocabulary in the same call; so does this path (one read-back: it is
+        # the incremental API, not the generate loop)
+        idc = input_ids.to(device=self.device)
+        if bool(((idc < 0) | (idc >= self.vocab)).any()):
+            raise IndexError(f"index out of range in self: a token id is outside [0, {self.vocab})")
         if past_len == 0:
             if feats is None or feats.shape[0] != S:
                 raise ValueError("image_hidden_states [S,1024] is needed when past_key_values is None")
             _require_gpu(feats.device)
-            dec = self._get_decoder(S, max(cache_len, T))
+            want = max(self.cache_tokens_that_fit(S, cache_len), T)
+            if self._decoder is not None and S <= self._decoder_caps[0]:
+                want = min(want, max(self._decoder_caps[1], T))   # an existing decoder is reused as is; it grows only for T
+            dec = self._get_decoder(S, want)
             self._cached = {"S": S, "tokens": 0}
         else:
             c = getattr(self, "_cached", None)
@@ -872,7 +918,9 @@ class HipEngine:
                                           "of this model (the cache lives in the HIP decoder)")
             dec = self._decoder
         if past_len + T > self._decoder_caps[1]:
-            raise NotImplementedError(f"the K/V cache holds {self._decoder_caps[1]} tokens; sequence of {past_len + T} requested")
+            raise NotImplementedError(f"the K/V cache of this call chain holds {self._decoder_caps[1]} tokens (sized when forward(use_cache=True) "
+                                      f"first ran: min(1024, what half of the free memory held for {S} rows)); a sequence of {past_len + T} "
+                                      "was requested")
         _hip.check(self.lib.rgrg_decoder_set_precision(dec, 0), "rgrg_decoder_set_precision")
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
         f = None if past_len else feats.to(torch.float32).contiguous()
@@ -883,9 +931,12 @@ class HipEngine:
         return logits, self._cache_views(dec, S, 1 + past_len + T)
 
     def _cache_views(self, dec, S: int, n_keys: int):
+        owner = self._decoder_owner   # every view keeps the decoder (whose cache it aliases) alive: see _DecoderOwner
+
         class _Plane:
             def __init__(self, ptr, shape):
                 self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (ptr, False), "version": 2}
+                self.owner = owner
         out = []
         for l in range(self.n_layer):
             pair = []

@@ -181,7 +181,9 @@ class ObjectDetector(EngineOwner):
     def _check_targets(self, targets) -> None:
         """object_detector.py:133-162 (torch._assert -> AssertionError, same messages) plus what torchvision's
         RoIHeads.check_targets and the losses enforce later in the reference's call: float boxes / int64 labels (TypeError)
-        and class labels inside the 30 logits (torch's cross entropy: "Target N is out of bounds")."""
+        and class labels below the 30 logits (torch's cross entropy: "Target N is out of bounds").  A NEGATIVE label raises
+        nothing, in the reference as here: proposals matched to that box count as neither positive nor negative for the
+        balanced sampler (torchvision samples labels >= 1 and == 0 only) and drop out of the losses."""
         for target_idx, t in enumerate(targets):   # shape / dtype checks: host metadata only
             boxes = t["boxes"]
             if not isinstance(boxes, torch.Tensor):
@@ -201,16 +203,16 @@ class ObjectDetector(EngineOwner):
         if not sum(sizes):
             return
         boxes = torch.cat([t["boxes"].reshape(-1, 4) for t in targets]).to(torch.float32)
-        labels = torch.cat([t["labels"].reshape(-1) for t in targets])
+        labels = torch.cat([t["labels"].reshape(-1).to(boxes.device) for t in targets])   # boxes / labels may sit on different devices
         degenerate = (boxes[:, 2:] <= boxes[:, :2]).any(dim=1)
-        flags = torch.stack([degenerate.any().to(torch.int64), labels.min(), labels.max()]).tolist()
+        flags = torch.stack([degenerate.any().to(torch.int64), labels.max()]).tolist()
         if flags[0]:
             bb = int(torch.where(degenerate)[0][0])
             target_idx = next(i for i in range(len(sizes)) if bb < sum(sizes[:i + 1]))
             raise AssertionError("All bounding boxes should have positive height and width."
                                  f" Found invalid box {boxes[bb].tolist()} for target at index {target_idx}.")
-        if flags[1] < 0 or flags[2] >= 30:
-            raise IndexError(f"Target {flags[2] if flags[2] >= 30 else flags[1]} is out of bounds.")
+        if flags[1] >= 30:
+            raise IndexError(f"Target {flags[1]} is out of bounds.")
 
     def forward(self, images: Tensor, targets: Optional[List[Dict[str, Tensor]]] = None):
         """Eval-mode ``ObjectDetector.forward`` (object_detector.py:184-261).  ``targets=None``: inference, losses = {}.

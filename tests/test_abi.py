@@ -128,6 +128,10 @@ def test_image_targets_are_validated_like_the_reference(model):
         model.object_detector(images, [{"boxes": ok, "labels": torch.tensor([1], dtype=torch.int32)}])
     with pytest.raises(IndexError, match="out of bounds"):                      # the class logits have 30 columns
         model.object_detector(images, [{"boxes": ok, "labels": torch.tensor([30])}])
+    # a negative label passes validation (torchvision / the reference raise nothing: such a box is ignored by the sampler);
+    # on this CPU-only model the call then stops at the missing GPU, not at the targets
+    with pytest.raises(_hip.RgrgHipError, match="no CPU fallback"):
+        model.object_detector(images, [{"boxes": ok, "labels": torch.tensor([-1])}])
 
 
 def test_no_cpu_fallback(model):

@@ -926,3 +926,37 @@ def test_incremental_forward_with_use_cache_matches_reference_fixture():
     for l, (k, v) in fx["presents"].items():
         assert presents[l][0].shape == k.shape
         assert (presents[l][0].cpu() - k).abs().max().item() <= 2e-3 and (presents[l][1].cpu() - v).abs().max().item() <= 2e-3
+
+
+def test_presents_are_invalidated_by_other_users_of_the_cache_and_outlive_a_replaced_decoder():
+    """(1) generate() / beam search rewrite the decoder's K/V cache and step counter, so the presents of an
+    earlier forward(use_cache=True) must be refused afterwards (they would silently continue on a clobbered cache);
+    (2) presents alias the decoder's memory: a decoder the engine replaces (larger batch) stays alive while they do -
+    reading them is not a use-after-free; (3) a token id outside the vocabulary raises IndexError in the same call, as
+    torch.nn.Embedding does (the path used to clamp silently)."""
+    m = gpu_model("ragged")
+    lm, eng = m.language_model, m.engine()
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn((3, 1024), generator=g).to(DEV)
+    prompt = torch.randint(0, 50000, (3, 4), generator=g).to(DEV)
+    one = torch.randint(0, 50000, (3, 1), generator=g).to(DEV)
+    am5 = torch.ones((3, 5), device=DEV)
+    _, presents = lm(prompt, torch.ones((3, 4), device=DEV), feats, return_loss=False, use_cache=True)
+    lm.generate(feats, max_length=8)                                    # same decoder, same cache rows
+    with pytest.raises(NotImplementedError, match="presents returned by the previous"):
+        lm(one, am5, feats, return_loss=False, past_key_values=presents, position_ids=torch.full((3, 1), 4), use_cache=True)
+    logits_a, presents = lm(prompt, torch.ones((3, 4), device=DEV), feats, return_loss=False, use_cache=True)
+    snapshot = presents[7][0].clone()
+    lm.generate(torch.randn((40, 1024), generator=g).to(DEV), max_length=6)   # 40 rows > 32: the engine creates a larger decoder
+    torch.cuda.synchronize()
+    assert torch.equal(presents[7][0], snapshot)                        # the old cache is still there, untouched
+    with pytest.raises(NotImplementedError):                            # ... but it is not the current decoder's
+        lm(one, am5, feats, return_loss=False, past_key_values=presents, position_ids=torch.full((3, 1), 4), use_cache=True)
+    del presents
+    bad = prompt.clone()
+    bad[1, 2] = 50257
+    with pytest.raises(IndexError, match="out of range"):
+        lm(bad, torch.ones((3, 4), device=DEV), feats, return_loss=False, use_cache=True)
+    logits_b, _ = lm(prompt, torch.ones((3, 4), device=DEV), feats, return_loss=False, use_cache=True)   # and the path still works
+    assert torch.equal(logits_a, logits_b)
+    assert eng.cache_tokens_that_fit(3, 1024) == 1024 and eng.cache_tokens_that_fit(100000, 1024) < 1024
