@@ -367,7 +367,7 @@ def config4_line(model, synth, world=1, use_dist=False, dev=None, steps=3, T=64)
                 "metric": "images/sec end-to-end training step", "value": B * world * steps / dt, "unit": "images/sec", "n_gpus": world,
                 "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": 1, "dtype": "bf16", "scaling": "weak", "global_batch": B * world,
                 "trainable_values": n_values, "allreduce_bytes_per_step": 4 * n_values if world > 1 else 0,
-                "losses_last_step": [float(o) for o in out[1:4]]}
+                "losses_last_step": [float(o.detach()) for o in out[1:4]]}
     finally:
         for p in model.trainable_parameters():
             p.grad = None

@@ -165,6 +165,14 @@ typedef struct rgrg_decoder rgrg_decoder;
  * decoder's own stream and this entry has no stream argument, so it first waits for whatever is still
  * producing them on the caller's streams.  Not on the hot loop.   max_seqs < 65536 (16-bit row tickets of the arg-max bookkeeping). */
 int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, int max_len, rgrg_decoder** out);
+/* The same with the K/V cache in CALLER-owned memory: kv_cache = device buffer of rgrg_decoder_kv_cache_bytes(n_layer,
+ * max_seqs, max_len) bytes, zero-filled by the caller, which must outlive the decoder; rgrg_decoder_destroy does not free it.
+ * The host mirror allocates it as a torch tensor, so that the `presents` of LanguageModel.forward(use_cache=True)
+ * (language_model.py:396-399) are ordinary views whose lifetime torch manages - they stay valid when the decoder is replaced. */
+int rgrg_decoder_create_with_cache(const rgrg_decoder_weights* w, int max_seqs, int max_len, void* kv_cache, size_t kv_cache_bytes,
+                                   rgrg_decoder** out);
+/* Bytes of the cache [n_layer][K | V][max_seqs][16 heads][max_len + 1 slots][64] in fp32. */
+size_t rgrg_decoder_kv_cache_bytes(int n_layer, int max_seqs, int max_len);
 void rgrg_decoder_destroy(rgrg_decoder* d);
 /* feats [S,1024] (selected region features); out_ids int64 [S,max_length] is filled
  * with the leading BOS, the generated ids, and PAD (50256) after a row finished;

@@ -16,7 +16,7 @@ c_float_p = C.c_void_p  # device pointers travel as void*
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p
 
 ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
-ABI_VERSION = 10  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
+ABI_VERSION = 11  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
 
 
 class RgrgHipError(RuntimeError):
@@ -52,6 +52,8 @@ SIGNATURES = {
     "rgrg_preprocess_u8_f32": (_i, [_p, _i, _i, _i, _i, _i, C.c_float, C.c_float, _p, _p]),
     "rgrg_gather_rows_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "rgrg_decoder_create": (_i, [C.POINTER(DecoderWeights), _i, _i, C.POINTER(_p)]),
+    "rgrg_decoder_create_with_cache": (_i, [C.POINTER(DecoderWeights), _i, _i, _p, C.c_size_t, C.POINTER(_p)]),
+    "rgrg_decoder_kv_cache_bytes": (C.c_size_t, [_i, _i, _i]),
     "rgrg_decoder_destroy": (None, [_p]),
     "rgrg_decoder_generate": (_i, [_p, _p, _i, _i, _p, _i, C.POINTER(_i), _i, _p]),
     "rgrg_decoder_beam_search": (_i, [_p, _p, _i, _i, _i, _i, _f, _i, _p, _i, C.POINTER(_i), _p]),

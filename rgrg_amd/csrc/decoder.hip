@@ -1808,7 +1808,16 @@ static int enqueue_prefill(rgrg_decoder* d, const float* feats, int S, int row_m
 
 }  // namespace rgrg
 
+extern "C" size_t rgrg_decoder_kv_cache_bytes(int n_layer, int max_seqs, int max_len) {
+    return (size_t)n_layer * 2 * (size_t)max_seqs * 16 * (size_t)(max_len + 1) * 64 * sizeof(float);
+}
+
 extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, int max_len, rgrg_decoder** out) {
+    return rgrg_decoder_create_with_cache(w, max_seqs, max_len, nullptr, 0, out);
+}
+
+extern "C" int rgrg_decoder_create_with_cache(const rgrg_decoder_weights* w, int max_seqs, int max_len, void* kv_cache, size_t kv_cache_bytes,
+                                              rgrg_decoder** out) {
     RGRG_CHECK_ARG(w && out && max_seqs > 0 && max_seqs < 65536 && max_len >= 2 && max_len <= 1024);  // 16-bit row tickets (argmax_update_kernel)
     RGRG_CHECK_ARG(w->d_model == 1024 && w->n_head == 16 && w->n_layer > 0 && w->vocab > 0 && w->layers);
     int rc = init_gemm_attrs();
@@ -1873,7 +1882,16 @@ extern "C" int rgrg_decoder_create(const rgrg_decoder_weights* w, int max_seqs, 
     TRY(dmalloc(d, (void**)&d->part, (size_t)(SKINNY_MAX_ROWS / PAD_ROWS) * 8 * PAD_ROWS * D * 4, true));  // [tiles<=4][KS<=8][32][N=1024]
     d->kv_kv_stride = (size_t)d->max_seqs * d->H * d->T * 64;
     d->kv_layer_stride = 2 * d->kv_kv_stride;
-    TRY(dmalloc(d, (void**)&d->kv, (size_t)d->n_layer * d->kv_layer_stride * 4, true));
+    if (kv_cache) {   // caller-owned (zero-filled) cache: never freed here
+        if (kv_cache_bytes < (size_t)d->n_layer * d->kv_layer_stride * 4) {
+            set_error("decoder: the caller's K/V cache holds %zu bytes, %zu needed", kv_cache_bytes, (size_t)d->n_layer * d->kv_layer_stride * 4);
+            rgrg_decoder_destroy(d);
+            return RGRG_EINVAL;
+        }
+        d->kv = static_cast<float*>(kv_cache);
+    } else {
+        TRY(dmalloc(d, (void**)&d->kv, (size_t)d->n_layer * d->kv_layer_stride * 4, true));
+    }
     TRY(dmalloc(d, (void**)&d->ids, R * max_len * sizeof(long long), true));
     TRY(dmalloc(d, (void**)&d->next, R * 4, true));
     TRY(dmalloc(d, (void**)&d->finished, R * 4, true));

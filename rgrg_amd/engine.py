@@ -173,25 +173,6 @@ def _bn_affine(sd: Dict[str, Tensor], p: str) -> Tuple[Tensor, Tensor]:
     return alpha.contiguous(), beta.contiguous()
 
 
-class _DecoderOwner:
-    """Owns one ``rgrg_decoder``: destroyed when the last reference goes - the engine's, or that of the ``presents`` views
-    ``forward(use_cache=True)`` handed out (they alias the decoder's K/V cache: freeing it under a live view would be a
-    use-after-free on the GPU).  A decoder the engine has replaced therefore lives (memory included) as long as a caller keeps
-    its presents."""
-
-    def __init__(self, lib, handle, device):
-        self.lib, self.handle, self.device = lib, handle, device
-
-    def __del__(self):
-        try:
-            if self.handle is not None:
-                with torch.cuda.device(self.device):
-                    self.lib.rgrg_decoder_destroy(self.handle)
-                self.handle = None
-        except Exception:  # noqa: BLE001
-            pass
-
-
 @_on_engine_device
 class HipEngine:
     def __init__(self, state_dict: Dict[str, Tensor], device: torch.device):
@@ -201,7 +182,7 @@ class HipEngine:
         self.device = device
         self.lib = _hip.load()
         self._decoder = None
-        self._decoder_owner = None
+        self._kv = None        # the decoder's K/V cache: a torch tensor (caller-owned memory of rgrg_decoder_create_with_cache)
         self._cached = None
         self._init(state_dict)
 
@@ -327,9 +308,11 @@ class HipEngine:
             pending = C.c_int(0)
             if self.lib.rgrg_decoder_take_id_error(self._decoder, C.byref(pending)) == 0 and pending.value:
                 self._pending_id_error = True
-            # the decoder is destroyed when its last owner goes: now, unless presents of forward(use_cache=True) still alias its cache
+            self.lib.rgrg_decoder_destroy(self._decoder)
+            # the K/V cache is a torch tensor: presents of forward(use_cache=True) are views of it and keep it alive by
+            # themselves after the decoder is gone (reading them is never a use-after-free)
             self._decoder = None
-            self._decoder_owner = None
+            self._kv = None
             self._cached = None
 
     def __del__(self):
@@ -737,10 +720,13 @@ class HipEngine:
             cap_s = max(32, ((S + 31) // 32) * 32, cap_s)
             cap_l = max(max_len, cap_l)
             h = C.c_void_p()
-            _hip.check(self.lib.rgrg_decoder_create(C.byref(self._dec_weights), cap_s, cap_l, C.byref(h)),
-                       "rgrg_decoder_create")
-            self._decoder, self._decoder_caps = h, (cap_s, cap_l)
-            self._decoder_owner = _DecoderOwner(self.lib, h, self.device)
+            nbytes = int(self.lib.rgrg_decoder_kv_cache_bytes(self.n_layer, cap_s, cap_l))
+            kv = torch.zeros((self.n_layer, 2, cap_s, 16, cap_l + 1, 64), dtype=torch.float32, device=self.device)
+            assert kv.numel() * 4 == nbytes
+            torch.cuda.current_stream(self.device).synchronize()   # the zero fill is complete before the decoder's own stream uses the cache
+            _hip.check(self.lib.rgrg_decoder_create_with_cache(C.byref(self._dec_weights), cap_s, cap_l, _hip.ptr(kv), nbytes, C.byref(h)),
+                       "rgrg_decoder_create_with_cache")
+            self._decoder, self._decoder_caps, self._kv = h, (cap_s, cap_l), kv
         return self._decoder
 
     def greedy_decode(self, feats: Tensor, max_length: Optional[int], use_graph: bool = True, bf16: bool = False) -> Tensor:
@@ -931,23 +917,8 @@ class HipEngine:
         return logits, self._cache_views(dec, S, 1 + past_len + T)
 
     def _cache_views(self, dec, S: int, n_keys: int):
-        owner = self._decoder_owner   # every view keeps the decoder (whose cache it aliases) alive: see _DecoderOwner
-
-        class _Plane:
-            def __init__(self, ptr, shape):
-                self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (ptr, False), "version": 2}
-                self.owner = owner
-        out = []
-        for l in range(self.n_layer):
-            pair = []
-            for kv in (0, 1):
-                ptr, ms, slots, b16 = C.c_void_p(), C.c_int(0), C.c_int(0), C.c_int(0)
-                _hip.check(self.lib.rgrg_decoder_cache_plane(dec, l, kv, C.byref(ptr), C.byref(ms), C.byref(slots), C.byref(b16)),
-                           "rgrg_decoder_cache_plane")
-                t = torch.as_tensor(_Plane(ptr.value, (ms.value, 16, slots.value, 64)), device=self.device)
-                pair.append(t[:S, :, :n_keys])
-            out.append(tuple(pair))
-        return tuple(out)
+        """The reference's ``presents``: 24 (key, value) pairs [S, 16, n_keys, 64], views of the cache tensor."""
+        return tuple((self._kv[l, 0, :S, :, :n_keys], self._kv[l, 1, :S, :, :n_keys]) for l in range(self.n_layer))
 
     def owns_cache(self, past_key_values) -> Optional[int]:
         """Number of tokens cached if ``past_key_values`` are this decoder's own presents (as returned by the previous
@@ -957,9 +928,8 @@ class HipEngine:
             return None
         try:
             k0 = past_key_values[0][0]
-            ptr = C.c_void_p()
-            _hip.check(self.lib.rgrg_decoder_cache_plane(self._decoder, 0, 0, C.byref(ptr), None, None, None), "rgrg_decoder_cache_plane")
-            if k0.data_ptr() == ptr.value and k0.shape[0] == c["S"] and k0.shape[-2] == 1 + c["tokens"] and len(past_key_values) == self.n_layer:
+            if (self._kv is not None and k0.data_ptr() == self._kv.data_ptr() and k0.shape[0] == c["S"] and k0.shape[-2] == 1 + c["tokens"]
+                    and len(past_key_values) == self.n_layer):
                 return c["tokens"]
         except Exception:  # noqa: BLE001
             return None
