@@ -195,7 +195,7 @@ def detector_rooflines(eng, images, bf16):
     def roi():
         fn = eng.lib.rgrg_roi_align_avgpool_bf16maps if low else eng.lib.rgrg_roi_align_avgpool_f32
         _hip.check(fn(feat.data_ptr(), props.data_ptr(), offsets.data_ptr(), maps.data_ptr(), pooled.data_ptr(), B, feat.shape[1], feat.shape[2],
-                      Cf, props.shape[1], R, 1.0 / 32, st()), "roi_align")
+                      Cf, props.shape[1], R, 1.0 / 32, *(([0]) if low else []), st()), "roi_align")
 
     ms_roi, _ = timed(roi)
     if low:
@@ -204,7 +204,7 @@ def detector_rooflines(eng, images, bf16):
 
         def fc6():
             _hip.check(eng.lib.rgrg_linear_bf16_f32(maps.data_ptr(), wb.data_ptr(), eng.fc6_b.data_ptr(), None, h6.data_ptr(), None, R, 1024,
-                                                    64 * Cf, 1024, _hip.ACT_RELU, st()), "fc6")
+                                                    64 * Cf, 1024, _hip.ACT_RELU, 0, st()), "fc6")
         ms_fc6, _ = timed(fc6)
     else:
         if maps.dtype != torch.float32:

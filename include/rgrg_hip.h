@@ -94,12 +94,12 @@ int rgrg_rpn_proposals_f32(const float* head_out, const float* anchors, float* p
 int rgrg_roi_align_avgpool_f32(const float* feat, const float* proposals, const int32_t* offsets, float* out,
                                float* pooled, int B, int FH, int FW, int C, int max_props, int R_total,
                                float spatial_scale, void* stream);
-/* The same with the [R, 64, C] maps stored as bf16 (round to nearest even; pooled stays f32 from unrounded values): what
- * the box head consumes under torch.autocast (generate_reports_for_images.py:108) - fc6 then runs on
- * rgrg_linear_bf16_f32 with half the A bytes. */
+/* The same with the [R, 64, C] maps stored as 16-bit values (fp16 = 0: bf16, 1: float16; round to nearest even; pooled stays
+ * f32 from unrounded values): what the box head consumes under torch.autocast (generate_reports_for_images.py:108) - fc6
+ * then runs on rgrg_linear_bf16_f32 with half the A bytes. */
 int rgrg_roi_align_avgpool_bf16maps(const float* feat, const float* proposals, const int32_t* offsets, uint16_t* out16,
                                     float* pooled, int B, int FH, int FW, int C, int max_props, int R_total,
-                                    float spatial_scale, void* stream);
+                                    float spatial_scale, int fp16, void* stream);
 
 /* CustomRoIHeads.get_top_region_features_detections_class_detected
  * (custom_roi_heads.py:63-208), eval: pred [R, ldp] holds 30 class logits then 120
@@ -193,12 +193,12 @@ int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S, int max_le
 int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int S, int num_beams, int max_length,
                              int early_stopping, float length_penalty, int num_return_sequences, int64_t* out_ids,
                              int out_ld, int* out_len, void* stream);
-/* Opt-in reduced precision for MANY sequences (BASELINE configs[2], batch 32): bf16_gemms = 1 makes the
- * > 128-row paths run their projections on the bf16 MFMA (bf16 weights, activations rounded to bf16 in LDS,
- * fp32 accumulate / LayerNorm / softmax / residual) and keep the decode K/V cache in bf16 (what the reference's
- * torch.autocast does to `present`).  NOT bit-exact with the fp32 reference; the <= 128-sequence decode path
- * (launch-latency bound) always stays fp32.  May allocate and synchronise. */
-int rgrg_decoder_set_precision(rgrg_decoder* d, int bf16_gemms);
+/* Opt-in reduced precision for MANY sequences (BASELINE configs[2], batch 32): mode 1 (bfloat16) / 2 (float16) makes the
+ * > 128-row paths run their projections on the 16-bit MFMA (16-bit weights and GEMM inputs, fp32 accumulate / LayerNorm /
+ * softmax / residual) and keep the decode K/V cache in that type (what the reference's torch.autocast does to `present`);
+ * 0 = fp32.  NOT bit-exact with the fp32 reference; the <= 128-sequence decode path (launch-latency bound) always stays
+ * fp32.  May allocate and synchronise (a change of the 16-bit type re-converts the weight copies). */
+int rgrg_decoder_set_precision(rgrg_decoder* d, int mode);
 /* Replaces LanguageModel.forward(input_ids, attention_mask, image_hidden_states, return_loss, use_cache=False)
  * in eval mode (src/language_model/language_model.py:258-399): one teacher-forced pass over
  * T tokens per sequence - feature_space_transformation_nn, wte[ids] + wte[arange(T)] (:298-307), 24 blocks of
@@ -280,10 +280,13 @@ int rgrg_bce_with_logits_masked_backward_f32(const float* logits, const uint8_t*
  * with g = grad * grad_scale (1/AMP-scale, 1/accumulation steps).  All arrays f32 [n]; step t >= 1. */
 int rgrg_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                         float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
-/* fp32 -> bf16 (round to nearest even), and Y = act(bf16(A) Wb^T + shift + R) on v_mfma_f32_32x32x16_bf16
- * (A fp32 [M,K], Wb bf16 [N,K], K % 64 == 0). */
-int rgrg_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
-int rgrg_bf16_to_f32(const uint16_t* src, float* dst, int64_t n, void* stream);   /* exact widening */
+/* The 16-bit entry points below (names say bf16 for history) take `fp16`: 0 = bfloat16, 1 = IEEE float16 - the dtype of the
+ * caller's torch.autocast (the reference's scripts use float16: generate_reports_for_images.py:108, train_full_model.py:172).
+ * Storage is uint16_t bits either way; the matrix core runs v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x16_f16 (same rate),
+ * fp32 accumulate; conversions round to nearest even, fp16 overflows to inf beyond 65504 as torch's does.
+ * fp32 -> 16 bit, and Y = act(r16(A) Wb^T + shift + R) (A fp32 [M,K], Wb 16-bit [N,K], K % 64 == 0). */
+int rgrg_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, int fp16, void* stream);
+int rgrg_bf16_to_f32(const uint16_t* src, float* dst, int64_t n, int fp16, void* stream);   /* exact widening */
 /* Replaces nn.Conv2d + eval BatchNorm2d (+ residual add) + ReLU of the ResNet-50 bottlenecks and the RPNHead convs
  * (src/object_detector/object_detector.py:51-62,219; custom_rpn.py:61) WHEN THE CALLER RUNS UNDER torch.autocast
  * (generate_reports_for_images.py:108: the reference's detector then computes in half precision): implicit GEMM on
@@ -293,20 +296,20 @@ int rgrg_bf16_to_f32(const uint16_t* src, float* dst, int64_t n, void* stream); 
  *       NULL; R16 bf16 [B,OH,OW,Cout] or NULL; the result goes to Y (f32) or Y16 (bf16), exactly one non-NULL. */
 int rgrg_conv2d_nhwc_bf16(const uint16_t* X16, const uint16_t* Wb, const float* shift, const uint16_t* R16, float* Y,
                           uint16_t* Y16, int B, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                          int act, void* stream);
+                          int act, int fp16, void* stream);
 int rgrg_linear_bf16w_f32(const float* A, const uint16_t* Wb, const float* shift, const float* R, float* Y, int M,
-                          int N, int K, int ldy, int act, void* stream);
+                          int N, int K, int ldy, int act, int fp16, void* stream);
 /* The same product with BOTH operands already bf16 in device memory (A16 [M,K], Wb [N,K], K % 256 == 0): the
  * LDS-DMA kernel of the opt-in bf16 decode / box-head paths (operands go HBM -> LDS without touching registers, 4 LDS
  * stages in flight across the barriers).  fp32 accumulate; epilogue shift [N] / residual R fp32 [M,ldy] / activation
  * in fp32; the result is stored as fp32 (Y) or as bf16 (Y16, feeds the next GEMM) - exactly one of them non-NULL. */
 int rgrg_linear_bf16_f32(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
-                         uint16_t* Y16, int M, int N, int K, int ldy, int act, void* stream);
+                         uint16_t* Y16, int M, int N, int K, int ldy, int act, int fp16, void* stream);
 /* Measurement hook (tools/gemm_bf16_bench.py): the LDS-DMA kernel with a forced configuration: tile = shape + 16 * stages
  * (shape 0 heuristic, 1 128x128, 2 64x64, 3 128x64, 4 64x128; stages 0 = 4, or 2 / 3 / 4 LDS stages) and operand row
  * pitches lda / ldw in elements (0 = K). */
 int rgrg_debug_linear_bf16_tile(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
-                                int M, int N, int K, int ldy, int act, int tile, int lda, int ldw, void* stream);
+                                int M, int N, int K, int ldy, int act, int tile, int lda, int ldw, int fp16, void* stream);
 /* ---- detector targets and losses: ObjectDetector.forward(images, targets), the detector half of
  * ReportGenerationModel.forward(images, image_targets, ...) (src/full_model/report_generation_model.py:55,91 ->
  * src/object_detector/object_detector.py:216-224 -> custom_rpn.py:74-83, custom_roi_heads.py:225-242, and underneath

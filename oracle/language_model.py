@@ -29,9 +29,11 @@ def gelu_new(x: Tensor) -> Tensor:
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
 
 
-def _r16(t: Tensor) -> Tensor:
-    """Round to bfloat16 and back (what a bf16 store / operand conversion does; round to nearest even)."""
-    return t.to(torch.bfloat16).to(torch.float32)
+def _r16(t: Tensor, mode=True) -> Tensor:
+    """Round to the 16-bit type of the reduced-precision mode and back (what a 16-bit store / operand conversion does; round
+    to nearest even): ``mode`` True / 1 = bfloat16, 2 = float16 (IEEE half - the dtype of the reference's own autocast,
+    generate_reports_for_images.py:108)."""
+    return t.to(torch.float16 if mode == 2 else torch.bfloat16).to(torch.float32)
 
 
 def conv1d(sd: SD, p: str, x: Tensor, bf16: bool = False) -> Tensor:
@@ -39,7 +41,7 @@ def conv1d(sd: SD, p: str, x: Tensor, bf16: bool = False) -> Tensor:
     autocast GEMM (both operands rounded to bf16, fp32 accumulation, fp32 bias) - used to check the opt-in bf16 path."""
     w = sd[p + "weight"]
     if bf16:
-        x, w = _r16(x), _r16(w)
+        x, w = _r16(x, bf16), _r16(w, bf16)
     return torch.addmm(sd[p + "bias"], x.reshape(-1, x.shape[-1]), w).view(*x.shape[:-1], w.shape[-1])
 
 
@@ -55,12 +57,12 @@ def pseudo_attention(sd: SD, p: str, x: Tensor, img: Tensor, add_mask: Tensor,
     K/V cache (the reference under autocast), scores / softmax / accumulation in fp32."""
     q, k, v = conv1d(sd, p + "c_attn.", x, bf16).split(D_MODEL, dim=2)
     if bf16:
-        k, v = _r16(k), _r16(v)
+        k, v = _r16(k, bf16), _r16(v, bf16)
     if past is None:
         k_img = F.linear(img[:, None, :], sd[p + "uk.weight"], sd[p + "uk.bias"])
         v_img = F.linear(img[:, None, :], sd[p + "uv.weight"], sd[p + "uv.bias"])
         if bf16:
-            k_img, v_img = _r16(k_img), _r16(v_img)
+            k_img, v_img = _r16(k_img, bf16), _r16(v_img, bf16)
         K = _heads(torch.cat((k_img, k), dim=1))
         V = _heads(torch.cat((v_img, v), dim=1))
     else:
@@ -117,7 +119,7 @@ def lm_forward(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_s
     if return_hidden:  # the caller applies lm_head itself (row chunks: [S,T,50257] does not fit for many rows)
         return x, presents
     lmw = sd[p + "gpt_with_lm_head.lm_head.weight"]
-    logits = F.linear(_r16(x), _r16(lmw)) if bf16 else F.linear(x, lmw)  # [S,T,50257]
+    logits = F.linear(_r16(x, bf16), _r16(lmw, bf16)) if bf16 else F.linear(x, lmw)  # [S,T,50257]
     return logits, presents
 
 
@@ -139,7 +141,7 @@ def teacher_forced_trace(sd: SD, ids: Tensor, image_hidden_states: Tensor, bf16:
     x, _ = lm_forward(sd, ids[:, :T], am, image_hidden_states, None, pos, p, bf16=bf16, return_hidden=True)
     lmw = sd[p + "gpt_with_lm_head.lm_head.weight"]
     if bf16:
-        x, lmw = _r16(x), _r16(lmw)
+        x, lmw = _r16(x, bf16), _r16(lmw, bf16)
     chosen = torch.empty((S, T))
     top_val = torch.empty((S, T, topk))
     top_idx = torch.empty((S, T, topk), dtype=torch.int64)

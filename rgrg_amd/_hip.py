@@ -16,7 +16,7 @@ c_float_p = C.c_void_p  # device pointers travel as void*
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p
 
 ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
-ABI_VERSION = 11  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
+ABI_VERSION = 12  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
 
 
 class RgrgHipError(RuntimeError):
@@ -45,7 +45,7 @@ SIGNATURES = {
     "rgrg_maxpool3x3s2_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "rgrg_rpn_proposals_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p]),
     "rgrg_roi_align_avgpool_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
-    "rgrg_roi_align_avgpool_bf16maps": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "rgrg_roi_align_avgpool_bf16maps": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "rgrg_top1_per_class_f32": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p]),
     "rgrg_select_regions_f32": (_i, [_p, _p, _f, _p, _p, _p, _i, _p]),
     "rgrg_bce_with_logits_masked_f32": (_i, [_p, _p, _p, C.c_float, _i, _p, _p]),
@@ -70,12 +70,12 @@ SIGNATURES = {
     "rgrg_relu_backward_f32": (_i, [_p, _p, C.c_int64, _p]),
     "rgrg_bce_with_logits_masked_backward_f32": (_i, [_p, _p, _p, C.c_float, _i, C.c_float, _p, _i, _p]),
     "rgrg_adamw_step_f32": (_i, [_p, _p, _p, _p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _p]),
-    "rgrg_f32_to_bf16": (_i, [_p, _p, C.c_int64, _p]),
-    "rgrg_bf16_to_f32": (_i, [_p, _p, C.c_int64, _p]),
-    "rgrg_conv2d_nhwc_bf16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "rgrg_linear_bf16w_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "rgrg_linear_bf16_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "rgrg_debug_linear_bf16_tile": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "rgrg_f32_to_bf16": (_i, [_p, _p, C.c_int64, _i, _p]),
+    "rgrg_bf16_to_f32": (_i, [_p, _p, C.c_int64, _i, _p]),
+    "rgrg_conv2d_nhwc_bf16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "rgrg_linear_bf16w_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "rgrg_linear_bf16_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "rgrg_debug_linear_bf16_tile": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rgrg_decoder_copy_last_logits": (_i, [_p, _p, _i, _p]),
     "rgrg_box_match_f32": (_i, [_p, _p, _i, _p, C.c_int64, _p, _i, _i, _f, _f, _i, _p, _p, _p]),
     "rgrg_box_encode_f32": (_i, [_p, _p, _i, _f, _f, _f, _f, _p, _p]),
@@ -124,6 +124,18 @@ def load() -> C.CDLL:
                            "(python -m rgrg_amd.build)")
     _lib = lib
     return lib
+
+
+def autocast_mode() -> int:
+    """The reduced-precision mode the caller asked for through torch.autocast("cuda", dtype): 0 = none (fp32), 1 = bfloat16,
+    2 = float16 (the dtype of the reference's own scripts: generate_reports_for_images.py:108, train_full_model.py:172).  The HIP
+    path then runs its matrix-core GEMMs / convolutions with 16-bit operands OF THAT TYPE and keeps the many-row K/V cache
+    in it; everything else stays fp32."""
+    import torch
+    if not torch.is_autocast_enabled("cuda"):
+        return 0
+    dt = torch.get_autocast_dtype("cuda")
+    return 1 if dt == torch.bfloat16 else (2 if dt == torch.float16 else 0)
 
 
 def check(rc: int, what: str = "") -> None:

@@ -66,6 +66,31 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     v += dpp_get<0x143, 0xc>(v);  // row_bcast31 -> rows 2, 3: row 3 holds the wave sum
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// The two 16-bit storage / matrix-core input types of the opt-in reduced-precision path (torch.autocast's dtype): bf16 and
+// IEEE fp16 - the reference's scripts run under torch.autocast(float16) (generate_reports_for_images.py:108,
+// train_full_model.py:172).  Both round to nearest even; fp16 saturates to inf beyond 65504 as torch's does.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned f32_to_bf16_bits(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ unsigned f32_to_f16_bits(float f) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)f); }
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ float f16_bits_to_f32(unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
+template <bool F16>
+__device__ __forceinline__ unsigned to16(float f) {
+    if constexpr (F16) return f32_to_f16_bits(f);
+    else return f32_to_bf16_bits(f);
+}
+template <bool F16>
+__device__ __forceinline__ float from16(unsigned h) {
+    if constexpr (F16) return f16_bits_to_f32(h);
+    else return bf16_bits_to_f32(h);
+}
+__device__ __forceinline__ unsigned to16_rt(float f, int f16) { return f16 ? f32_to_f16_bits(f) : f32_to_bf16_bits(f); }
+__device__ __forceinline__ float from16_rt(unsigned h, int f16) { return f16 ? f16_bits_to_f32(h) : bf16_bits_to_f32(h); }
+
 // XCD (accelerator complex die, 0..7) this wave runs on: every XCD has its own 4 MiB L2
 __device__ __forceinline__ int xcc_id() {
     int x;

@@ -35,11 +35,12 @@ int launch_gemm_dense(const float* A, const float* W, const float* shift, const 
                       int ldy, int act, float* ws, size_t ws_floats, hipStream_t st);
 int init_gemm_attrs();
 int init_gemm_bf16_attrs();
+// (gemm_bf16.hip; f16: the 16-bit type - 0 bf16, 1 IEEE fp16)
 int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const float* shift, const float* R, float* Y, void* Y16,
-                         int M, int N, int K, int ldy, int act, hipStream_t st);
+                         int M, int N, int K, int ldy, int act, hipStream_t st, int f16);
 int launch_gemm_bf16w(const float* A, const void* Wb, const float* shift, const float* R, float* Y, int M, int N, int K,
-                      int ldy, int act, hipStream_t st);
-int convert_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st);
+                      int ldy, int act, hipStream_t st, int f16);
+int convert_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st, int f16);
 
 constexpr int PAD_ROWS = 32;
 constexpr int SKINNY_MAX_ROWS = 128;  // 4 row tiles of 32 sequences per weight-streaming launch (RGRG_SKINNY_MAX_ROWS)
@@ -321,16 +322,11 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// fp32 -> bf16 bits, round to nearest even (the rounding the bf16 GEMM applies when it stages fp32 activations)
-__device__ __forceinline__ unsigned short bf16_bits_rne(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ void store_bf16x4(unsigned short* dst, const f32x4 v) {
+// 4 fp32 -> 4 16-bit values (bf16 / fp16 by f16, round to nearest even: the rounding the 16-bit GEMM would apply to an fp32 input)
+__device__ __forceinline__ void store_16x4(unsigned short* dst, const f32x4 v, int f16) {
     uint2 o;
-    o.x = (unsigned)bf16_bits_rne(v[0]) | ((unsigned)bf16_bits_rne(v[1]) << 16);
-    o.y = (unsigned)bf16_bits_rne(v[2]) | ((unsigned)bf16_bits_rne(v[3]) << 16);
+    o.x = to16_rt(v[0], f16) | (to16_rt(v[1], f16) << 16);
+    o.y = to16_rt(v[2], f16) | (to16_rt(v[3], f16) << 16);
     *reinterpret_cast<uint2*>(dst) = o;
 }
 
@@ -357,14 +353,14 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
                                                        int ld_ids, const int* __restrict__ step, const float* __restrict__ g,
                                                        const float* __restrict__ b, float* __restrict__ x,
                                                        float* __restrict__ xn, int D, const int* __restrict__ tok_override,
-                                                       unsigned short* __restrict__ xn16 = nullptr) {
+                                                       unsigned short* __restrict__ xn16, int f16) {
     __shared__ float sh[4];
     const int s = blockIdx.x, t = *step, tid = threadIdx.x;
     const long long tok = tok_override ? (long long)tok_override[s] : ids[(size_t)s * ld_ids + t];  // beam search feeds the beam tokens
     const f32x4 v = reinterpret_cast<const f32x4*>(wte + (size_t)tok * D)[tid] + reinterpret_cast<const f32x4*>(wte + (size_t)t * D)[tid];
     reinterpret_cast<f32x4*>(x + (size_t)s * D)[tid] = v;
     const f32x4 o = ln_row(v, g, b, sh, D);
-    if (xn16) store_bf16x4(xn16 + (size_t)s * D + 4 * tid, o);  // bf16-activation mode: the GEMMs read only this copy
+    if (xn16) store_16x4(xn16 + (size_t)s * D + 4 * tid, o, f16);  // 16-bit-activation mode: the GEMMs read only this copy
     else reinterpret_cast<f32x4*>(xn + (size_t)s * D)[tid] = o;
 }
 
@@ -374,7 +370,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
 // in two block reductions: 12 192 launches = 6 % of a batch-32 run).  Two-pass variance like nn.LayerNorm.
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                       const float* __restrict__ b, float* __restrict__ xn, int D,
-                                                      unsigned short* __restrict__ xn16, int rows) {
+                                                      unsigned short* __restrict__ xn16, int f16, int rows) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
@@ -404,7 +400,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = v[j][e] * rstd * gg[j][e] + bb[j][e];
-        if (xn16) store_bf16x4(xn16 + (size_t)row * D + 4 * (j * 64 + lane), o);
+        if (xn16) store_16x4(xn16 + (size_t)row * D + 4 * (j * 64 + lane), o, f16);
         else reinterpret_cast<f32x4*>(xn + (size_t)row * D)[j * 64 + lane] = o;
     }
 }
@@ -523,12 +519,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
 // hence ``present``, bf16 as well)
 typedef unsigned short u16;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned bf16_rne_bits(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+// the two values of a packed 16-bit pair as fp32 (bf16: shift / mask; fp16: v_cvt_f32_f16)
+template <bool F16>
+__device__ __forceinline__ float pair_lo(unsigned u) {
+    if constexpr (F16) return f16_bits_to_f32(u & 0xffffu);
+    else return __uint_as_float(u << 16);
 }
-__device__ __forceinline__ float bf16_round(float f) { return __uint_as_float(bf16_rne_bits(f) << 16); }
+template <bool F16>
+__device__ __forceinline__ float pair_hi(unsigned u) {
+    if constexpr (F16) return f16_bits_to_f32(u >> 16);
+    else return __uint_as_float(u & 0xffff0000u);
+}
 
 // Wave-per-head variant of the bf16-cache attention (round 2): a WAVE owns one (sequence, head) - the 4 waves of a
 // workgroup are 4 consecutive heads of one sequence - so there is no LDS, no barrier and a quarter of the workgroups
@@ -541,17 +542,18 @@ __device__ __forceinline__ float bf16_round(float f) { return __uint_as_float(bf
 struct Kv16Row {  // this lane's 8 dims of the current token's q / k / v (fp32, as c_attn wrote them)
     f32x4 q0, q1, k0, k1, v0, v1;
 };
-__device__ __forceinline__ u32x4 kv16_pack_round(const f32x4& lo, const f32x4& hi) {  // 8 fp32 -> 8 bf16 (RNE), packed
+template <bool F16>
+__device__ __forceinline__ u32x4 kv16_pack_round(const f32x4& lo, const f32x4& hi) {  // 8 fp32 -> 8 16-bit values (RNE), packed
     u32x4 o;
-    o[0] = bf16_rne_bits(lo[0]) | (bf16_rne_bits(lo[1]) << 16);
-    o[1] = bf16_rne_bits(lo[2]) | (bf16_rne_bits(lo[3]) << 16);
-    o[2] = bf16_rne_bits(hi[0]) | (bf16_rne_bits(hi[1]) << 16);
-    o[3] = bf16_rne_bits(hi[2]) | (bf16_rne_bits(hi[3]) << 16);
+    o[0] = to16<F16>(lo[0]) | (to16<F16>(lo[1]) << 16);
+    o[1] = to16<F16>(lo[2]) | (to16<F16>(lo[3]) << 16);
+    o[2] = to16<F16>(hi[0]) | (to16<F16>(hi[1]) << 16);
+    o[3] = to16<F16>(hi[2]) | (to16<F16>(hi[3]) << 16);
     return o;
 }
 
 // FIRST: the first chunk of a wave turns the raw q / k / v into q[8] and the packed bf16 kn16 / vn16 (after its loads)
-template <int NI, bool HAS_SRC, bool FIRST>
+template <int NI, bool HAS_SRC, bool FIRST, bool F16>
 __device__ __forceinline__ void kv16_wave_chunk(const __amdgpu_buffer_rsrc_t kc, const __amdgpu_buffer_rsrc_t vc, const int* __restrict__ srow,
                                                 int s, int hd, int H, int T, int base, int nkeys, int slot, int g, int d8,
                                                 Kv16Row& r, float (&q)[8], u32x4& kn16, u32x4& vn16, float& m, float& l, float (&acc)[8]) {
@@ -580,8 +582,8 @@ __device__ __forceinline__ void kv16_wave_chunk(const __amdgpu_buffer_rsrc_t kc,
             asm volatile("" : "+v"(r.q0[e]), "+v"(r.q1[e]), "+v"(r.k0[e]), "+v"(r.k1[e]), "+v"(r.v0[e]), "+v"(r.v1[e]));
 #pragma unroll
         for (int e = 0; e < 4; ++e) { q[e] = r.q0[e]; q[4 + e] = r.q1[e]; }
-        kn16 = kv16_pack_round(r.k0, r.k1);
-        vn16 = kv16_pack_round(r.v0, r.v1);
+        kn16 = kv16_pack_round<F16>(r.k0, r.k1);
+        vn16 = kv16_pack_round<F16>(r.v0, r.v1);
     }
     float sc[NI];
     float cmax = -INFINITY;
@@ -592,7 +594,7 @@ __device__ __forceinline__ void kv16_wave_chunk(const __amdgpu_buffer_rsrc_t kc,
         float dot = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            dot += q[2 * e] * __uint_as_float(kk[i][e] << 16) + q[2 * e + 1] * __uint_as_float(kk[i][e] & 0xffff0000u);
+            dot += q[2 * e] * pair_lo<F16>(kk[i][e]) + q[2 * e + 1] * pair_hi<F16>(kk[i][e]);
         dot += dpp_get<0xB1, 0xf>(dot);
         dot += dpp_get<0x4E, 0xf>(dot);
         dot += dpp_get<0x141, 0xf>(dot);  // row_half_mirror: sum over the 8 lanes of the group
@@ -613,14 +615,14 @@ __device__ __forceinline__ void kv16_wave_chunk(const __amdgpu_buffer_rsrc_t kc,
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const unsigned u = j < nkeys ? vv[i][e] : 0u;
-            acc[2 * e] += pj * __uint_as_float(u << 16);
-            acc[2 * e + 1] += pj * __uint_as_float(u & 0xffff0000u);
+            acc[2 * e] += pj * pair_lo<F16>(u);
+            acc[2 * e + 1] += pj * pair_hi<F16>(u);
         }
     }
     m = m_new;
 }
 
-template <bool HAS_SRC>
+template <bool HAS_SRC, bool F16>
 __global__ __launch_bounds__(256) void attn_decode_kv16_wave_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                                     u16* __restrict__ kc, u16* __restrict__ vc,
                                                                     const int* __restrict__ step, float* __restrict__ out,
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(256) void attn_decode_kv16_wave_kernel(const float*
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     const __amdgpu_buffer_rsrc_t rk = dx_rsrc(kc), rv = dx_rsrc(vc);
 #define KV16_CHUNK(NI_, FIRST_, BASE_) \
-    kv16_wave_chunk<NI_, HAS_SRC, FIRST_>(rk, rv, srow, s, hd, H, T, BASE_, nkeys, slot, g, d8, r, q, kn16, vn16, m, l, acc)
+    kv16_wave_chunk<NI_, HAS_SRC, FIRST_, F16>(rk, rv, srow, s, hd, H, T, BASE_, nkeys, slot, g, d8, r, q, kn16, vn16, m, l, acc)
     // chunks of 72 keys while more than 48 remain, then one of 48 or 24 (nkeys >= 2: at least one chunk runs)
     if (nkeys > 48) {
         KV16_CHUNK(9, true, 0);
@@ -688,8 +690,8 @@ __global__ __launch_bounds__(256) void attn_decode_kv16_wave_kernel(const float*
         if (out16) {
             u32x4 pk;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pk[i] = bf16_rne_bits(acc[2 * i]) | (bf16_rne_bits(acc[2 * i + 1]) << 16);
-            *reinterpret_cast<u32x4*>(out16 + o) = pk;  // feeds the bf16 attn_proj GEMM only
+            for (int i = 0; i < 4; ++i) pk[i] = to16<F16>(acc[2 * i]) | (to16<F16>(acc[2 * i + 1]) << 16);
+            *reinterpret_cast<u32x4*>(out16 + o) = pk;  // feeds the 16-bit attn_proj GEMM only
         } else {
             *reinterpret_cast<f32x4*>(out + o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
             *reinterpret_cast<f32x4*>(out + o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(256) void attn_decode_kv16_wave_kernel(const float*
 template <typename KV>  // float, or u16 (bf16 cache)
 __global__ __launch_bounds__(256) void kv_slot0_kernel(const float* __restrict__ ukv, int ld, KV* __restrict__ kv_all,
                                                        size_t layer_stride, size_t kv_stride, int S, int H, int T,
-                                                       int L, int row_mul) {
+                                                       int L, int row_mul, int f16) {
     const int D = H * 64;
     const size_t total = (size_t)L * 2 * S * D;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(256) void kv_slot0_kernel(const float* __restrict__
         const int hd = d >> 6, e = d & 63;
         const float val = ukv[(size_t)s * ld + ((size_t)l * 2 + kv) * D + d];
         const size_t o = (size_t)l * layer_stride + (size_t)kv * kv_stride + (((size_t)s * row_mul * H + hd) * T) * 64 + e;
-        if constexpr (sizeof(KV) == 2) kv_all[o] = (KV)bf16_rne_bits(val);
+        if constexpr (sizeof(KV) == 2) kv_all[o] = (KV)to16_rt(val, f16);
         else kv_all[o] = val;
     }
 }
@@ -1322,7 +1324,8 @@ struct Lin {
     float* packed = nullptr;   // skinny layout
     void* wb = nullptr;        // bf16 copy of w (opt-in many-sequence path)
     float* wT = nullptr;       // [K][Np] transposed copy, Np = N rounded up to 256 (backward pass: dX = dY W)
-    void* wTb = nullptr;       // bf16 copy of wT (training under autocast)
+    void* wTb = nullptr;       // 16-bit copy of wT (training under autocast)
+    int wb_f16 = 0, wTb_f16 = 0;   // the 16-bit type wb / wTb currently hold (0 bf16, 1 fp16)
     int N = 0, K = 0, NT = 0, KS = 1, ntile = 32;
     // fused decode plan (skinny_direct.inc): `packed` holds 16-column fragments, pre-scaled by the LayerNorm weight of
     // the LayerNorm this GEMM consumes when lnf is set; c1 / c2 are the folded vectors of that LayerNorm
@@ -1389,7 +1392,8 @@ struct rgrg_decoder {
     int* tr_count = nullptr;
     size_t tr_rows = 0, tr_seqs = 0;
     bool have_wT = false;
-    int bf16_gemms = 0;  // 1: bf16-weight MFMA GEMMs on the many-sequence path (not bit-exact; opt-in)
+    int bf16_gemms = 0;  // 1 (bf16) / 2 (fp16): 16-bit-weight MFMA GEMMs on the many-sequence path (not bit-exact; opt-in)
+    int f16() const { return bf16_gemms == 2 ? 1 : 0; }   // the 16-bit type of that mode
     unsigned short *xn16 = nullptr, *att16 = nullptr, *ff16 = nullptr;  // bf16 activations of that path (GEMM inputs)
     int gemm_launches_per_step = 0;
     void* a16_scratch = nullptr;   // bf16 copy of an fp32 GEMM input (teacher-forced / training passes under autocast)
@@ -1523,7 +1527,7 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
     }
     if (d->bf16_gemms && l.wb && l.K % 256 == 0) {
         if (count) d->gemm_bytes_per_step += (size_t)l.N * l.K * 2;
-        return launch_gemm_bf16w_ex(X16 ? nullptr : X, X16, l.wb, l.b, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream);
+        return launch_gemm_bf16w_ex(X16 ? nullptr : X, X16, l.wb, l.b, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream, d->f16());
     }
     if (count) d->gemm_bytes_per_step += (size_t)l.N * l.K * sizeof(float);
     return launch_gemm_dense(X, l.w, l.b, R, Y, M, l.N, l.K, ldy, act, d->gemm_ws, d->gemm_ws_floats, d->stream);
@@ -1545,12 +1549,11 @@ static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsig
             return RGRG_EINVAL;
         }
         const dim3 wgrid(S * d->H / 4), wblk(256);
-        if (src)
-            hipLaunchKernelGGL((attn_decode_kv16_wave_kernel<true>), wgrid, wblk, 0, st, d->qkv, 3 * D, kc16, kc16 + d->kv_kv_stride,
-                               d->step, d->att, S, d->H, d->T, src, att16);
-        else
-            hipLaunchKernelGGL((attn_decode_kv16_wave_kernel<false>), wgrid, wblk, 0, st, d->qkv, 3 * D, kc16, kc16 + d->kv_kv_stride,
-                               d->step, d->att, S, d->H, d->T, src, att16);
+#define KV16_LAUNCH(SRC_, F16_) hipLaunchKernelGGL((attn_decode_kv16_wave_kernel<SRC_, F16_>), wgrid, wblk, 0, st, d->qkv, 3 * D, kc16, \
+                                                  kc16 + d->kv_kv_stride, d->step, d->att, S, d->H, d->T, src, att16)
+        if (src) { if (d->f16()) KV16_LAUNCH(true, true); else KV16_LAUNCH(true, false); }
+        else { if (d->f16()) KV16_LAUNCH(false, true); else KV16_LAUNCH(false, false); }
+#undef KV16_LAUNCH
     } else {
         const dim3 grid(S * d->H), blk(256);
 #define ATT_LAUNCH(SRC_, NI_) hipLaunchKernelGGL((attn_decode_kernel<SRC_, NI_>), grid, blk, 0, st, d->qkv, 3 * D, kc, vc, d->step, d->att, S, d->H, d->T, src, frag_out)
@@ -1754,7 +1757,7 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
     unsigned short* att16 = xn16 ? d->att16 : nullptr;
     unsigned short* ff16 = xn16 ? d->ff16 : nullptr;
     hipLaunchKernelGGL(embed_ln_kernel, dim3(S), dim3(256), 0, st, d->wte, d->ids, d->max_len, d->step,
-                       d->layers[0].ln1_g, d->layers[0].ln1_b, d->x, d->xn, D, tok_override, xn16);
+                       d->layers[0].ln1_g, d->layers[0].ln1_b, d->x, d->xn, D, tok_override, xn16, d->f16());
     RGRG_LAUNCH_CHECK();
     for (int l = 0; l < d->n_layer; ++l) {
         const LayerW& w = d->layers[l];
@@ -1763,11 +1766,11 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
         if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, count, xn16))) return rc;
         if ((rc = launch_attention(d, l, S, src, att16))) return rc;
         if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count, att16))) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3((S + 3) / 4), dim3(256), 0, st, d->x, w.ln2_g, w.ln2_b, d->xn, D, xn16, S);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((S + 3) / 4), dim3(256), 0, st, d->x, w.ln2_g, w.ln2_b, d->xn, D, xn16, d->f16(), S);
         RGRG_LAUNCH_CHECK();
         if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, count, xn16, ff16))) return rc;
         if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->x, S, D, RGRG_ACT_NONE, count, ff16))) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3((S + 3) / 4), dim3(256), 0, st, d->x, ng, nb, d->xn, D, xn16, S);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((S + 3) / 4), dim3(256), 0, st, d->x, ng, nb, d->xn, D, xn16, d->f16(), S);
         RGRG_LAUNCH_CHECK();
     }
     if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, xn16))) return rc;
@@ -1798,10 +1801,10 @@ static int enqueue_prefill(rgrg_decoder* d, const float* feats, int S, int row_m
     // the bf16 cache lives in the same allocation with the same ELEMENT strides (half the bytes used)
     if (kv_is_bf16(d, S * row_mul))
         hipLaunchKernelGGL(kv_slot0_kernel<u16>, dim3(1024), dim3(256), 0, st, d->ukv_out, d->ld_ukv,
-                           reinterpret_cast<u16*>(d->kv), d->kv_layer_stride, d->kv_kv_stride, S, d->H, d->T, d->n_layer, row_mul);
+                           reinterpret_cast<u16*>(d->kv), d->kv_layer_stride, d->kv_kv_stride, S, d->H, d->T, d->n_layer, row_mul, d->f16());
     else
         hipLaunchKernelGGL(kv_slot0_kernel<float>, dim3(1024), dim3(256), 0, st, d->ukv_out, d->ld_ukv, d->kv,
-                           d->kv_layer_stride, d->kv_kv_stride, S, d->H, d->T, d->n_layer, row_mul);
+                           d->kv_layer_stride, d->kv_kv_stride, S, d->H, d->T, d->n_layer, row_mul, 0);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
@@ -2315,9 +2318,9 @@ static int bf16_linear_f32in(rgrg_decoder* d, const float* X, const void* Wb, co
         RGRG_HIP(hipMalloc(&d->a16_scratch, need));
         d->a16_bytes = need;
     }
-    int rc = convert_f32_to_bf16(X, d->a16_scratch, (size_t)M * K, d->stream);
+    int rc = convert_f32_to_bf16(X, d->a16_scratch, (size_t)M * K, d->stream, d->f16());
     if (rc) return rc;
-    return launch_gemm_bf16w_ex(nullptr, d->a16_scratch, Wb, b, R, Y, nullptr, M, N, K, ldy, act, d->stream);
+    return launch_gemm_bf16w_ex(nullptr, d->a16_scratch, Wb, b, R, Y, nullptr, M, N, K, ldy, act, d->stream, d->f16());
 }
 
 static int tf_linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R, float* Y, int M, int ldy, int act) {
@@ -2358,11 +2361,11 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
                                       DropoutParams{0ull, 0u, 0.f}, st)))
             return rc;
         if ((rc = tf_linear(d, w.attn_proj, d->tf_att, d->tf_x, d->tf_x, M, D, RGRG_ACT_NONE))) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, d->tf_x, w.ln2_g, w.ln2_b, d->tf_xn, D, (unsigned short*)nullptr, M);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, d->tf_x, w.ln2_g, w.ln2_b, d->tf_xn, D, (unsigned short*)nullptr, 0, M);
         RGRG_LAUNCH_CHECK();
         if ((rc = tf_linear(d, w.c_fc, d->tf_xn, nullptr, d->tf_ff, M, 4 * D, RGRG_ACT_GELU_NEW))) return rc;
         if ((rc = tf_linear(d, w.mlp_proj, d->tf_ff, d->tf_x, d->tf_x, M, D, RGRG_ACT_NONE))) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, d->tf_x, ng, nb, d->tf_xn, D, (unsigned short*)nullptr, M);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, d->tf_x, ng, nb, d->tf_xn, D, (unsigned short*)nullptr, 0, M);
         RGRG_LAUNCH_CHECK();
     }
     // lm_head (tied to wte, no bias) and the loss, over chunks of token rows
@@ -2415,15 +2418,16 @@ static int make_wT(rgrg_decoder* d, Lin& l) {
         if ((rc = dmalloc(d, (void**)&l.wT, (size_t)l.K * Np * sizeof(float), false))) return rc;
         if ((rc = launch_transpose_pad(l.w, l.wT, l.N, l.K, Np, d->stream))) return rc;
     }
-    if (d->bf16_gemms && !l.wTb) {
-        if ((rc = dmalloc(d, &l.wTb, (size_t)l.K * Np * 2, false))) return rc;
-        if ((rc = convert_f32_to_bf16(l.wT, l.wTb, (size_t)l.K * Np, d->stream))) return rc;
+    if (d->bf16_gemms && (!l.wTb || l.wTb_f16 != d->f16())) {   // (re)made in the current 16-bit type
+        if (!l.wTb && (rc = dmalloc(d, &l.wTb, (size_t)l.K * Np * 2, false))) return rc;
+        if ((rc = convert_f32_to_bf16(l.wT, l.wTb, (size_t)l.K * Np, d->stream, d->f16()))) return rc;
+        l.wTb_f16 = d->f16();
     }
     return RGRG_OK;
 }
 
 static int ensure_wT(rgrg_decoder* d) {
-    if (d->have_wT && (!d->bf16_gemms || d->layers[0].c_attn.wTb)) return RGRG_OK;
+    if (d->have_wT && (!d->bf16_gemms || (d->layers[0].c_attn.wTb && d->layers[0].c_attn.wTb_f16 == d->f16()))) return RGRG_OK;
     int rc;
     if ((rc = make_wT(d, d->lm_head)) || (rc = make_wT(d, d->ukv)) || (rc = make_wT(d, d->fst2))) return rc;
     for (auto& w : d->layers)
@@ -2524,7 +2528,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
     if (dropout_p > 0.f) {  // self.drop on the embeddings (language_model.py:311), then ln_1 of layer 0 again
         if ((rc = launch_dropout_add(xs(0), nullptr, xs(0), MD, DropoutParams{dropout_seed, 0u, dropout_p}, st))) return rc;
         hipLaunchKernelGGL(ln_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, xs(0), d->layers[0].ln1_g,
-                           d->layers[0].ln1_b, d->tf_xn, D, (unsigned short*)nullptr, M);
+                           d->layers[0].ln1_b, d->tf_xn, D, (unsigned short*)nullptr, 0, M);
         RGRG_LAUNCH_CHECK();
     }
     for (int l = 0; l < L; ++l) {
@@ -2543,7 +2547,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
             if ((rc = tr_lin(d, w.attn_proj, false, att, nullptr, d->tr_dbig, M, D))) return rc;
             if ((rc = launch_dropout_add(d->tr_dbig, xs(2 * l), xs(2 * l + 1), MD, dp_r1, st))) return rc;
         } else if ((rc = tr_lin(d, w.attn_proj, false, att, xs(2 * l), xs(2 * l + 1), M, D))) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, xs(2 * l + 1), w.ln2_g, w.ln2_b, d->tf_xn, D, (unsigned short*)nullptr, M);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, xs(2 * l + 1), w.ln2_g, w.ln2_b, d->tf_xn, D, (unsigned short*)nullptr, 0, M);
         RGRG_LAUNCH_CHECK();
         if ((rc = tr_lin(d, w.c_fc, false, d->tf_xn, nullptr, ffpre, M, 4 * D))) return rc;
         if ((rc = launch_gelu_apply(ffpre, d->tr_ff, (size_t)M * 4 * D, st))) return rc;
@@ -2551,7 +2555,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
             if ((rc = tr_lin(d, w.mlp_proj, false, d->tr_ff, nullptr, d->tr_dxn, M, D))) return rc;
             if ((rc = launch_dropout_add(d->tr_dxn, xs(2 * l + 1), xs(2 * l + 2), MD, dp_r2, st))) return rc;
         } else if ((rc = tr_lin(d, w.mlp_proj, false, d->tr_ff, xs(2 * l + 1), xs(2 * l + 2), M, D))) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, xs(2 * l + 2), ng, nb, d->tf_xn, D, (unsigned short*)nullptr, M);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, xs(2 * l + 2), ng, nb, d->tf_xn, D, (unsigned short*)nullptr, 0, M);
         RGRG_LAUNCH_CHECK();
     }
     // ---------------- lm_head + loss + d(logits) + d(ln_f output), chunk by chunk (the logits never exist as a whole)
@@ -2701,19 +2705,25 @@ extern "C" int rgrg_decoder_refresh_trainable(rgrg_decoder* d, void* stream) {
     return RGRG_OK;
 }
 
-extern "C" int rgrg_decoder_set_precision(rgrg_decoder* d, int bf16_gemms) {
-    RGRG_CHECK_ARG(d && (bf16_gemms == 0 || bf16_gemms == 1));
-    if (bf16_gemms == d->bf16_gemms) return RGRG_OK;
-    if (bf16_gemms) {
+extern "C" int rgrg_decoder_set_precision(rgrg_decoder* d, int mode) {
+    RGRG_CHECK_ARG(d && mode >= 0 && mode <= 2);
+    if (mode == d->bf16_gemms) return RGRG_OK;
+    const int prev = d->bf16_gemms;
+    d->bf16_gemms = mode;   // d->f16() below is the NEW type
+    if (mode) {
         int rc = init_gemm_bf16_attrs();
-        if (rc) return rc;
-        auto mk = [&](Lin& l) -> int {
-            if (l.wb) return RGRG_OK;
-            int r = dmalloc(d, &l.wb, (size_t)l.N * l.K * 2, false);
-            if (r) return r;
-            return convert_f32_to_bf16(l.w, l.wb, (size_t)l.N * l.K, d->stream);
+        if (rc) { d->bf16_gemms = prev; return rc; }
+        auto mk = [&](Lin& l) -> int {   // 16-bit copy of the weight in the requested type (re-converted when the type changes)
+            if (l.wb && l.wb_f16 == d->f16()) return RGRG_OK;
+            if (!l.wb) {
+                int r = dmalloc(d, &l.wb, (size_t)l.N * l.K * 2, false);
+                if (r) return r;
+            }
+            l.wb_f16 = d->f16();
+            return convert_f32_to_bf16(l.w, l.wb, (size_t)l.N * l.K, d->stream, d->f16());
         };
         int rc2;
+        RGRG_HIP(hipStreamSynchronize(d->stream));   // nothing queued still reads the copies that are about to be rewritten
         if (!d->xn16) {
             if ((rc2 = dmalloc(d, (void**)&d->xn16, (size_t)d->rows * d->D * 2, false)) ||
                 (rc2 = dmalloc(d, (void**)&d->att16, (size_t)d->rows * d->D * 2, false)) ||
@@ -2729,7 +2739,6 @@ extern "C" int rgrg_decoder_set_precision(rgrg_decoder* d, int bf16_gemms) {
     // captured graphs bake the GEMM choice in: drop them
     for (auto& g : d->graphs) (void)hipGraphExecDestroy(g.exec);
     d->graphs.clear();
-    d->bf16_gemms = bf16_gemms;
     return RGRG_OK;
 }
 

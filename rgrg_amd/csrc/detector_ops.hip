@@ -315,18 +315,13 @@ struct RoiTables {
     f32x4 y[16];
     f32x4 x[16];
 };
-__device__ __forceinline__ unsigned roi_bf16_rne(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
 constexpr int ROI_THREADS = 1024;  // 16 waves per CU hide the LDS latency of the 16-tap gathers
 constexpr int ROI_SUB = 32;        // RoIs per sub-chunk = 32-lane groups per workgroup: all processed concurrently
 
-// OUT16: the [roi][bin][channel] maps are stored as bf16 (round to nearest even) - under torch.autocast the box head
+// OUT16 (1 bf16, 2 fp16; 0 = fp32 maps): the [roi][bin][channel] maps are stored as 16-bit values (round to nearest even) - under torch.autocast the box head
 // runs in reduced precision, and fc6 (81 % of the detector's FLOPs) then reads its A operand through the LDS-DMA GEMM at
 // half the bytes; the 8x8 average (top_region_features) is still formed from the unrounded values.
-template <bool OUT16>
+template <int OUT16>
 __global__ __launch_bounds__(ROI_THREADS) void roi_align_avg_kernel(const float* __restrict__ feat,
                                                             const float* __restrict__ proposals,
                                                             const int* __restrict__ offsets, float* __restrict__ out,
@@ -416,8 +411,8 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_avg_kernel(const float*
                     for (int e = 0; e < 4; ++e) { acc[e] = acc[e] / 4.0f; psum[e] += acc[e]; }
                     if constexpr (OUT16) {
                         uint2 pk;
-                        pk.x = roi_bf16_rne(acc[0]) | (roi_bf16_rne(acc[1]) << 16);
-                        pk.y = roi_bf16_rne(acc[2]) | (roi_bf16_rne(acc[3]) << 16);
+                        pk.x = to16<OUT16 == 2>(acc[0]) | (to16<OUT16 == 2>(acc[1]) << 16);
+                        pk.y = to16<OUT16 == 2>(acc[2]) | (to16<OUT16 == 2>(acc[3]) << 16);
                         *reinterpret_cast<uint2*>(obase16 + (size_t)(ph * 8 + pw) * C) = pk;
                     } else {
                         *reinterpret_cast<f32x4*>(obase + (size_t)(ph * 8 + pw) * C) = acc;
@@ -712,7 +707,7 @@ extern "C" int rgrg_rpn_proposals_f32(const float* head_out, const float* anchor
     return RGRG_OK;
 }
 
-static int roi_align_launch(const float* feat, const float* proposals, const int32_t* offsets, void* out, bool out16,
+static int roi_align_launch(const float* feat, const float* proposals, const int32_t* offsets, void* out, int out16,
                             float* pooled, int B, int FH, int FW, int C, int max_props, int R_total,
                             float spatial_scale, void* stream) {
     RGRG_CHECK_ARG(feat && proposals && offsets && out && pooled && B > 0 && C % 128 == 0);
@@ -721,9 +716,11 @@ static int roi_align_launch(const float* feat, const float* proposals, const int
     if (R_total <= 0) return RGRG_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_avg_kernel<false>),
+        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_avg_kernel<0>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_avg_kernel<true>),
+        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_avg_kernel<1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_avg_kernel<2>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -731,12 +728,12 @@ static int roi_align_launch(const float* feat, const float* proposals, const int
     // chunks of <= 32 RoIs (one per 32-lane group); chunks beyond an image's RoI count exit immediately
     int nchunk = (max_props + ROI_SUB - 1) / ROI_SUB;
     if (nchunk < 1) nchunk = 1;
-    if (out16)
-        hipLaunchKernelGGL(roi_align_avg_kernel<true>, dim3(slabs, nchunk, B), dim3(ROI_THREADS), lds, as_stream(stream), feat, proposals,
-                           offsets, reinterpret_cast<float*>(out), pooled, FH, FW, C, max_props, spatial_scale);
-    else
-        hipLaunchKernelGGL(roi_align_avg_kernel<false>, dim3(slabs, nchunk, B), dim3(ROI_THREADS), lds, as_stream(stream), feat, proposals,
-                           offsets, reinterpret_cast<float*>(out), pooled, FH, FW, C, max_props, spatial_scale);
+#define ROI_LAUNCH(O_) hipLaunchKernelGGL(roi_align_avg_kernel<O_>, dim3(slabs, nchunk, B), dim3(ROI_THREADS), lds, as_stream(stream), feat, proposals, \
+                                          offsets, reinterpret_cast<float*>(out), pooled, FH, FW, C, max_props, spatial_scale)
+    if (out16 == 2) ROI_LAUNCH(2);
+    else if (out16 == 1) ROI_LAUNCH(1);
+    else ROI_LAUNCH(0);
+#undef ROI_LAUNCH
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
@@ -744,13 +741,13 @@ static int roi_align_launch(const float* feat, const float* proposals, const int
 extern "C" int rgrg_roi_align_avgpool_f32(const float* feat, const float* proposals, const int32_t* offsets, float* out,
                                           float* pooled, int B, int FH, int FW, int C, int max_props, int R_total,
                                           float spatial_scale, void* stream) {
-    return roi_align_launch(feat, proposals, offsets, out, false, pooled, B, FH, FW, C, max_props, R_total, spatial_scale, stream);
+    return roi_align_launch(feat, proposals, offsets, out, 0, pooled, B, FH, FW, C, max_props, R_total, spatial_scale, stream);
 }
 
 extern "C" int rgrg_roi_align_avgpool_bf16maps(const float* feat, const float* proposals, const int32_t* offsets, uint16_t* out16,
                                                float* pooled, int B, int FH, int FW, int C, int max_props, int R_total,
-                                               float spatial_scale, void* stream) {
-    return roi_align_launch(feat, proposals, offsets, out16, true, pooled, B, FH, FW, C, max_props, R_total, spatial_scale, stream);
+                                               float spatial_scale, int fp16, void* stream) {
+    return roi_align_launch(feat, proposals, offsets, out16, fp16 ? 2 : 1, pooled, B, FH, FW, C, max_props, R_total, spatial_scale, stream);
 }
 
 extern "C" int rgrg_top1_per_class_f32(const float* pred, int ldp, const float* proposals, const int32_t* offsets,

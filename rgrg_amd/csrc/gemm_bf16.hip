@@ -32,15 +32,17 @@ struct GemmBf16Params {
     // 128 ZERO ELEMENTS (the line padding taps read); row m = output pixel (b, oy, ox), K = KH * KW * Cin (tap major)
     int cH = 0, cW = 0, cCin = 0, cKH = 0, cKW = 0, cStride = 1, cPad = 0, cOH = 0, cOW = 0;
     const u16* R16 = nullptr;  // residual as bf16 [M, ldy] (CONV: the bottleneck's identity branch)
+    int f16 = 0;               // the 16-bit type of A16 / Wb / Y16 / R16: 0 = bf16, 1 = IEEE fp16 (common.h)
 };
 
 constexpr int BK16 = 64;                 // k per tile
 constexpr int LDB = (BK16 * 2 + 16) / 2;  // padded LDS row in bf16 elements (144 B)
 
-__device__ __forceinline__ u16 f32_to_bf16_rne(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (u16)(u >> 16);
+// one 32x32x16 matrix-core step on 16-bit fragments of either type (fp32 accumulate)
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // Workgroup = BM x BN output tile, THREADS/64 waves in a 2 x (WAVES/2) grid, each wave a (BM/2) x (BN/(WAVES/2))
@@ -49,7 +51,7 @@ __device__ __forceinline__ u16 f32_to_bf16_rne(float f) {
 // tile kt+NS are issued before tile kt is computed) and the LDS tiles are double buffered, one barrier per
 // K tile.  Workgroup ids are remapped so that the 1/8 of the grid an XCD receives (ids i mod 8) covers a
 // compact band of column tiles: its L2 then holds that band of W plus A.
-template <int BM, int BN, int THREADS, bool A16>
+template <int BM, int BN, int THREADS, bool A16, bool F16>
 __global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Params p, const int mtiles, const int ntiles) {
     constexpr int WAVES = THREADS / 64, WN = WAVES / 2;
     constexpr int TM = BM / 2, TN = BN / WN;    // wave sub-tile
@@ -115,8 +117,8 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Param
             } else {                                                                             \
                 bf16x4 lo, hi;                                                                   \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                  \
-                    lo[e] = (short)f32_to_bf16_rne(ra[S][i][0][e]);                              \
-                    hi[e] = (short)f32_to_bf16_rne(ra[S][i][1][e]);                              \
+                    lo[e] = (short)to16<F16>(ra[S][i][0][e]);                                    \
+                    hi[e] = (short)to16<F16>(ra[S][i][1][e]);                                    \
                 }                                                                                \
                 u16* dst = &As[((BUF) * BM + lrow + RSTEP * i) * LDB + kchunk * 4];              \
                 *reinterpret_cast<bf16x4*>(dst) = lo;                                            \
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Param
                 *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * LDB + ((KS) + 1) * 16);                      \
         }                                                                                                    \
         _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)  \
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(KS) & 1][mi], b[(KS) & 1][ni], acc[mi][ni], 0, 0, 0); \
+            acc[mi][ni] = mfma16<F16>(a[(KS) & 1][mi], b[(KS) & 1][ni], acc[mi][ni]);                        \
         RGRG_STORE_ITEM((s + 1) % NS, buf ^ 1, KS)                                                           \
     }
                 RGRG_KSTEP(0) RGRG_KSTEP(1) RGRG_KSTEP(2) RGRG_KSTEP(3)
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Param
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 const float v = apply_act(acc[mi][ni][r] + sh + rv[r], p.act);
                 if (row < p.M && col < p.N) {
-                    if (p.Y16) p.Y16[(size_t)row * p.ldy + col] = f32_to_bf16_rne(v);
+                    if (p.Y16) p.Y16[(size_t)row * p.ldy + col] = (u16)to16<F16>(v);
                     else p.Y[(size_t)row * p.ldy + col] = v;
                 }
             }
@@ -289,7 +291,7 @@ __device__ __forceinline__ void glds_issue(const u16* abase, const u16* wbase, u
 }
 
 // the MFMAs of one wave on one staged K tile (4 K steps of 16): sa / sw = the wave's first A / W row in the stage
-template <int MI, int NI>
+template <int MI, int NI, bool F16>
 __device__ __forceinline__ void glds_compute(const unsigned char* sa, const unsigned char* sw, const int (&foff)[4],
                                              f32x16 (&acc)[MI][NI]) {
     // two fragment register sets: the ds_reads of K step ks + 1 are issued before the MFMAs of step ks
@@ -310,7 +312,7 @@ __device__ __forceinline__ void glds_compute(const unsigned char* sa, const unsi
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][mi], b[ks & 1][ni], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = mfma16<F16>(a[ks & 1][mi], b[ks & 1][ni], acc[mi][ni]);
     }
     // pin that order (hipcc otherwise re-serialises read -> wait -> MFMA per K step on ONE register set):
     // reads(0) reads(1) | MFMA(0) reads(2) | MFMA(1) reads(3) | MFMA(2) | MFMA(3)       (0x100 = DS read, 0x008 = MFMA)
@@ -327,7 +329,7 @@ __device__ __forceinline__ void glds_compute(const unsigned char* sa, const unsi
 // (oy * stride + kh - pad, ox * stride + kw - pad): still one contiguous 128-byte line per row, so the LDS-DMA path is
 // unchanged; only the per-lane source offset is recomputed per K tile (tap = kt * 64 / Cin, a handful of integer
 // instructions), and taps outside the image read the zero line that precedes the tensor.
-template <int BM, int BN, int NST, bool CONV>
+template <int BM, int BN, int NST, bool CONV, bool F16>
 __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Params p, const int mtiles, const int ntiles) {
     constexpr int BK = 64;
     constexpr int MI = BM / 64, NI = BN / 64;   // 32x32 MFMA blocks per wave
@@ -387,9 +389,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
                 const bool in_ = (unsigned)iy_ < (unsigned)p.cH && (unsigned)ix_ < (unsigned)p.cW;                     \
                 va[j] = (in_ ? 256 + (cpix[j] + iy_ * p.cW + ix_) * p.cCin * 2 + c0_ * 2 : 0) + cswz[j];               \
             }                                                                                                          \
-            glds_issue<BM, LA, LB, NST * 2 + 1>(abase, wbase, glds_smem + (STAGE_) * STAGE + wave * 1024, va, vb, 0, (KT_) * (BK * 2)); \
+            glds_issue<BM, LA, LB, NST * 4 + 2 + (F16 ? 1 : 0)>(abase, wbase, glds_smem + (STAGE_) * STAGE + wave * 1024, va, vb, 0, (KT_) * (BK * 2)); \
         } else {                                                                                                       \
-            glds_issue<BM, LA, LB, NST * 2>(abase, wbase, glds_smem + (STAGE_) * STAGE + wave * 1024, va, vb, (KT_) * (BK * 2),       \
+            glds_issue<BM, LA, LB, NST * 4 + (F16 ? 1 : 0)>(abase, wbase, glds_smem + (STAGE_) * STAGE + wave * 1024, va, vb, (KT_) * (BK * 2),       \
                                             (KT_) * (BK * 2));                                                         \
         }                                                                                                              \
     }
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
     }
 
 #define RGRG_GLDS_COMPUTE(STAGE_)                                                                         \
-    glds_compute<MI, NI>(glds_smem + (STAGE_) * STAGE + wm * (BM / 2) * 128,                              \
+    glds_compute<MI, NI, F16>(glds_smem + (STAGE_) * STAGE + wm * (BM / 2) * 128,                         \
                          glds_smem + (STAGE_) * STAGE + BM * 128 + wn * (BN / 2) * 128, foff, acc)
 
     // prologue: K tiles 0 .. NST-2 in flight (the launcher guarantees nk >= NST - 1)
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
-                    rv[r] = __uint_as_float((unsigned)p.R16[(size_t)row * p.ldy + colc] << 16);
+                    rv[r] = from16<F16>(p.R16[(size_t)row * p.ldy + colc]);
                 }
             }
             if (col < p.N) {
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
                     const float v = apply_act_fast(acc[mi][ni][r] + sh + rv[r], p.act);
                     if (rbase + dr < p.M) {
                         const size_t o = (size_t)rbase * p.ldy + col + (size_t)(dr * p.ldy);
-                        if (p.Y16) p.Y16[o] = f32_to_bf16_rne(v);
+                        if (p.Y16) p.Y16[o] = (u16)to16<F16>(v);
                         else if (p.N > 8192) __builtin_nontemporal_store(v, &p.Y[o]);  // logits: streamed, keep A / W in L2
                         else p.Y[o] = v;
                     }
@@ -512,37 +514,45 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
         }
 }
 
-__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, size_t n) {
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, size_t n, int f16) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        dst[i] = f32_to_bf16_rne(src[i]);
+        dst[i] = (u16)to16_rt(src[i], f16);
 }
 
 template <int BM, int BN, int THREADS>
 static int launch_bf16_cfg(const GemmBf16Params& p, hipStream_t st) {
     constexpr size_t lds = (size_t)(2 * BM + 2 * BN) * LDB * sizeof(u16);
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
-    if (p.A16)
-        hipLaunchKernelGGL((gemm_bf16w_kernel<BM, BN, THREADS, true>), dim3(mtiles * ntiles), dim3(THREADS), lds, st, p, mtiles, ntiles);
-    else
-        hipLaunchKernelGGL((gemm_bf16w_kernel<BM, BN, THREADS, false>), dim3(mtiles * ntiles), dim3(THREADS), lds, st, p, mtiles, ntiles);
+#define RGRG_W_LAUNCH(A16_, F16_) hipLaunchKernelGGL((gemm_bf16w_kernel<BM, BN, THREADS, A16_, F16_>), dim3(mtiles * ntiles), dim3(THREADS), lds, st, p, mtiles, ntiles)
+    if (p.A16) { if (p.f16) RGRG_W_LAUNCH(true, true); else RGRG_W_LAUNCH(true, false); }
+    else { if (p.f16) RGRG_W_LAUNCH(false, true); else RGRG_W_LAUNCH(false, false); }
+#undef RGRG_W_LAUNCH
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
 
 template <int BM, int BN, int THREADS>
 static int bf16_attr() {
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<BM, BN, THREADS, false>),
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<BM, BN, THREADS, false, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<BM, BN, THREADS, true>),
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<BM, BN, THREADS, true, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<BM, BN, THREADS, false, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16w_kernel<BM, BN, THREADS, true, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
     return RGRG_OK;
 }
 
 template <int BM, int BN, int NST>
 static int glds_attr() {
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST, false>),
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST, false, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, NST * (BM + BN) * 128));
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST, true>),
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST, true, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, NST * (BM + BN) * 128));
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST, false, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, NST * (BM + BN) * 128));
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST, true, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, NST * (BM + BN) * 128));
     return RGRG_OK;
 }
@@ -566,12 +576,10 @@ int init_gemm_bf16_attrs() {
 template <int BM, int BN, int NST>
 static int launch_glds_cfg(const GemmBf16Params& p, hipStream_t st) {
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
-    if (p.cCin)
-        hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, NST, true>), dim3(mtiles * ntiles), dim3(256), NST * (BM + BN) * 128, st, p,
-                           mtiles, ntiles);
-    else
-        hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, NST, false>), dim3(mtiles * ntiles), dim3(256), NST * (BM + BN) * 128, st, p,
-                           mtiles, ntiles);
+#define RGRG_G_LAUNCH(CONV_, F16_) hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, NST, CONV_, F16_>), dim3(mtiles * ntiles), dim3(256), NST * (BM + BN) * 128, st, p, mtiles, ntiles)
+    if (p.cCin) { if (p.f16) RGRG_G_LAUNCH(true, true); else RGRG_G_LAUNCH(true, false); }
+    else { if (p.f16) RGRG_G_LAUNCH(false, true); else RGRG_G_LAUNCH(false, false); }
+#undef RGRG_G_LAUNCH
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
@@ -617,10 +625,11 @@ static int launch_glds(const GemmBf16Params& p, int tile, hipStream_t st) {
 
 // A16 / Y16 (either may be null): bf16 activations in / out, see GemmBf16Params
 int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const float* shift, const float* R, float* Y, void* Y16,
-                         int M, int N, int K, int ldy, int act, hipStream_t st) {
+                         int M, int N, int K, int ldy, int act, hipStream_t st, int f16) {
     RGRG_CHECK_ARG((A || A16) && Wb && (Y || Y16) && M > 0 && N > 0 && K > 0 && K % (4 * BK16) == 0 && ldy >= N);  // 4 = depth NS
     GemmBf16Params p{A, reinterpret_cast<const u16*>(A16), reinterpret_cast<const u16*>(Wb), shift, R, Y,
                      reinterpret_cast<u16*>(Y16), M, N, K, ldy, act};
+    p.f16 = f16 ? 1 : 0;
     if (A16 && (size_t)128 * K * 2 < ((size_t)1 << 31)) return launch_glds(p, 0, st);  // both operands bf16: LDS-DMA kernel
     // fp32 activations (rounded to bf16 while they are staged through registers)
     const long tiles_big = (long)((M + 127) / 128) * ((N + 127) / 128);
@@ -628,18 +637,18 @@ int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const 
 }
 
 int launch_gemm_bf16w(const float* A, const void* Wb, const float* shift, const float* R, float* Y, int M, int N, int K,
-                      int ldy, int act, hipStream_t st) {
-    return launch_gemm_bf16w_ex(A, nullptr, Wb, shift, R, Y, nullptr, M, N, K, ldy, act, st);
+                      int ldy, int act, hipStream_t st, int f16) {
+    return launch_gemm_bf16w_ex(A, nullptr, Wb, shift, R, Y, nullptr, M, N, K, ldy, act, st, f16);
 }
 
-__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const u16* __restrict__ src, float* __restrict__ dst, size_t n) {
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const u16* __restrict__ src, float* __restrict__ dst, size_t n, int f16) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        dst[i] = __uint_as_float((unsigned)src[i] << 16);
+        dst[i] = from16_rt(src[i], f16);
 }
 
-int convert_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st) {
+int convert_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st, int f16) {
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, st, src, reinterpret_cast<u16*>(dst), n);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, st, src, reinterpret_cast<u16*>(dst), n, f16 ? 1 : 0);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
@@ -648,41 +657,42 @@ int convert_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st) {
 
 using namespace rgrg;
 
-extern "C" int rgrg_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream) {
+extern "C" int rgrg_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, int fp16, void* stream) {
     RGRG_CHECK_ARG(src && dst && n > 0);
-    return convert_f32_to_bf16(src, dst, (size_t)n, as_stream(stream));
+    return convert_f32_to_bf16(src, dst, (size_t)n, as_stream(stream), fp16);
 }
 
-extern "C" int rgrg_bf16_to_f32(const uint16_t* src, float* dst, int64_t n, void* stream) {
+extern "C" int rgrg_bf16_to_f32(const uint16_t* src, float* dst, int64_t n, int fp16, void* stream) {
     RGRG_CHECK_ARG(src && dst && n > 0);
     const int blocks = (int)(((size_t)n + 255) / 256 < 4096 ? ((size_t)n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, (size_t)n);
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, (size_t)n, fp16 ? 1 : 0);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
 
 extern "C" int rgrg_linear_bf16w_f32(const float* A, const uint16_t* Wb, const float* shift, const float* R, float* Y,
-                                     int M, int N, int K, int ldy, int act, void* stream) {
+                                     int M, int N, int K, int ldy, int act, int fp16, void* stream) {
     int rc = init_gemm_bf16_attrs();
     if (rc) return rc;
-    return launch_gemm_bf16w(A, Wb, shift, R, Y, M, N, K, ldy, act, as_stream(stream));
+    return launch_gemm_bf16w(A, Wb, shift, R, Y, M, N, K, ldy, act, as_stream(stream), fp16);
 }
 
 extern "C" int rgrg_linear_bf16_f32(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
-                                    uint16_t* Y16, int M, int N, int K, int ldy, int act, void* stream) {
+                                    uint16_t* Y16, int M, int N, int K, int ldy, int act, int fp16, void* stream) {
     int rc = init_gemm_bf16_attrs();
     if (rc) return rc;
     RGRG_CHECK_ARG(A16 && ((Y != nullptr) != (Y16 != nullptr)));
-    return launch_gemm_bf16w_ex(nullptr, A16, Wb, shift, R, Y, Y16, M, N, K, ldy, act, as_stream(stream));
+    return launch_gemm_bf16w_ex(nullptr, A16, Wb, shift, R, Y, Y16, M, N, K, ldy, act, as_stream(stream), fp16);
 }
 
 extern "C" int rgrg_debug_linear_bf16_tile(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
-                                           int M, int N, int K, int ldy, int act, int tile, int lda, int ldw, void* stream) {
+                                           int M, int N, int K, int ldy, int act, int tile, int lda, int ldw, int fp16, void* stream) {
     int rc = init_gemm_bf16_attrs();
     if (rc) return rc;
     RGRG_CHECK_ARG(A16 && Wb && Y && M > 0 && N > 0 && K > 0 && K % 256 == 0 && ldy >= N && (size_t)128 * K * 2 < ((size_t)1 << 31));
     RGRG_CHECK_ARG((lda == 0 || lda >= K) && (ldw == 0 || ldw >= K));
     GemmBf16Params p{nullptr, A16, Wb, shift, R, Y, nullptr, M, N, K, ldy, act, lda, ldw};
+    p.f16 = fp16 ? 1 : 0;
     return launch_glds(p, tile, as_stream(stream));
 }
 
@@ -693,14 +703,14 @@ extern "C" int rgrg_debug_linear_bf16_tile(const uint16_t* A16, const uint16_t* 
 //   R16 [B,OH,OW,Cout] bf16 or NULL; exactly one of Y (f32) / Y16 (bf16) [B,OH,OW,Cout]
 extern "C" int rgrg_conv2d_nhwc_bf16(const uint16_t* X16, const uint16_t* Wb, const float* shift, const uint16_t* R16, float* Y,
                                      uint16_t* Y16, int B, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                     int act, void* stream) {
+                                     int act, int fp16, void* stream) {
     int rc = init_gemm_bf16_attrs();
     if (rc) return rc;
     RGRG_CHECK_ARG(X16 && Wb && ((Y != nullptr) != (Y16 != nullptr)) && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cin % 64 == 0);
     RGRG_CHECK_ARG(Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
     RGRG_CHECK_ARG((size_t)B * H * Wd * Cin * 2 + 256 < ((size_t)1 << 31));   // 32-bit byte offsets into the image
     GemmBf16Params p{};
-    p.A16 = X16; p.Wb = Wb; p.shift = shift; p.R16 = R16; p.Y = Y; p.Y16 = Y16;
+    p.A16 = X16; p.Wb = Wb; p.shift = shift; p.R16 = R16; p.Y = Y; p.Y16 = Y16; p.f16 = fp16 ? 1 : 0;
     p.cH = H; p.cW = Wd; p.cCin = Cin; p.cKH = KH; p.cKW = KW; p.cStride = stride; p.cPad = pad;
     p.cOH = (H + 2 * pad - KH) / stride + 1;
     p.cOW = (Wd + 2 * pad - KW) / stride + 1;

@@ -378,27 +378,30 @@ class HipEngine:
         buf[:128].zero_()
         return buf[128:].view(*shape)
 
-    def _conv16_weights(self, c: _Conv):
-        """[Cout][KH][KW][Cin] bf16 with the eval-BatchNorm scale folded in (alpha o W, then rounded once) + the f32 shift."""
-        if getattr(c, "w16", None) is None:
+    def _conv16_weights(self, c: _Conv, f16: int = 0):
+        """[Cout][KH][KW][Cin] as 16-bit values (f16 = 0: bf16, 1: fp16) with the eval-BatchNorm scale folded in (alpha o W,
+        then rounded once) + the f32 shift; one copy per type, made on first use."""
+        key = "w16_f16" if f16 else "w16"
+        if getattr(c, key, None) is None:
             w = c.w if c.scale is None else c.w * c.scale.view(-1, 1, 1, 1)
-            c.w16 = torch.empty(w.shape, dtype=torch.int16, device=w.device)
-            _hip.check(self.lib.rgrg_f32_to_bf16(_hip.ptr(w.contiguous()), _hip.ptr(c.w16), w.numel(), self._s()), "rgrg_f32_to_bf16")
-        return c.w16
+            w16 = torch.empty(w.shape, dtype=torch.int16, device=w.device)
+            _hip.check(self.lib.rgrg_f32_to_bf16(_hip.ptr(w.contiguous()), _hip.ptr(w16), w.numel(), f16, self._s()), "rgrg_f32_to_bf16")
+            setattr(c, key, w16)
+        return getattr(c, key)
 
-    def conv16(self, x16: Tensor, c: _Conv, act: int, residual16: Optional[Tensor] = None, out_f32: bool = False) -> Tensor:
-        """nn.Conv2d + eval BatchNorm2d + residual + ReLU on bf16 NHWC activations (rgrg_conv2d_nhwc_bf16)."""
+    def conv16(self, x16: Tensor, c: _Conv, act: int, residual16: Optional[Tensor] = None, out_f32: bool = False, f16: int = 0) -> Tensor:
+        """nn.Conv2d + eval BatchNorm2d + residual + ReLU on 16-bit (bf16 / fp16) NHWC activations (rgrg_conv2d_nhwc_bf16)."""
         B, H, W, Cin = x16.shape
         assert Cin == c.cin and Cin % 64 == 0
         OH = (H + 2 * c.pad - c.kh) // c.stride + 1
         OW = (W + 2 * c.pad - c.kw) // c.stride + 1
         y = torch.empty((B, OH, OW, c.cout), dtype=torch.float32, device=x16.device) if out_f32 else self._act16((B, OH, OW, c.cout))
-        _hip.check(self.lib.rgrg_conv2d_nhwc_bf16(_hip.ptr(x16), _hip.ptr(self._conv16_weights(c)), _hip.ptr(c.shift), _hip.ptr(residual16),
+        _hip.check(self.lib.rgrg_conv2d_nhwc_bf16(_hip.ptr(x16), _hip.ptr(self._conv16_weights(c, f16)), _hip.ptr(c.shift), _hip.ptr(residual16),
                                                   _hip.ptr(y) if out_f32 else None, None if out_f32 else _hip.ptr(y), B, H, W, Cin, c.cout,
-                                                  c.kh, c.kw, c.stride, c.pad, act, self._s()), "rgrg_conv2d_nhwc_bf16")
+                                                  c.kh, c.kw, c.stride, c.pad, act, f16, self._s()), "rgrg_conv2d_nhwc_bf16")
         return y
 
-    def backbone16(self, images: Tensor):
+    def backbone16(self, images: Tensor, f16: int = 0):
         """The trunk under autocast: stem + max-pool in fp32 (one input channel: 1 % of the FLOPs), the 16 bottlenecks as
         bf16 implicit GEMMs with fp32 accumulation, activations stored as bf16 -> (feat16 [B,16,16,2048] bf16,
         feat fp32 NHWC for RoIAlign / the caller)."""
@@ -411,24 +414,24 @@ class HipEngine:
         p = torch.empty((B, H // 4, W // 4, 64), dtype=torch.float32, device=x.device)
         _hip.check(self.lib.rgrg_maxpool3x3s2_nhwc_f32(_hip.ptr(y), _hip.ptr(p), B, H // 2, W // 2, 64, self._s()), "maxpool")
         x16 = self._act16(p.shape)
-        _hip.check(self.lib.rgrg_f32_to_bf16(_hip.ptr(p), _hip.ptr(x16), p.numel(), self._s()), "rgrg_f32_to_bf16")
+        _hip.check(self.lib.rgrg_f32_to_bf16(_hip.ptr(p), _hip.ptr(x16), p.numel(), f16, self._s()), "rgrg_f32_to_bf16")
         del y, p
         for blk in self.blocks:
-            o = self.conv16(x16, blk["c1"], _hip.ACT_RELU)
-            o = self.conv16(o, blk["c2"], _hip.ACT_RELU)
-            idt = self.conv16(x16, blk["ds"], _hip.ACT_NONE) if "ds" in blk else x16
-            x16 = self.conv16(o, blk["c3"], _hip.ACT_RELU, residual16=idt)
+            o = self.conv16(x16, blk["c1"], _hip.ACT_RELU, f16=f16)
+            o = self.conv16(o, blk["c2"], _hip.ACT_RELU, f16=f16)
+            idt = self.conv16(x16, blk["ds"], _hip.ACT_NONE, f16=f16) if "ds" in blk else x16
+            x16 = self.conv16(o, blk["c3"], _hip.ACT_RELU, residual16=idt, f16=f16)
         feat = torch.empty(x16.shape, dtype=torch.float32, device=x16.device)
-        _hip.check(self.lib.rgrg_bf16_to_f32(_hip.ptr(x16), _hip.ptr(feat), x16.numel(), self._s()), "rgrg_bf16_to_f32")
+        _hip.check(self.lib.rgrg_bf16_to_f32(_hip.ptr(x16), _hip.ptr(feat), x16.numel(), f16, self._s()), "rgrg_bf16_to_f32")
         return x16, feat
 
-    def rpn(self, feat: Tensor, return_head: bool = False, feat16: Optional[Tensor] = None):
+    def rpn(self, feat: Tensor, return_head: bool = False, feat16: Optional[Tensor] = None, f16: int = 0):
         """RPN head + proposal filtering -> proposals [B,1000,4], counts [B], offsets [B+1] (device)
         (+ the raw head output [B,FH,FW,800] = objectness | deltas when ``return_head``: the RPN losses read it)."""
         B, FH, FW, _ = feat.shape
         if feat16 is not None:  # autocast: the 3x3 conv (20 GFLOP / image) and the fused 1x1 heads on the bf16 matrix core
-            t = self.conv16(feat16, self.rpn_conv, _hip.ACT_RELU)
-            head = self.conv16(t, self.rpn_head, _hip.ACT_NONE, out_f32=True)
+            t = self.conv16(feat16, self.rpn_conv, _hip.ACT_RELU, f16=f16)
+            head = self.conv16(t, self.rpn_head, _hip.ACT_NONE, out_f32=True, f16=f16)
         else:
             t = self.conv(feat, self.rpn_conv, _hip.ACT_RELU)
             head = self.conv(t, self.rpn_head, _hip.ACT_NONE)  # [B,FH,FW,800]
@@ -444,15 +447,17 @@ class HipEngine:
             return props, counts, offsets, head
         return props, counts, offsets
 
-    def _fc6_bf16(self) -> Tensor:
-        """bf16 copy of the (K-permuted) fc6 weight, made on first use of the autocast path."""
-        if getattr(self, "fc6_wb", None) is None:
-            self.fc6_wb = torch.empty(self.fc6_w.shape, dtype=torch.int16, device=self.fc6_w.device)
-            _hip.check(self.lib.rgrg_f32_to_bf16(_hip.ptr(self.fc6_w), _hip.ptr(self.fc6_wb), self.fc6_w.numel(), self._s()),
+    def _fc6_bf16(self, f16: int = 0) -> Tensor:
+        """16-bit copy (bf16 / fp16) of the (K-permuted) fc6 weight, made on first use of the autocast path."""
+        key = "fc6_wb_f16" if f16 else "fc6_wb"
+        if getattr(self, key, None) is None:
+            wb = torch.empty(self.fc6_w.shape, dtype=torch.int16, device=self.fc6_w.device)
+            _hip.check(self.lib.rgrg_f32_to_bf16(_hip.ptr(self.fc6_w), _hip.ptr(wb), self.fc6_w.numel(), f16, self._s()),
                        "rgrg_f32_to_bf16")
-        return self.fc6_wb
+            setattr(self, key, wb)
+        return getattr(self, key)
 
-    def roi_heads(self, feat: Tensor, props: Tensor, offsets: Tensor, taps: Optional[dict] = None, bf16: bool = False):
+    def roi_heads(self, feat: Tensor, props: Tensor, offsets: Tensor, taps: Optional[dict] = None, bf16=False):
         B, FH, FW, Cf = feat.shape
         R = int(offsets[-1].item())  # host sync #1: number of RoIs sizes the box-head launches
         dev = feat.device
@@ -461,7 +466,8 @@ class HipEngine:
         boxes = torch.zeros((B, NUM_REGIONS, 4), dtype=torch.float32, device=dev)
         feats = torch.zeros((B, NUM_REGIONS, Cf), dtype=torch.float32, device=dev)
         if R > 0:
-            low = bf16 and R > 128
+            low = bool(bf16) and R > 128
+            f16 = 1 if int(bf16) == 2 else 0
             pooled = torch.empty((R, Cf), dtype=torch.float32, device=dev)
             scale = 2.0 ** round(__import__("math").log2(FH / IMAGE_INPUT_SIZE))
             if low:
@@ -471,11 +477,11 @@ class HipEngine:
                 pooled_maps = torch.empty((R, 64, Cf), dtype=torch.int16, device=dev)
                 _hip.check(self.lib.rgrg_roi_align_avgpool_bf16maps(_hip.ptr(feat), _hip.ptr(props), _hip.ptr(offsets),
                                                                     _hip.ptr(pooled_maps), _hip.ptr(pooled), B, FH, FW, Cf,
-                                                                    props.shape[1], R, scale, self._s()), "rgrg_roi_align")
+                                                                    props.shape[1], R, scale, f16, self._s()), "rgrg_roi_align")
                 h = torch.empty((R, self.fc6_w.shape[0]), dtype=torch.float32, device=dev)
-                _hip.check(self.lib.rgrg_linear_bf16_f32(_hip.ptr(pooled_maps), _hip.ptr(self._fc6_bf16()), _hip.ptr(self.fc6_b), None,
+                _hip.check(self.lib.rgrg_linear_bf16_f32(_hip.ptr(pooled_maps), _hip.ptr(self._fc6_bf16(f16)), _hip.ptr(self.fc6_b), None,
                                                          _hip.ptr(h), None, R, self.fc6_w.shape[0], 64 * Cf, self.fc6_w.shape[0],
-                                                         _hip.ACT_RELU, self._s()), "rgrg_linear_bf16_f32")
+                                                         _hip.ACT_RELU, f16, self._s()), "rgrg_linear_bf16_f32")
             else:
                 pooled_maps = torch.empty((R, 64, Cf), dtype=torch.float32, device=dev)
                 _hip.check(self.lib.rgrg_roi_align_avgpool_f32(_hip.ptr(feat), _hip.ptr(props), _hip.ptr(offsets),
@@ -515,21 +521,23 @@ class HipEngine:
                                                        _hip.ptr(pooled), B, FH, FW, Cf, maxn, R, scale, self._s()), "rgrg_roi_align")
         return maps, pooled
 
-    def detect(self, images: Tensor, taps: Optional[dict] = None, bf16: bool = False, targets=None, keys_fn=None):
+    def detect(self, images: Tensor, taps: Optional[dict] = None, bf16=False, targets=None, keys_fn=None):
         """ObjectDetector.forward in eval mode: -> (detections, top_region_features, class_detected) or, with
         ``targets`` (list of {"boxes" [n,4], "labels" [n]} per image), (losses, detections, top_region_features,
         class_detected) where - as in the reference - the RoI heads then run on the SAMPLED training proposals.
-        bf16 (opt-in through torch.autocast, like the reference's scripts): bottlenecks, RPN convs and fc6 on the bf16 matrix core
-        with fp32 accumulation, RoIAlign maps stored as bf16; stem, proposals / NMS, fc7, predictor, post-processing stay fp32."""
+        bf16 (opt-in through torch.autocast, like the reference's scripts; a mode: False / 0 fp32, True / 1 bfloat16, 2 float16 =
+        _hip.autocast_mode()): bottlenecks, RPN convs and fc6 on the 16-bit matrix core of that type with fp32 accumulation, RoIAlign
+        maps stored in it; stem, proposals / NMS, fc7, predictor, post-processing stay fp32."""
         _require_gpu(images.device)
         images = images.to(torch.float32)
         feat16 = None
+        f16 = 1 if int(bf16) == 2 else 0
         if bf16:
-            feat16, feat = self.backbone16(images)
+            feat16, feat = self.backbone16(images, f16)
         else:
             feat = self.backbone(images)
         if targets is None:
-            props, counts, offsets = self.rpn(feat, feat16=feat16)
+            props, counts, offsets = self.rpn(feat, feat16=feat16, f16=f16)
             cd, scores, boxes, top = self.roi_heads(feat, props, offsets, taps, bf16)
             if taps is not None:
                 taps.update(features_nhwc=feat, proposals=props, counts=counts, offsets=offsets)
@@ -538,7 +546,7 @@ class HipEngine:
         # SMALLEST keys are taken, lower index first on ties - a uniformly random subset for i.i.d. keys, like
         # torchvision's positive[randperm(|positive|)[:k]].  Default: torch.rand on the device.
         keys_fn = keys_fn or (lambda stage, B, n: torch.rand((B, n), dtype=torch.float32, device=images.device))
-        props, counts, offsets, head = self.rpn(feat, return_head=True, feat16=feat16)
+        props, counts, offsets, head = self.rpn(feat, return_head=True, feat16=feat16, f16=f16)
         gt, gt_count, gt_labels = self._pad_targets(targets, images.device)
         loss_obj, loss_rpn_box = self._rpn_losses(head, gt, gt_count, keys_fn)
         props_s, offsets_s, labels_s, reg_s = self._select_training_samples(props, counts, gt, gt_count, gt_labels, keys_fn)
@@ -729,15 +737,16 @@ class HipEngine:
             self._decoder, self._decoder_caps, self._kv = h, (cap_s, cap_l), kv
         return self._decoder
 
-    def greedy_decode(self, feats: Tensor, max_length: Optional[int], use_graph: bool = True, bf16: bool = False) -> Tensor:
-        """LanguageModel.generate(num_beams=1): feats [S,1024] -> int64 [S, L'].  bf16=True (opt-in through
-        torch.autocast) lets the > 128-sequence path use bf16-weight MFMA GEMMs (not bit-exact)."""
+    def greedy_decode(self, feats: Tensor, max_length: Optional[int], use_graph: bool = True, bf16=False) -> Tensor:
+        """LanguageModel.generate(num_beams=1): feats [S,1024] -> int64 [S, L'].  bf16 = precision mode (opt-in through
+        torch.autocast: False / 0 fp32, True / 1 bfloat16, 2 float16): lets the > 128-sequence path use 16-bit-weight MFMA GEMMs
+        and a 16-bit K/V cache of that type (not bit-exact)."""
         _require_gpu(feats.device)
         S = feats.shape[0]
         limit = int(max_length) if max_length else 1024  # reference has no bound when None; positions stop at 1024
         dec = self._get_decoder(S, limit)
         self._cached = None   # the K/V cache and the step counter are rewritten: presents of an earlier forward(use_cache=True) are stale
-        _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")
+        _hip.check(self.lib.rgrg_decoder_set_precision(dec, int(bf16)), "rgrg_decoder_set_precision")
         feats = feats.to(torch.float32).contiguous()
         out = torch.empty((S, limit), dtype=torch.int64, device=feats.device)
         out_len = C.c_int(0)
@@ -747,14 +756,14 @@ class HipEngine:
         return out[:, :out_len.value].contiguous()
 
     def beam_search(self, feats: Tensor, max_length: int, num_beams: int, early_stopping: bool = False,
-                    length_penalty: float = 1.0, bf16: bool = False, num_return_sequences: int = 1) -> Tensor:
+                    length_penalty: float = 1.0, bf16=False, num_return_sequences: int = 1) -> Tensor:
         """LanguageModel.generate(num_beams>1): feats [S,1024] -> int64 [S * num_return_sequences, L]."""
         _require_gpu(feats.device)
         S = feats.shape[0]
         limit = int(max_length)
         dec = self._get_decoder(S * num_beams, limit)
         self._cached = None   # as in greedy_decode
-        _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")
+        _hip.check(self.lib.rgrg_decoder_set_precision(dec, int(bf16)), "rgrg_decoder_set_precision")
         feats = feats.to(torch.float32).contiguous()
         out = torch.empty((S * int(num_return_sequences), limit), dtype=torch.int64, device=feats.device)
         out_len = C.c_int(0)
@@ -784,7 +793,7 @@ class HipEngine:
             raise
 
     def lm_forward(self, feats: Tensor, input_ids: Tensor, attention_mask: Optional[Tensor], want_logits: bool = False,
-                   want_loss: bool = True, bf16: bool = False) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+                   want_loss: bool = True, bf16=False) -> Tuple[Optional[Tensor], Optional[Tensor]]:
         """LanguageModel.forward without cache (teacher forcing): feats [S,1024], input_ids int64 [S,T],
         attention_mask [S,T] -> (logits f32 [S,T,V] or None, loss f32 scalar tensor or None)."""
         _require_gpu(feats.device)
@@ -796,7 +805,7 @@ class HipEngine:
         # token ids are range-checked on the device (no host sync here): see embed_seq_ln_kernel
         dec = self._get_decoder(S, 2)
         self._raise_pending_id_error()
-        _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")
+        _hip.check(self.lib.rgrg_decoder_set_precision(dec, int(bf16)), "rgrg_decoder_set_precision")
         feats = feats.to(torch.float32).contiguous()
         ids = input_ids.to(torch.int64).contiguous()
         am = None if attention_mask is None else attention_mask.to(torch.float32).contiguous()
@@ -809,7 +818,7 @@ class HipEngine:
         return logits, loss
 
     def lm_loss_grad(self, feats: Tensor, input_ids: Tensor, attention_mask: Optional[Tensor], loss_scale: float = 1.0,
-                     bf16: bool = False, dropout_p: float = 0.0, dropout_seed: int = 0):
+                     bf16=False, dropout_p: float = 0.0, dropout_seed: int = 0):
         """Teacher-forced loss and its gradients w.r.t. the trainable decoder weights (rgrg_decoder_lm_loss_grad):
         -> (loss, {"ukv_w" [L*2*1024,1024], "ukv_b", "fst0_w", "fst0_b", "fst2_w", "fst2_b"}).  bf16=True (torch.autocast,
         as the reference's training loop uses): the frozen-weight GEMMs of forward and backward run on the bf16 MFMA
@@ -823,7 +832,7 @@ class HipEngine:
         # token ids are range-checked on the device (no host sync here): see embed_seq_ln_kernel
         dec = self._get_decoder(S, 2)
         self._raise_pending_id_error()
-        _hip.check(self.lib.rgrg_decoder_set_precision(dec, 1 if bf16 else 0), "rgrg_decoder_set_precision")
+        _hip.check(self.lib.rgrg_decoder_set_precision(dec, int(bf16)), "rgrg_decoder_set_precision")
         feats = feats.detach().to(torch.float32).contiguous()
         ids = input_ids.to(torch.int64).contiguous()
         am = None if attention_mask is None else attention_mask.to(torch.float32).contiguous()

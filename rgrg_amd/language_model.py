@@ -13,6 +13,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from . import _hip
 from ._owner import EngineOwner
 from .constants import BOS_TOKEN_ID, EOS_TOKEN_ID, PAD_TOKEN_ID
 
@@ -83,9 +84,9 @@ class _TeacherForcedLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, lm, input_ids, attention_mask, feats, *params):
-        low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
+        low = _hip.autocast_mode()
         lm.dropout_seed += 1  # a fresh counter-based stream per pass
-        loss, g = lm.engine().lm_loss_grad(feats, input_ids, attention_mask, bf16=bool(low), dropout_p=float(lm.dropout_p),
+        loss, g = lm.engine().lm_loss_grad(feats, input_ids, attention_mask, bf16=low, dropout_p=float(lm.dropout_p),
                                            dropout_seed=lm.pass_dropout_seed())
         D, grads = 1024, []
         for l in range(len(lm.gpt.h)):  # same order as LanguageModel.trainable_parameters()
@@ -155,8 +156,8 @@ class LanguageModel(EngineOwner):
             loss = _TeacherForcedLoss.apply(self, ids2, am2, image_hidden_states, *self.trainable_parameters())
         else:
             self.sync_trainable_if_stale()
-            low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
-            _, loss = self.engine().lm_forward(image_hidden_states, ids2, am2, want_logits=False, want_loss=True, bf16=bool(low))
+            low = _hip.autocast_mode()
+            _, loss = self.engine().lm_forward(image_hidden_states, ids2, am2, want_logits=False, want_loss=True, bf16=low)
         ids2[~am2.to(torch.bool)] = -100  # the reference's in-place label write (labels IS input_ids)
         return loss
 
@@ -249,8 +250,8 @@ class LanguageModel(EngineOwner):
                 raise ValueError(f"num_return_sequences has to be 1, but is {num_return_sequences} when doing greedy search.")
             # like the reference's scripts, callers may wrap generate() in torch.autocast: a reduced-precision
             # autocast dtype opts the many-sequence decode GEMMs into the bf16 MFMA path
-            low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
-            return self.engine().greedy_decode(image_hidden_states, max_length, bf16=bool(low))
+            low = _hip.autocast_mode()
+            return self.engine().greedy_decode(image_hidden_states, max_length, bf16=low)
         if num_beams > 1 and single_group:
             if do_sample is True:
                 raise NotImplementedError("Beam-search multinomial sampling is not implemented.")
@@ -261,7 +262,7 @@ class LanguageModel(EngineOwner):
             if num_beams > 16:
                 raise NotImplementedError("the HIP beam search supports num_beams <= 16")
             # length_penalty = 1.0 as in the reference (language_model.py:461)
-            low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
-            return self.engine().beam_search(image_hidden_states, max_length, num_beams, early_stopping, 1.0, bf16=bool(low),
+            low = _hip.autocast_mode()
+            return self.engine().beam_search(image_hidden_states, max_length, num_beams, early_stopping, 1.0, bf16=low,
                                              num_return_sequences=num_return_sequences)
         raise NotImplementedError("Diverse beam-search decoding is not implemented.")

@@ -17,6 +17,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from .constants import RESNET50_LAYERS
+from . import _hip
 from ._owner import EngineOwner
 
 
@@ -223,14 +224,14 @@ class ObjectDetector(EngineOwner):
         if self.training:
             raise NotImplementedError("rgrg_amd runs the detector in eval mode (BatchNorm running statistics, test-time "
                                       "proposal counts); training the detector is not implemented")
-        low = images.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
+        low = _hip.autocast_mode() if images.is_cuda else 0
         losses: Dict[str, Tensor] = {}
         if targets is not None:
             self._check_targets(targets)
             losses, detections, top_region_features, class_detected = self.engine().detect(
-                images, bf16=bool(low), targets=targets, keys_fn=getattr(self, "sampler_keys", None))
+                images, bf16=low, targets=targets, keys_fn=getattr(self, "sampler_keys", None))
         else:
-            detections, top_region_features, class_detected = self.engine().detect(images, bf16=bool(low))
+            detections, top_region_features, class_detected = self.engine().detect(images, bf16=low)
         if not self.return_feature_vectors:
             return losses, detections, class_detected
         return losses, detections, top_region_features, class_detected

@@ -11,6 +11,7 @@ from typing import Dict, Optional
 import torch
 from torch import Tensor
 
+from . import _hip
 from ._owner import EngineOwner
 from .binary_classifier import BinaryClassifierRegionAbnormal, BinaryClassifierRegionSelection
 from .language_model import LanguageModel
@@ -134,9 +135,9 @@ class ReportGenerationModel(EngineOwner):
         not used and ``obj_detector_loss_dict`` is ``{}``.  Returns ``(obj_detector_loss_dict,
         classifier_loss_region_selection, classifier_loss_region_abnormal[, language_model_loss])`` - losses with a
         ``grad_fn`` for the classifiers and for uk/uv/feature_space_transformation_nn - or ``-1`` (:136)."""
-        low = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
+        low = _hip.autocast_mode()
         with torch.no_grad():
-            _detections, top_region_features, class_detected = self.engine().detect(images, bf16=bool(low))
+            _detections, top_region_features, class_detected = self.engine().detect(images, bf16=low)
         del images
         classifier_loss_region_selection = self.binary_classifier_region_selection(
             top_region_features, class_detected, return_loss=True, region_has_sentence=region_has_sentence)

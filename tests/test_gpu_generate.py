@@ -674,7 +674,7 @@ def test_detector_under_autocast_close_to_fp32():
     # RPN on the same (fp32) feature map: fp32 convs vs bf16 convs
     feat32 = t32["features_nhwc"]
     feat16 = eng._act16(tuple(feat32.shape))
-    _hip.check(eng.lib.rgrg_f32_to_bf16(feat32.data_ptr(), feat16.data_ptr(), feat32.numel(), torch.cuda.current_stream().cuda_stream))
+    _hip.check(eng.lib.rgrg_f32_to_bf16(feat32.data_ptr(), feat16.data_ptr(), feat32.numel(), 0, torch.cuda.current_stream().cuda_stream))
     *_, head32 = eng.rpn(feat32, return_head=True)
     *_, head16 = eng.rpn(feat32, return_head=True, feat16=feat16)
     hspan = head32.abs().max().item()

@@ -343,44 +343,56 @@ def test_detector_end_to_end_vs_oracle(eng, oracle_bench):
 
 
 # ------------------------------------------------------------------------- bf16-weight GEMM (opt-in path)
-def test_f32_to_bf16_is_round_to_nearest_even(eng):
+T16 = {0: torch.bfloat16, 1: torch.float16}   # the `fp16` argument of the 16-bit entry points -> torch dtype
+
+
+@pytest.mark.parametrize("fp16", [0, 1])
+def test_f32_to_bf16_is_round_to_nearest_even(eng, fp16):
+    """fp32 -> bf16 / fp16 bits exactly as torch rounds (nearest even; fp16: subnormals, overflow to inf beyond 65504),
+    and the widening back is exact."""
     g = torch.Generator().manual_seed(17)
     x = torch.randn((4099,), generator=g) * 37.0
-    x[:4] = torch.tensor([1.0 + 2 ** -8, 1.0 + 3 * 2 ** -8, -0.0, 65504.0])  # exact ties -> even mantissa
+    x[:8] = torch.tensor([1.0 + 2 ** -8, 1.0 + 3 * 2 ** -8, -0.0, 65504.0, 65520.0, 1e-7, -3e-6, 1.0 + 2 ** -11])  # exact ties, edges
     xd = x.to(DEV)
     out = torch.empty((4099,), dtype=torch.int16, device=DEV)
-    _hip.check(eng.lib.rgrg_f32_to_bf16(xd.data_ptr(), out.data_ptr(), 4099, _stream()))
-    assert torch.equal(out.cpu(), x.bfloat16().view(torch.int16))
+    _hip.check(eng.lib.rgrg_f32_to_bf16(xd.data_ptr(), out.data_ptr(), 4099, fp16, _stream()))
+    assert torch.equal(out.cpu(), x.to(T16[fp16]).view(torch.int16))
+    back = torch.empty((4099,), dtype=torch.float32, device=DEV)
+    _hip.check(eng.lib.rgrg_bf16_to_f32(out.data_ptr(), back.data_ptr(), 4099, fp16, _stream()))
+    assert torch.equal(back.cpu(), x.to(T16[fp16]).float())
 
 
+@pytest.mark.parametrize("fp16", [0, 1])
 @pytest.mark.parametrize("M,N,K,act,res", [(300, 512, 1024, 0, True), (928, 1024, 4096, 2, False), (129, 50257, 1024, 0, False)])
-def test_linear_bf16w(eng, M, N, K, act, res):
-    """bf16 MFMA path (v_mfma_f32_32x32x16_bf16): products of bf16-rounded operands are exact in fp32, so the only
+def test_linear_bf16w(eng, M, N, K, act, res, fp16):
+    """16-bit MFMA path (v_mfma_f32_32x32x16_bf16 / _f16): products of rounded operands are exact in fp32, so the only
     difference to a float64 reference on the SAME rounded operands is the fp32 summation order."""
+    t16 = T16[fp16]
     g = torch.Generator().manual_seed(M + N)
     A = torch.randn((M, K), generator=g)
     W = torch.randn((N, K), generator=g) / math.sqrt(K)
     b = torch.randn((N,), generator=g)
     R = torch.randn((M, N), generator=g) if res else None
-    ref = A.bfloat16().double() @ W.bfloat16().double().t() + b.double()
+    ref = A.to(t16).double() @ W.to(t16).double().t() + b.double()
     if res:
         ref = ref + R.double()
     ref = {0: lambda x: x, 2: lambda x: F.gelu(x, approximate="tanh")}[act](ref)
     Ad, Wd, bd = A.to(DEV), W.to(DEV), b.to(DEV)
     Rd = R.to(DEV) if res else None
     Wb = torch.empty((N, K), dtype=torch.int16, device=DEV)
-    _hip.check(eng.lib.rgrg_f32_to_bf16(Wd.data_ptr(), Wb.data_ptr(), N * K, _stream()))
+    _hip.check(eng.lib.rgrg_f32_to_bf16(Wd.data_ptr(), Wb.data_ptr(), N * K, fp16, _stream()))
     y = torch.empty((M, N), device=DEV)
     _hip.check(eng.lib.rgrg_linear_bf16w_f32(Ad.data_ptr(), Wb.data_ptr(), bd.data_ptr(), Rd.data_ptr() if res else None,
-                                             y.data_ptr(), M, N, K, N, act, _stream()))
-    close(y, ref, 2e-5, 2e-6, f"bf16w linear {M}x{N}x{K}")
+                                             y.data_ptr(), M, N, K, N, act, fp16, _stream()))
+    close(y, ref, 2e-5, 2e-6, f"16-bit-weight linear {M}x{N}x{K} ({t16})")
 
 
 @pytest.mark.parametrize("M,N,K,act,res,out16", [(923, 3072, 1024, 0, False, False), (923, 1024, 4096, 0, True, False),
                                                    (923, 4096, 1024, 2, False, True), (129, 50257, 1024, 0, False, False),
                                                    (70, 192, 256, 0, True, False), (300, 1000, 768, 2, False, False),
                                                    (1, 64, 256, 0, False, False)])
-def test_linear_bf16_lds_dma_kernel(eng, M, N, K, act, res, out16):
+@pytest.mark.parametrize("fp16", [0, 1])
+def test_linear_bf16_lds_dma_kernel(eng, M, N, K, act, res, out16, fp16):
     """Round-3 LDS-DMA GEMM (both operands bf16 in HBM, `buffer_load ... lds`, 4 stages across raw barriers, XOR-swizzled
     LDS rows): against a float64 reference on the same bf16 operands.  Shapes: the four decode projections at the
     configs[2] row count (923: ragged last row tile; 128x128 and 64x64 tile paths), the vocabulary edge (50257 columns:
@@ -390,29 +402,30 @@ def test_linear_bf16_lds_dma_kernel(eng, M, N, K, act, res, out16):
     W = torch.randn((N, K), generator=g) / math.sqrt(K)
     b = torch.randn((N,), generator=g)
     R = torch.randn((M, N), generator=g) if res else None
-    ref = A.bfloat16().double() @ W.bfloat16().double().t() + b.double()
+    t16 = T16[fp16]
+    ref = A.to(t16).double() @ W.to(t16).double().t() + b.double()
     if res:
         ref = ref + R.double()
     ref = {0: lambda x: x, 2: lambda x: F.gelu(x, approximate="tanh")}[act](ref)
-    A16 = A.bfloat16().view(torch.int16).to(DEV)
-    Wb = W.bfloat16().view(torch.int16).to(DEV)
+    A16 = A.to(t16).view(torch.int16).to(DEV)
+    Wb = W.to(t16).view(torch.int16).to(DEV)
     bd = b.to(DEV)
     Rd = R.to(DEV) if res else None
     y = torch.empty((M, N), device=DEV)
     y16 = torch.empty((M, N), dtype=torch.int16, device=DEV)
     _hip.check(eng.lib.rgrg_linear_bf16_f32(A16.data_ptr(), Wb.data_ptr(), bd.data_ptr(), Rd.data_ptr() if res else None,
                                             None if out16 else y.data_ptr(), y16.data_ptr() if out16 else None, M, N, K, N, act,
-                                            _stream()))
+                                            fp16, _stream()))
     if out16:
-        assert torch.equal(y16.cpu().view(torch.bfloat16), ref.float().bfloat16()) or \
-            (y16.cpu().view(torch.bfloat16).double() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+        assert torch.equal(y16.cpu().view(t16), ref.float().to(t16)) or \
+            (y16.cpu().view(t16).double() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
     else:
-        close(y, ref, 2e-5, 2e-6, f"bf16 LDS-DMA linear {M}x{N}x{K}")
+        close(y, ref, 2e-5, 2e-6, f"16-bit LDS-DMA linear {M}x{N}x{K} ({t16})")
     tol = (2e-5, 2e-6) if act == 0 else (2e-5, 4e-6)  # GELU on the hardware exp2 / rcp (~1e-7 relative to tanhf)
     for tile in [shape + 16 * nst for shape in (1, 2, 3, 4) for nst in (2, 3, 4)]:   # every tile shape x stage count
         y2 = torch.empty((M, N), device=DEV)
         _hip.check(eng.lib.rgrg_debug_linear_bf16_tile(A16.data_ptr(), Wb.data_ptr(), bd.data_ptr(), Rd.data_ptr() if res else None,
-                                                       y2.data_ptr(), M, N, K, N, act, tile, 0, 0, _stream()))
+                                                       y2.data_ptr(), M, N, K, N, act, tile, 0, 0, fp16, _stream()))
         close(y2, ref, tol[0], tol[1], f"bf16 LDS-DMA linear {M}x{N}x{K} tile {tile}")
 
 

@@ -203,6 +203,26 @@ def test_bf16_oracle_is_within_quantisation_noise_of_the_reference_under_autocas
     assert abs(fx["meta"]["oracle16_vs_ref16"][0] - fx["meta"]["ref16_vs_ref32"][0]) <= 1e-2   # same noise level
 
 
+def test_fp16_oracle_is_within_quantisation_noise_of_the_reference_under_fp16_autocast(sd_bench):
+    """lm_autocast_fp16.pt (round 4): the REAL reference's LanguageModel.forward under torch.autocast("cpu", float16) - the
+    dtype its own scripts use (generate_reports_for_images.py:108).  The float16 mode of the oracle (bf16=2), parity target of
+    the HIP fp16 path, sits within the reference's own fp16-vs-fp32 distance: ~0.15 % of the logit range (8x below bf16)."""
+    fx = load_golden("lm_autocast_fp16.pt")
+    ids, mask, feats = fx["input_ids"], fx["attention_mask"], fx["feats"]
+    T = ids.shape[1]
+    o16, _ = o_lm.lm_forward(sd_bench, ids, mask, feats, None, torch.arange(T)[None, :], bf16=2)
+    rng = fx["meta"]["logit_range"]
+    d = (o16[:, -1] - fx["ref16_logits_last"]).abs().max().item() / rng
+    agree16 = (o16.argmax(-1) == fx["ref16_argmax"]).float().mean().item()
+    agree32 = (o16.argmax(-1) == fx["ref32_argmax"]).float().mean().item()
+    assert fx["meta"]["autocast"] == "cpu, float16" and fx["meta"]["ref16_vs_ref32"][0] <= 3e-3
+    assert d <= 3e-3, d
+    assert agree16 >= 0.98 and agree32 >= 0.98, (agree16, agree32)
+    # and it is NOT the bf16 arithmetic: the bf16 oracle is ~5x further from this fixture
+    b16, _ = o_lm.lm_forward(sd_bench, ids, mask, feats, None, torch.arange(T)[None, :], bf16=1)
+    assert (b16[:, -1] - fx["ref16_logits_last"]).abs().max().item() / rng >= 3 * d
+
+
 @pytest.mark.parametrize("name", ["lm_grads.pt", "lm_grads_t300.pt"])
 def test_lm_gradients_oracle_matches_reference_autograd(sd_ragged, name):
     """The REAL reference's loss.backward() through the language model (tests/golden/make_golden_lm_grads.py; T = 11 and,

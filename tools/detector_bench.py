@@ -69,7 +69,8 @@ pooled = torch.empty((R, Cf), device="cuda")
 
 def roi():
     fn = eng.lib.rgrg_roi_align_avgpool_bf16maps if LOW else eng.lib.rgrg_roi_align_avgpool_f32
-    _hip.check(fn(feat.data_ptr(), props.data_ptr(), offsets.data_ptr(), maps.data_ptr(), pooled.data_ptr(), B, 16, 16, Cf, 1000, R, 1.0 / 32, st()))
+    _hip.check(fn(feat.data_ptr(), props.data_ptr(), offsets.data_ptr(), maps.data_ptr(), pooled.data_ptr(), B, 16, 16, Cf, 1000, R, 1.0 / 32,
+                  *([0] if LOW else []), st()))
 
 
 ms, _ = timed(roi)
@@ -81,7 +82,7 @@ if LOW:
 
     def fc6():
         _hip.check(eng.lib.rgrg_linear_bf16_f32(maps.data_ptr(), wb.data_ptr(), eng.fc6_b.data_ptr(), None, h6.data_ptr(), None, R, 1024, 64 * Cf, 1024,
-                                                _hip.ACT_RELU, st()))
+                                                _hip.ACT_RELU, 0, st()))
     ms, _ = timed(fc6)
 else:
     x6 = maps.view(R, 64 * Cf)

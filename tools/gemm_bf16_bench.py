@@ -65,9 +65,9 @@ def main():
         Wb = torch.empty((ncopy, N, K), dtype=torch.int16, device="cuda")
         b = torch.randn((N,), device="cuda")
         Y = torch.zeros((M, N), device="cuda")
-        _hip.check(lib.rgrg_f32_to_bf16(A.data_ptr(), A16.data_ptr(), M * K, st))
+        _hip.check(lib.rgrg_f32_to_bf16(A.data_ptr(), A16.data_ptr(), M * K, 0, st))
         for c in range(ncopy):
-            _hip.check(lib.rgrg_f32_to_bf16(W.data_ptr(), Wb[c].data_ptr(), N * K, st))
+            _hip.check(lib.rgrg_f32_to_bf16(W.data_ptr(), Wb[c].data_ptr(), N * K, 0, st))
         it = [0]
 
         def wptr(Wx):  # next weight copy
@@ -76,7 +76,7 @@ def main():
         R = Y.data_ptr() if res else None
         ref = (A16.view(torch.bfloat16).float() @ Wb[0].view(torch.bfloat16).float().t() + b)
         print(f"{name:9s} M={M} N={N} K={K}" + (f"  (cold: {ncopy} weight copies)" if args.cold else ""), flush=True)
-        us = timed(lambda: _hip.check(lib.rgrg_linear_bf16w_f32(A.data_ptr(), wptr(Wb), b.data_ptr(), R, Y.data_ptr(), M, N, K, N, act, st)), args.iters)
+        us = timed(lambda: _hip.check(lib.rgrg_linear_bf16w_f32(A.data_ptr(), wptr(Wb), b.data_ptr(), R, Y.data_ptr(), M, N, K, N, act, 0, st)), args.iters)
         print(f"   reg-staged (fp32 A)          {us:7.1f} us {2.0 * M * N * K / us / 1e6:5.0f} TF/s", flush=True)
         if args.vendor:
             Ab, Wv, Yb = A16.view(torch.bfloat16), Wb.view(torch.bfloat16), torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
@@ -95,7 +95,7 @@ def main():
 
                     def call(out=Y, r=R, a=act):
                         _hip.check(lib.rgrg_debug_linear_bf16_tile(Ap.data_ptr(), wptr(Wp), b.data_ptr(), r, out.data_ptr(), M, N, K, N, a, tile,
-                                                                   K + pad, K + pad, st))
+                                                                   K + pad, K + pad, 0, st))
                     us = timed(call, args.iters)
                     Y2 = torch.empty((M, N), device="cuda")
                     it[0] = -1
