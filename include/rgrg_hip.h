@@ -243,12 +243,13 @@ int rgrg_dropout_mask_f32(uint64_t seed, uint32_t stream_id, float p, int64_t n,
  * (src/language_model/language_model.py:258-366, :396-399), the call the reference's own generate loop makes every step -
  * over this decoder's pre-allocated K/V cache instead of concatenated tensors.  past_len = number of tokens already in the
  * cache (0: feats [S,1024] must be given, the image key / value goes to slot 0, :135-157; > 0: feats must be NULL).  The T
- * tokens input_ids [S,T] (int64) are fed at positions past_len .. past_len + T - 1 (wte[token] + wte[position], the
- * position_ids the reference's prepare_inputs_for_generation passes, :498-520), each appending its key / value;
+ * tokens input_ids [S,T] (int64) go to cache slots past_len + 1 .. past_len + T; their embedding is wte[token] +
+ * wte[position] with position = position_ids[s][j] (int64 [S,T] on the device, any values in [0, vocab): :293-307) or, when
+ * position_ids is NULL, past_len + j (what prepare_inputs_for_generation passes, :498-520); each appends its key / value;
  * logits_out f32 [S,T,vocab] receives lm_logits of every fed position.  past_len + T <= the decoder's max_len.  All-ones
  * attention mask (generation).  Runs on the decoder's stream between two event edges with `stream`. */
-int rgrg_decoder_forward_cached(rgrg_decoder* d, const float* feats, const int64_t* input_ids, int S, int T, int past_len,
-                                float* logits_out, void* stream);
+int rgrg_decoder_forward_cached(rgrg_decoder* d, const float* feats, const int64_t* input_ids, const int64_t* position_ids,
+                                int S, int T, int past_len, float* logits_out, void* stream);
 /* Device address and geometry of one cache plane (layer, kv = 0 key / 1 value): f32 [max_seqs][16][slots][64]; the host
  * wraps rows [:S], slots [:1 + tokens] as the `presents` views of forward(use_cache=True) - no copy. */
 int rgrg_decoder_cache_plane(rgrg_decoder* d, int layer, int kv, void** ptr, int* max_seqs, int* slots, int* is_bf16);

@@ -16,7 +16,7 @@ c_float_p = C.c_void_p  # device pointers travel as void*
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p
 
 ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
-ABI_VERSION = 12  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
+ABI_VERSION = 13  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
 
 
 class RgrgHipError(RuntimeError):
@@ -63,7 +63,7 @@ SIGNATURES = {
     "rgrg_dropout_mask_f32": (_i, [C.c_uint64, C.c_uint32, C.c_float, C.c_int64, _p, _p]),
     "rgrg_decoder_refresh_trainable": (_i, [_p, _p]),
     "rgrg_decoder_take_id_error": (_i, [_p, C.POINTER(_i)]),
-    "rgrg_decoder_forward_cached": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
+    "rgrg_decoder_forward_cached": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "rgrg_decoder_cache_plane": (_i, [_p, _i, _i, C.POINTER(C.c_void_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "rgrg_transpose_pad_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "rgrg_colsum_f32": (_i, [_p, _p, _i, _i, _p]),

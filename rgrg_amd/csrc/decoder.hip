@@ -353,10 +353,11 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
                                                        int ld_ids, const int* __restrict__ step, const float* __restrict__ g,
                                                        const float* __restrict__ b, float* __restrict__ x,
                                                        float* __restrict__ xn, int D, const int* __restrict__ tok_override,
-                                                       unsigned short* __restrict__ xn16, int f16) {
+                                                       unsigned short* __restrict__ xn16, int f16, const int* __restrict__ pos_override) {
     __shared__ float sh[4];
-    const int s = blockIdx.x, t = *step, tid = threadIdx.x;
-    const long long tok = tok_override ? (long long)tok_override[s] : ids[(size_t)s * ld_ids + t];  // beam search feeds the beam tokens
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int t = pos_override ? pos_override[s] : *step;   // forward(position_ids=...): the caller's position of this row
+    const long long tok = tok_override ? (long long)tok_override[s] : ids[(size_t)s * ld_ids + *step];  // beam search feeds the beam tokens
     const f32x4 v = reinterpret_cast<const f32x4*>(wte + (size_t)tok * D)[tid] + reinterpret_cast<const f32x4*>(wte + (size_t)t * D)[tid];
     reinterpret_cast<f32x4*>(x + (size_t)s * D)[tid] = v;
     const f32x4 o = ln_row(v, g, b, sh, D);
@@ -1401,6 +1402,8 @@ struct rgrg_decoder {
     // persistent decode kernel (persistent.inc), greedy decode of <= 32 rows.  pk_mode: 0 = the launch chain, 1 = c_fc' + mlp_proj
     // of a layer in one launch, 2 = attn_proj' .. mlp_proj, 3 = attention .. mlp_proj, 4 = one launch per layer, 5 = one
     // launch per decode step (all layers + lm_head' + arg-max).  RGRG_PERSISTENT overrides the default.
+    const int* pos_override_cur = nullptr;   // set around the steps of rgrg_decoder_forward_cached: per-row embedding positions
+    int* row_pos = nullptr;                  // [rows] buffer behind it
     int pk_mode = 0;
     std::vector<PkLayer> pk_layers;   // per-layer pointer table (copied into the kernel arguments)
     unsigned* pk_bar = nullptr;     // barrier state (persistent.inc), zeroed at creation
@@ -1590,6 +1593,7 @@ static int direct_linear(rgrg_decoder* d, const Lin& l, DirectArgs a, int mode, 
         else if (l.lnf && mode == DX_COMBINE4) DX_LAUNCH(MT_, DX_COMBINE4, true);            \
         else if (l.lnf && mode == DX_EMBED) DX_LAUNCH(MT_, DX_EMBED, true);                  \
         else if (l.lnf && mode == DX_EMBED_TOK) DX_LAUNCH(MT_, DX_EMBED_TOK, true);          \
+        else if (l.lnf && mode == DX_EMBED_TOKPOS) DX_LAUNCH(MT_, DX_EMBED_TOKPOS, true);    \
         else { set_error("direct_linear: unsupported mode %d (lnf %d)", mode, (int)l.lnf); return RGRG_EINVAL; } \
     } while (0)
         if (mt == 1) DX_MODES(1);
@@ -1622,7 +1626,8 @@ static int enqueue_layer_gemms(rgrg_decoder* d, int l, int S, bool count, const 
         int mode;
         if (l == 0) {
             a.wte = d->wte; a.ids = d->ids; a.ld_ids = d->max_len; a.step = d->step; a.tok_override = tok_override;
-            mode = tok_override ? DX_EMBED_TOK : DX_EMBED;
+            a.pos_override = d->pos_override_cur;
+            mode = tok_override ? (d->pos_override_cur ? DX_EMBED_TOKPOS : DX_EMBED_TOK) : DX_EMBED;
         } else {
             a.Xf = cur; a.part = d->part;
             mode = DX_COMBINE4;
@@ -1757,7 +1762,7 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
     unsigned short* att16 = xn16 ? d->att16 : nullptr;
     unsigned short* ff16 = xn16 ? d->ff16 : nullptr;
     hipLaunchKernelGGL(embed_ln_kernel, dim3(S), dim3(256), 0, st, d->wte, d->ids, d->max_len, d->step,
-                       d->layers[0].ln1_g, d->layers[0].ln1_b, d->x, d->xn, D, tok_override, xn16, d->f16());
+                       d->layers[0].ln1_g, d->layers[0].ln1_b, d->x, d->xn, D, tok_override, xn16, d->f16(), d->pos_override_cur);
     RGRG_LAUNCH_CHECK();
     for (int l = 0; l < d->n_layer; ++l) {
         const LayerW& w = d->layers[l];
@@ -1907,6 +1912,7 @@ extern "C" int rgrg_decoder_create_with_cache(const rgrg_decoder_weights* w, int
     TRY(dmalloc(d, (void**)&d->src_a, R * d->T * 4, true));
     TRY(dmalloc(d, (void**)&d->src_b, R * d->T * 4, true));
     TRY(dmalloc(d, (void**)&d->beam_tok, R * 4, true));
+    TRY(dmalloc(d, (void**)&d->row_pos, R * 4, true));
     TRY(dmalloc(d, (void**)&d->beam_parent, R * 4, true));
     TRY(dmalloc(d, (void**)&d->beam_scores, R * 4, true));
     TRY(dmalloc(d, (void**)&d->row_max, R * 4, true));
@@ -2236,12 +2242,17 @@ __global__ void set_int_kernel(int* p, int v) {
 }
 // incremental forward: the tokens of input position j (clamped into the vocabulary) -> the step's token-override buffer,
 // and the step counter = the position (cache slot position + 1, embedding row wte[position])
-__global__ __launch_bounds__(256) void forward_cached_tokens_kernel(const long long* __restrict__ ids, int T, int j, int S, int V,
-                                                                    int* __restrict__ tok, int* __restrict__ step, int position) {
+__global__ __launch_bounds__(256) void forward_cached_tokens_kernel(const long long* __restrict__ ids, const long long* __restrict__ pos_ids,
+                                                                    int T, int j, int S, int V, int* __restrict__ tok,
+                                                                    int* __restrict__ row_pos, int* __restrict__ step, int position) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s < S) {
         const long long t = ids[(size_t)s * T + j];
-        tok[s] = (int)(t < 0 ? 0 : (t >= V ? V - 1 : t));
+        tok[s] = (int)(t < 0 ? 0 : (t >= V ? V - 1 : t));   // (the host mirror rejects ids / positions outside the table beforehand)
+        if (pos_ids) {
+            const long long q = pos_ids[(size_t)s * T + j];
+            row_pos[s] = (int)(q < 0 ? 0 : (q >= V ? V - 1 : q));
+        }
     }
     if (s == 0) *step = position;
 }
@@ -2636,8 +2647,8 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
 // key / value is computed from feats and stored in slot 0 (past_key_values=None, :135-157); then the T tokens of every row
 // are fed one position at a time (position = past_len + j; wte[token] + wte[position], :298-307), each appending its
 // key / value to the cache; logits_out [S, T, vocab] receives lm_head of every fed position.  No arg-max, no EOS bookkeeping.
-extern "C" int rgrg_decoder_forward_cached(rgrg_decoder* d, const float* feats, const int64_t* input_ids, int S, int T, int past_len,
-                                           float* logits_out, void* stream) {
+extern "C" int rgrg_decoder_forward_cached(rgrg_decoder* d, const float* feats, const int64_t* input_ids, const int64_t* position_ids,
+                                           int S, int T, int past_len, float* logits_out, void* stream) {
     RGRG_CHECK_ARG(d && input_ids && logits_out && S > 0 && S <= d->max_seqs && T >= 1 && past_len >= 0);
     RGRG_CHECK_ARG((past_len == 0) == (feats != nullptr));
     RGRG_CHECK_ARG(past_len + T <= d->max_len);   // slot of the last token = past_len + T <= T_cache - 1
@@ -2648,9 +2659,13 @@ extern "C" int rgrg_decoder_forward_cached(rgrg_decoder* d, const float* feats, 
     if (past_len == 0 && (rc = enqueue_prefill(d, feats, S))) return rc;   // also resets the step counter to 0
     for (int j = 0; j < T; ++j) {
         hipLaunchKernelGGL(forward_cached_tokens_kernel, dim3((S + 255) / 256), dim3(256), 0, st,
-                           reinterpret_cast<const long long*>(input_ids), T, j, S, d->V, d->beam_tok, d->step, past_len + j);
+                           reinterpret_cast<const long long*>(input_ids), reinterpret_cast<const long long*>(position_ids), T, j, S, d->V,
+                           d->beam_tok, d->row_pos, d->step, past_len + j);
         RGRG_LAUNCH_CHECK();
-        if ((rc = enqueue_step(d, S, false, d->beam_tok, nullptr, true))) return rc;   // ... lm_head: logits, nothing else
+        d->pos_override_cur = position_ids ? d->row_pos : nullptr;   // embedding rows wte[position_ids[s][j]]; the cache slot stays past_len + j + 1
+        rc = enqueue_step(d, S, false, d->beam_tok, nullptr, true);   // ... lm_head: logits, nothing else
+        d->pos_override_cur = nullptr;
+        if (rc) return rc;
         RGRG_HIP(hipMemcpy2DAsync(logits_out + (size_t)j * d->V, (size_t)T * d->V * sizeof(float), d->logits,
                                   (size_t)d->ld_logits * sizeof(float), (size_t)d->V * sizeof(float), S, hipMemcpyDeviceToDevice, st));
     }

@@ -309,8 +309,10 @@ __global__ void prefix_counts_kernel(const int* __restrict__ counts, int* __rest
 // output float4, output rows written as 512-B coalesced runs in [bin][channel] order.
 // ----------------------------------------------------------------------------------
 // Sampling tables of one RoI: per y / x sample (bin*2 + sample) one 16-byte record
-// {lo, hi (int bits), l, h}; a sample outside the map ("dead") gets l = h = 0, so all four of
-// its bilinear weights are exactly 0 and it adds exactly 0 - same result as skipping it.
+// {lo, hi (int bits: BYTE offsets of that row / column inside the LDS slab: y * FW * 512, x * 512), l, h}; a sample
+// outside the map ("dead") gets l = h = 0, so all four of its bilinear weights are exactly 0 and it adds exactly 0 -
+// same result as skipping it.  (Round 4: the records carry byte offsets, so a corner address is one add - the inner
+// loop is VALU bound, ~150 instructions per 4-channel bin of which a third was address arithmetic.)
 struct RoiTables {
     f32x4 y[16];
     f32x4 x[16];
@@ -367,11 +369,13 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_avg_kernel(const float*
             if (lo >= size - 1) { lo = hi = size - 1; v = (float)lo; } else { hi = lo + 1; }
             const float l = v - (float)lo;
             f32x4 rec;
-            rec[0] = __int_as_float(lo); rec[1] = __int_as_float(hi);
+            const int step = ax ? 512 : FW * 512;   // bytes per column / per row of the [pos][128 floats] slab
+            rec[0] = __int_as_float(lo * step); rec[1] = __int_as_float(hi * step);
             rec[2] = dead ? 0.0f : l; rec[3] = dead ? 0.0f : 1.0f - l;
             if (ax) tabs[rr].x[sidx] = rec; else tabs[rr].y[sidx] = rec;
         }
         __syncthreads();
+        const unsigned char* slab_lane = reinterpret_cast<const unsigned char*>(slab) + c4 * 16;   // this lane's 4 channels of position 0
         for (int rr = grp; rr < ns; rr += ROI_THREADS / 32) {
             const RoiTables& T = tabs[rr];
             const int r = s0 + rr;
@@ -396,10 +400,10 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_avg_kernel(const float*
                             const int xlo = __float_as_int(tx[0]), xhi = __float_as_int(tx[1]);
                             const float lx = tx[2], hx = tx[3];
                             const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-                            const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + (ylo * FW + xlo) * 128 + c4 * 4);
-                            const f32x4 v2 = *reinterpret_cast<const f32x4*>(slab + (ylo * FW + xhi) * 128 + c4 * 4);
-                            const f32x4 v3 = *reinterpret_cast<const f32x4*>(slab + (yhi * FW + xlo) * 128 + c4 * 4);
-                            const f32x4 v4 = *reinterpret_cast<const f32x4*>(slab + (yhi * FW + xhi) * 128 + c4 * 4);
+                            const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab_lane + ylo + xlo);
+                            const f32x4 v2 = *reinterpret_cast<const f32x4*>(slab_lane + ylo + xhi);
+                            const f32x4 v3 = *reinterpret_cast<const f32x4*>(slab_lane + yhi + xlo);
+                            const f32x4 v4 = *reinterpret_cast<const f32x4*>(slab_lane + yhi + xhi);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float val = w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];

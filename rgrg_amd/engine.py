@@ -885,27 +885,47 @@ class HipEngine:
         fit = int(free * budget_fraction) // per_slot - 1
         return max(2, min(int(want), fit))
 
-    def forward_cached(self, feats: Optional[Tensor], input_ids: Tensor, past_len: int, cache_len: int = 1024):
+    def forward_cached(self, feats: Optional[Tensor], input_ids: Tensor, past_len: int, cache_len: int = 1024,
+                       position_ids: Optional[Tensor] = None, adopt_past=None):
         """LanguageModel.forward(use_cache=True[, past_key_values]) over the decoder's K/V cache (rgrg_decoder_forward_cached):
-        feeds input_ids [S,T] at positions past_len .. past_len + T - 1 -> (logits f32 [S,T,V], presents) where presents is
-        the reference's tuple of 24 (key, value) pairs, each a VIEW [S,16,1 + past_len + T,64] of the cache.  ``cache_len`` =
-        token slots to provide for when the cache is created (the first call): the reference's 1024 positions, clipped to what
-        half of the free device memory holds for this many rows."""
+        feeds input_ids [S,T] into cache slots past_len + 1 .. past_len + T -> (logits f32 [S,T,V], presents) where presents is
+        the reference's tuple of 24 (key, value) pairs, each a VIEW [S,16,1 + past_len + T,64] of the cache.  ``position_ids``
+        [S,T] (or [1,T]): the embedding positions (wte[position], language_model.py:293-307), any values inside the table; None:
+        past_len + j.  ``adopt_past``: a FOREIGN past_key_values (24 pairs of [S,16,1 + past_len,64] tensors that are not views of
+        this decoder's cache, e.g. clones or another model's presents): copied into the cache first.  ``cache_len`` = token slots
+        to provide for when the cache is created: the reference's 1024 positions, clipped to what half of the free device memory
+        holds for this many rows."""
         S, T = input_ids.shape
         # torch.nn.Embedding raises on an id outside the vocabulary in the same call; so does this path (one read-back: it is
         # the incremental API, not the generate loop)
         idc = input_ids.to(device=self.device)
         if bool(((idc < 0) | (idc >= self.vocab)).any()):
             raise IndexError(f"index out of range in self: a token id is outside [0, {self.vocab})")
-        if past_len == 0:
-            if feats is None or feats.shape[0] != S:
+        pos = None
+        if position_ids is not None:
+            pos = position_ids.to(device=self.device, dtype=torch.int64).reshape(-1, T)
+            if pos.shape[0] not in (1, S):
+                raise ValueError(f"position_ids has {pos.shape[0]} rows, input_ids {S}")
+            if bool(((pos < 0) | (pos >= self.vocab)).any()):   # positions index wte as well (the quirk, :307)
+                raise IndexError(f"index out of range in self: a position id is outside [0, {self.vocab})")
+            pos = pos.expand(S, T).contiguous()
+        if past_len == 0 or adopt_past is not None:
+            if past_len == 0 and (feats is None or feats.shape[0] != S):
                 raise ValueError("image_hidden_states [S,1024] is needed when past_key_values is None")
-            _require_gpu(feats.device)
-            want = max(self.cache_tokens_that_fit(S, cache_len), T)
+            _require_gpu(feats.device if feats is not None else adopt_past[0][0].device)
+            want = max(self.cache_tokens_that_fit(S, cache_len), past_len + T)
             if self._decoder is not None and S <= self._decoder_caps[0]:
-                want = min(want, max(self._decoder_caps[1], T))   # an existing decoder is reused as is; it grows only for T
+                want = min(want, max(self._decoder_caps[1], past_len + T))   # an existing decoder is reused as is; it grows only when it must
             dec = self._get_decoder(S, want)
-            self._cached = {"S": S, "tokens": 0}
+            if adopt_past is not None:
+                if len(adopt_past) != self.n_layer:
+                    raise ValueError(f"past_key_values has {len(adopt_past)} layers, the model {self.n_layer}")
+                for l, (k, v) in enumerate(adopt_past):
+                    if tuple(k.shape) != (S, 16, 1 + past_len, 64) or tuple(v.shape) != tuple(k.shape):
+                        raise ValueError(f"past_key_values[{l}] has shape {tuple(k.shape)}, expected {(S, 16, 1 + past_len, 64)}")
+                    self._kv[l, 0, :S, :, :1 + past_len].copy_(k.to(device=self.device, dtype=torch.float32))
+                    self._kv[l, 1, :S, :, :1 + past_len].copy_(v.to(device=self.device, dtype=torch.float32))
+            self._cached = {"S": S, "tokens": past_len}
         else:
             c = getattr(self, "_cached", None)
             if self._decoder is None or c is None or c["S"] != S or c["tokens"] != past_len:
@@ -920,8 +940,8 @@ class HipEngine:
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
         f = None if past_len else feats.to(torch.float32).contiguous()
         logits = torch.empty((S, T, self.vocab), dtype=torch.float32, device=self.device)
-        _hip.check(self.lib.rgrg_decoder_forward_cached(dec, _hip.ptr(f), _hip.ptr(ids), S, T, int(past_len), _hip.ptr(logits), self._s()),
-                   "rgrg_decoder_forward_cached")
+        _hip.check(self.lib.rgrg_decoder_forward_cached(dec, _hip.ptr(f), _hip.ptr(ids), _hip.ptr(pos), S, T, int(past_len), _hip.ptr(logits),
+                                                        self._s()), "rgrg_decoder_forward_cached")
         self._cached["tokens"] = past_len + T
         return logits, self._cache_views(dec, S, 1 + past_len + T)
 
@@ -943,6 +963,14 @@ class HipEngine:
         except Exception:  # noqa: BLE001
             return None
         return None
+
+    def aliases_cache(self, past_key_values) -> bool:
+        """True when the tensors live in this decoder's cache allocation (views of it) - valid only as its current presents."""
+        try:
+            st = past_key_values[0][0].untyped_storage().data_ptr()
+            return self._kv is not None and st == self._kv.untyped_storage().data_ptr()
+        except Exception:  # noqa: BLE001
+            return False
 
     def last_logits(self, S: int) -> Tensor:
         dst = torch.empty((S, self.vocab), dtype=torch.float32, device=self.device)

@@ -165,35 +165,37 @@ class LanguageModel(EngineOwner):
     def _forward_cached(self, input_ids, attention_mask, image_hidden_states, return_loss, past_key_values, position_ids):
         """The incremental form (language_model.py:258-366, :396-399): ``forward(..., use_cache=True)`` returns
         ``(lm_logits [S,T,50257], presents)``; ``presents`` - 24 (key, value) pairs [S,16,1+tokens,64], the image key / value
-        in slot 0 - are zero-copy VIEWS of the HIP decoder's pre-allocated cache, and feeding them back as
-        ``past_key_values`` continues on that cache (the reference concatenates new tensors every step).  Limits, all
-        raised: the presents must come from the previous call of this model (no foreign / re-ordered tensors), positions
-        are the token indices (what prepare_inputs_for_generation passes, :498-520; with ``position_ids=None`` and a past
-        the reference counts the image key as a position, :298-300 - pass the ids), no padding inside the prompt, eval
-        mode, no loss."""
+        in slot 0 - are VIEWS of the HIP decoder's pre-allocated cache (a torch tensor), and feeding them back as
+        ``past_key_values`` continues on that cache (the reference concatenates new tensors every step).  Round 4:
+        ``position_ids`` may be anything the embedding table holds ([S,T] or [1,T]; default, as in the reference :293-304,
+        arange(past_length, past_length + T) where past_length counts the image key when a past is given), and a FOREIGN
+        ``past_key_values`` (clones, tensors of another model instance) is copied into the cache and continued from.  Still
+        raised: stale views of this decoder's own cache (generate() or another call chain has rewritten it since), padding
+        inside the prompt, train mode, a loss."""
         if return_loss or self.training:
             raise NotImplementedError("forward(use_cache=True) is the generation form: eval mode, return_loss=False")
         self.sync_trainable_if_stale()
         ids2 = input_ids.view(-1, input_ids.shape[-1])
         S, T = ids2.shape
         eng = self.engine()
+        adopt = None
         if past_key_values is None:
             past = 0
         else:
             past = eng.owns_cache(past_key_values)
             if past is None:
-                raise NotImplementedError("past_key_values must be the presents returned by the previous forward(use_cache=True) of "
-                                          "this model, unmodified (the cache lives in the HIP decoder)")
+                if eng.aliases_cache(past_key_values):
+                    raise NotImplementedError("past_key_values must be the presents returned by the previous forward(use_cache=True) of "
+                                              "this model, or independent tensors: these are stale views of the decoder's cache (it has "
+                                              "been rewritten since)")
+                adopt = past_key_values
+                past = int(past_key_values[0][0].shape[-2]) - 1   # slot 0 = the image key
         if attention_mask is not None and not bool((attention_mask.reshape(S, -1) != 0).all()):
             raise NotImplementedError("forward(use_cache=True) supports the all-ones attention mask of generation only")
-        expect = torch.arange(past, past + T)
-        if position_ids is None:
-            if past != 0:
-                raise NotImplementedError("pass position_ids = token indices with past_key_values (the reference's default would "
-                                          "count the image key as a position)")
-        elif not torch.equal(position_ids.reshape(-1, T).cpu(), expect.view(1, T).expand(position_ids.reshape(-1, T).shape[0], T)):
-            raise NotImplementedError("position_ids must be the token indices arange(past_tokens, past_tokens + seq_len)")
-        return eng.forward_cached(image_hidden_states if past == 0 else None, ids2, past)
+        if position_ids is None and past_key_values is not None:
+            # the reference's default counts the image key: arange(past_length, past_length + T), past_length = keys in the cache
+            position_ids = torch.arange(past + 1, past + 1 + T).view(1, T)
+        return eng.forward_cached(image_hidden_states if past == 0 else None, ids2, past, position_ids=position_ids, adopt_past=adopt)
 
     def trainable_parameters(self):
         """uk/uv of every layer, then feature_space_transformation_nn: the language-model tensors the reference

@@ -882,10 +882,25 @@ def test_incremental_forward_with_use_cache_reproduces_the_oracles_cached_steps(
     for l in (0, 11, 23):
         assert (presents[l][0].cpu() - o_past[l][0]).abs().max().item() <= 2e-3
         assert (presents[l][1].cpu() - o_past[l][1]).abs().max().item() <= 2e-3
-    # foreign / re-ordered past tensors are refused, loudly
-    with pytest.raises(NotImplementedError, match="presents returned by the previous"):
-        lm(nxt[0].to(DEV), torch.ones((3, ntok + 1), device=DEV), feats.to(DEV), past_key_values=tuple((k.clone(), v.clone()) for k, v in presents),
-           position_ids=torch.full((3, 1), ntok), use_cache=True)
+    # round 4: a FOREIGN past (clones - independent tensors, as the reference's presents are) is adopted: copied into the decoder's
+    # cache and continued from, with the same result as continuing on the views; shifted / per-row position_ids are honoured
+    clones = tuple((k.clone(), v.clone()) for k, v in presents)
+    am = torch.ones((3, ntok + 1), dtype=torch.int64)
+    pos = torch.tensor([[7], [ntok], [1000]])                      # any row of the embedding table, per sequence
+    o_logits, _ = o_lm.lm_forward(sd, nxt[0], am, feats, o_past, pos)
+    l_views, _ = lm(nxt[0].to(DEV), am.to(DEV), feats.to(DEV), return_loss=False, past_key_values=presents, position_ids=pos, use_cache=True)
+    lm.generate(_lm_feats().to(DEV), max_length=6)                 # clobbers the decoder's cache: the views are stale now ...
+    with pytest.raises(NotImplementedError, match="stale views"):
+        lm(nxt[0].to(DEV), am.to(DEV), feats.to(DEV), past_key_values=presents, position_ids=pos, use_cache=True)
+    l_clone, p2 = lm(nxt[0].to(DEV), am.to(DEV), feats.to(DEV), return_loss=False, past_key_values=clones, position_ids=pos, use_cache=True)
+    assert torch.equal(l_clone, l_views) and (l_clone.cpu() - o_logits).abs().max().item() <= 2e-3    # ... the clones are not
+    assert p2[3][0].shape == (3, 16, ntok + 2, 64) and torch.equal(p2[3][0][:, :, :ntok + 1], clones[3][0])
+    # position_ids=None with a past: the reference's default arange(past_length, ...) counts the image key (:298-304)
+    o_def, _ = o_lm.lm_forward(sd, nxt[1], am, feats, o_past, torch.full((1, 1), ntok + 1))
+    l_def, _ = lm(nxt[1].to(DEV), am.to(DEV), feats.to(DEV), return_loss=False, past_key_values=clones, use_cache=True)
+    assert (l_def.cpu() - o_def).abs().max().item() <= 2e-3
+    with pytest.raises(IndexError, match="position id"):
+        lm(nxt[1].to(DEV), am.to(DEV), feats.to(DEV), past_key_values=clones, position_ids=torch.full((3, 1), 50257), use_cache=True)
     # greedy loop written against forward(), as the reference's greedy_search does (:609-652)
     f5 = _lm_feats().to(DEV)
     ref = lm.generate(f5, max_length=10)
@@ -936,6 +951,8 @@ def test_presents_are_invalidated_by_other_users_of_the_cache_and_outlive_a_repl
     torch.nn.Embedding does (the path used to clamp silently)."""
     m = gpu_model("ragged")
     lm, eng = m.language_model, m.engine()
+    eng.close()                      # start from a fresh 32-row decoder whatever ran before (the 40-row call below must replace it)
+    eng._decoder_caps = (0, 0)
     g = torch.Generator().manual_seed(3)
     feats = torch.randn((3, 1024), generator=g).to(DEV)
     prompt = torch.randint(0, 50000, (3, 4), generator=g).to(DEV)
@@ -943,16 +960,20 @@ def test_presents_are_invalidated_by_other_users_of_the_cache_and_outlive_a_repl
     am5 = torch.ones((3, 5), device=DEV)
     _, presents = lm(prompt, torch.ones((3, 4), device=DEV), feats, return_loss=False, use_cache=True)
     lm.generate(feats, max_length=8)                                    # same decoder, same cache rows
-    with pytest.raises(NotImplementedError, match="presents returned by the previous"):
+    with pytest.raises(NotImplementedError, match="stale views"):
         lm(one, am5, feats, return_loss=False, past_key_values=presents, position_ids=torch.full((3, 1), 4), use_cache=True)
     logits_a, presents = lm(prompt, torch.ones((3, 4), device=DEV), feats, return_loss=False, use_cache=True)
     snapshot = presents[7][0].clone()
     lm.generate(torch.randn((40, 1024), generator=g).to(DEV), max_length=6)   # 40 rows > 32: the engine creates a larger decoder
     torch.cuda.synchronize()
     assert torch.equal(presents[7][0], snapshot)                        # the old cache is still there, untouched
-    with pytest.raises(NotImplementedError):                            # ... but it is not the current decoder's
-        lm(one, am5, feats, return_loss=False, past_key_values=presents, position_ids=torch.full((3, 1), 4), use_cache=True)
-    del presents
+    # ... and, no longer being the current decoder's cache, it is a FOREIGN past now: adopted by copy (round 4), same logits as
+    # continuing directly would have given
+    l_adopt, _ = lm(one, am5, feats, return_loss=False, past_key_values=presents, position_ids=torch.full((3, 1), 4), use_cache=True)
+    _, p_direct = lm(prompt, torch.ones((3, 4), device=DEV), feats, return_loss=False, use_cache=True)
+    l_direct, _ = lm(one, am5, feats, return_loss=False, past_key_values=p_direct, position_ids=torch.full((3, 1), 4), use_cache=True)
+    assert torch.equal(l_adopt, l_direct)
+    del presents, p_direct
     bad = prompt.clone()
     bad[1, 2] = 50257
     with pytest.raises(IndexError, match="out of range"):
