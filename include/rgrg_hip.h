@@ -315,7 +315,8 @@ int rgrg_debug_linear_bf16_tile(const uint16_t* A16, const uint16_t* Wb, const f
  * ReportGenerationModel.forward(images, image_targets, ...) (src/full_model/report_generation_model.py:55,91 ->
  * src/object_detector/object_detector.py:216-224 -> custom_rpn.py:74-83, custom_roi_heads.py:225-242, and underneath
  * torchvision 0.13.1 det_utils.Matcher / BoxCoder.encode / RegionProposalNetwork.compute_loss / fastrcnn_loss).
- * The random sub-sampling (BalancedPositiveNegativeSampler) and the index gathers stay with the caller. */
+ * Matching, the BalancedPositiveNegativeSampler, add_gt_proposals, the gathers of the sampled rows and the losses are all
+ * kernels; the caller allocates and passes pointers. */
 /* Matcher: gt [B][G][4] (gt_count[b] valid rows), boxes [N][4] per image at boxes + b * box_image_stride floats
  * (stride 0: one shared set, the anchors), box_count[b] valid boxes (NULL: N).  matched [B][N] = index of the best gt
  * (first maximum), -1 below `low`, -2 between; allow_low_quality restores the arg-max of every box that ties a gt's
@@ -323,16 +324,37 @@ int rgrg_debug_linear_bf16_tile(const uint16_t* A16, const uint16_t* Wb, const f
 int rgrg_box_match_f32(const float* gt, const int* gt_count, int G, const float* boxes, int64_t box_image_stride,
                        const int* box_count, int B, int N, float high, float low, int allow_low_quality, int* matched,
                        int* ws_best_per_gt, void* stream);
-/* BoxCoder.encode: deltas [n][4] of ref_boxes [n][4] relative to proposals [n][4], weights (wx, wy, ww, wh). */
-int rgrg_box_encode_f32(const float* ref_boxes, const float* proposals, int n, float wx, float wy, float ww, float wh,
-                        float* out, void* stream);
-/* RPN losses on the fused head output rpn_out [B * cells][ld] (anchors_per_cell objectness columns, then 4 deltas per
- * anchor); labels / reg_targets / sampled are per flat anchor index (image-major, `total` of them); sampled = the
- * BalancedPositiveNegativeSampler's choice as a byte per anchor: 0 not sampled, 1 sampled positive, 2 sampled negative
- * (a device mask: no index lists, no counts on the host).  out2[0] = loss_objectness (BCE over the sampled anchors, mean),
- * out2[1] = loss_rpn_box_reg (smooth-L1 beta 1/9 over the sampled positives / #sampled); nan when nothing is sampled. */
-int rgrg_rpn_loss_f32(const float* rpn_out, int ld, int anchors_per_cell, const float* labels, const float* reg_targets,
-                      const uint8_t* sampled, int64_t total, float* out2, void* stream);
+/* det_utils.BalancedPositiveNegativeSampler for B images at once (custom_rpn.py:79: batch 256, half positive;
+ * custom_roi_heads.py:225: batch 512, a quarter positive).  The candidates' labels come from the match codes: matched
+ * [B][n] (rgrg_box_match_f32), gt_labels [B][G] (NULL: RPN - matched >= 0 is a positive; else the matched box's class:
+ * >= 1 positive, 0 negative, < 0 ignored), box_count[b] candidates per image (NULL: n).  Per image num_pos = min(#positive,
+ * max_pos), num_neg = min(#negative, batch - num_pos); taken are the candidates with the SMALLEST keys of each class, lower
+ * index first on ties: keys [B][n] fp32 when given (tests replay the reference's draws this way), else Philox4x32-10 words
+ * of (seed, stage, image, index) - a uniformly random subset like torchvision's randperm()[:k].  ws_keys: B * n words of
+ * work space.  mask [B][n]: 0 / 1 sampled positive / 2 sampled negative; list [B][batch]: the sampled indices ascending
+ * (torch.where(pos | neg)), zero filled; count [B]. */
+int rgrg_balanced_sample(const int* matched, const int64_t* gt_labels, int G, const int* box_count, const float* keys,
+                         uint64_t seed, int stage, int B, int n, int batch, int max_pos, uint32_t* ws_keys, uint8_t* mask,
+                         int* list, int* count, void* stream);
+/* RegionProposalNetwork.compute_loss on the fused head output rpn_out [B * cells][ld] (anchors_per_cell objectness columns,
+ * then 4 deltas per anchor) from the sampler's outputs: anchors [A][4] shared by the images, gt [B][G][4]; labels and
+ * regression targets (BoxCoder.encode, weights 1) of the sampled anchors are derived in the kernel from mask / matched.
+ * out2[0] = loss_objectness (BCE over the sampled anchors, mean), out2[1] = loss_rpn_box_reg (smooth-L1 beta 1/9 over the
+ * sampled positives / #sampled); nan when nothing is sampled. */
+int rgrg_rpn_loss_sampled_f32(const float* rpn_out, int ld, int anchors_per_cell, const int* matched, const float* gt, int G,
+                              const float* anchors, const uint8_t* mask, const int* list, const int* count, int B, int A,
+                              int batch, float* out2, void* stream);
+/* RoIHeads.add_gt_proposals with static shapes: boxes [B][P + G][4] = props[b][:counts[b]], gt[b][:gt_count[b]], zeros;
+ * box_count[b] = counts[b] + gt_count[b]. */
+int rgrg_roi_add_gt_f32(const float* props, const int* counts, int P, const float* gt, const int* gt_count, int G, int B,
+                        float* boxes, int* box_count, void* stream);
+/* The sampled rows of RoIHeads.select_training_samples from (boxes, matched, list, count): props_s [B][K][4] zero padded,
+ * offsets [B + 1], and in RoI order (row offsets[b] + k) labels_flat [B * K] and reg_targets [B * K][4] =
+ * BoxCoder(wx, wy, ww, wh).encode(matched gt box, proposal); rows from offsets[B] on are left untouched. */
+int rgrg_roi_gather_samples_f32(const float* boxes, const int* matched, const float* gt, const int64_t* gt_labels,
+                                const int* gt_count, int G, const int* list, const int* count, int B, int N, int K, float wx,
+                                float wy, float ww, float wh, float* props_s, int* offsets, int64_t* labels_flat,
+                                float* reg_targets, void* stream);
 /* fastrcnn_loss on pred [N][ld] = num_classes logits | num_classes x 4 deltas.  out2[0] = loss_classifier,
  * out2[1] = loss_box_reg. */
 int rgrg_fastrcnn_loss_f32(const float* pred, int ld, int num_classes, const int64_t* labels, const float* reg_targets, int N,

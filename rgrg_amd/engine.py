@@ -68,77 +68,6 @@ def pick_splitk(M: int, N: int, K: int) -> int:
     return grow(tiles, 256, 16)
 
 
-def balanced_sample_mask(labels: Tensor, keys: Tensor, batch: int, frac: float) -> Tensor:
-    """det_utils.BalancedPositiveNegativeSampler for a whole batch, on the device and without a host round trip:
-    labels [B,n] (>= 1 positive, 0 negative, < 0 ignored), keys [B,n] -> uint8 [B,n]: 1 sampled positive, 2 sampled negative.
-    Per image num_pos = min(#positive, int(batch * frac)), num_neg = min(#negative, batch - num_pos); taken are the
-    candidates with the smallest keys (stable sort: lower index first on ties) - for i.i.d. keys a uniformly random subset,
-    like torchvision's positive[randperm(|positive|)[:num_pos]]."""
-    B, n = labels.shape
-    pos, neg = labels >= 1, labels == 0
-    num_pos = pos.sum(1).clamp(max=int(batch * frac))
-    num_neg = torch.minimum(neg.sum(1), batch - num_pos)
-    ar = torch.arange(n, device=labels.device).expand(B, n)
-    big = torch.full_like(keys, float("inf"))
-
-    def pick(cand: Tensor, k: Tensor) -> Tensor:
-        order = torch.sort(torch.where(cand, keys, big), dim=1, stable=True).indices
-        rank = torch.empty_like(order).scatter_(1, order, ar)
-        return cand & (rank < k[:, None])
-    return pick(pos, num_pos).to(torch.uint8) + 2 * pick(neg, num_neg).to(torch.uint8)
-
-
-def select_training_samples_batched(props: Tensor, counts: Tensor, gt: Tensor, gt_count: Tensor, gt_labels: Tensor, keys: Tensor,
-                                    match_fn, encode_fn, K: int = 512):
-    """RoIHeads.select_training_samples (custom_roi_heads.py:225-226; object_detector.py:118-123: the ground-truth boxes
-    join the proposals, IoU 0.5, K = 512 per image, a quarter positive, BoxCoder weights (10,10,5,5)) for a whole batch with
-    static shapes and no host synchronisation.  props [B,P,4] with counts [B] valid rows, gt [B,G,4] / gt_labels [B,G] with
-    gt_count [B] valid rows, keys [B,P+G] (balanced_sample_mask); match_fn(boxes [B,N,4], box_count int32 [B]) -> matched
-    [B,N] (gt index, -1 below, -2 between; HIP: rgrg_box_match_f32), encode_fn(ref [n,4], proposals [n,4]) -> deltas (HIP:
-    rgrg_box_encode_f32).  -> proposals [B,K,4] (the sampled ones of an image first, in index order, zero padded), offsets
-    int32 [B+1] (device), labels int64 [B*K] and regression targets [B*K,4] in RoI order = image-major compaction (the first
-    offsets[B] rows are meaningful)."""
-    B, P = props.shape[:2]
-    G = gt.shape[1]
-    N = P + G
-    dev = props.device
-    j = torch.arange(N, device=dev)[None, :]
-    cnt, g = counts.to(torch.int64)[:, None], gt_count.to(torch.int64)[:, None]
-    # add_gt_proposals: slots [0, cnt) = proposals, [cnt, cnt + g) = ground truth, the rest unused
-    boxes = torch.zeros((B, N, 4), dtype=torch.float32, device=dev)
-    boxes[:, :P] = torch.where((j[:, :P] < cnt)[:, :, None], props.to(torch.float32), boxes[:, :P])
-    from_gt = (j >= cnt) & (j < cnt + g)
-    gsrc = torch.gather(gt, 1, (j - cnt).clamp(0, G - 1)[:, :, None].expand(B, N, 4))
-    boxes = torch.where(from_gt[:, :, None], gsrc, boxes).contiguous()
-    box_count = (cnt + g)[:, 0].to(torch.int32)
-    m = match_fn(boxes, box_count).to(torch.int64)
-    clamped = m.clamp(0, G - 1)
-    lab = torch.gather(gt_labels, 1, clamped)
-    lab = torch.where(m == -1, torch.zeros_like(lab), lab)       # below the threshold (and every box of an image without gt)
-    lab = torch.where(m == -2, torch.full_like(lab, -1), lab)    # between the thresholds: ignored
-    lab = torch.where(j >= box_count[:, None], torch.full_like(lab, -1), lab)   # unused slots are no candidates
-    smask = balanced_sample_mask(lab, keys, K, 0.25) != 0
-    ks = smask.sum(1)                                             # sampled per image (<= K)
-    jj = j.expand(B, N)
-    idx = torch.sort(torch.where(smask, jj, jj + N), dim=1).indices[:, :K]   # the sampled slots first, in index order
-    if idx.shape[1] < K:
-        idx = torch.cat([idx, idx.new_zeros((B, K - idx.shape[1]))], 1)
-    ar = torch.arange(K, device=dev)[None, :]
-    valid = ar < ks[:, None]
-    props_s = torch.gather(boxes, 1, idx[:, :, None].expand(B, K, 4)) * valid[:, :, None]
-    lab_s = torch.gather(lab, 1, idx)
-    ref_s = torch.gather(gt, 1, torch.gather(clamped, 1, idx)[:, :, None].expand(B, K, 4)) * (gt_count > 0)[:, None, None]
-    offsets_s = torch.cat([ks.new_zeros((1,)), torch.cumsum(ks, 0)])
-    # RoI order: row offsets[i] + k; the unused slots of every image are routed to one dummy row behind the end
-    dest = torch.where(valid, offsets_s[:-1, None] + ar, torch.full((1, 1), B * K, dtype=torch.int64, device=dev)).reshape(-1)
-    labels_flat = torch.zeros((B * K + 1,), dtype=torch.int64, device=dev).scatter_(0, dest, lab_s.reshape(-1))[:B * K]
-    d4 = dest[:, None].expand(-1, 4)
-    props_flat = torch.ones((B * K + 1, 4), dtype=torch.float32, device=dev).scatter_(0, d4, props_s.reshape(-1, 4))[:B * K]
-    ref_flat = torch.ones((B * K + 1, 4), dtype=torch.float32, device=dev).scatter_(0, d4, ref_s.reshape(-1, 4))[:B * K]
-    reg = encode_fn(ref_flat.contiguous(), props_flat.contiguous())
-    return props_s.contiguous(), offsets_s.to(torch.int32), labels_flat.contiguous(), reg
-
-
 def grid_anchors(image_size: int, grid: int) -> Tensor:
     """AnchorGenerator of object_detector.py:78-81 (torchvision 0.13.1 semantics):
     160 anchors per cell, index = (y*grid + x)*160 + ratio*10 + size, base anchors
@@ -542,14 +471,14 @@ class HipEngine:
             if taps is not None:
                 taps.update(features_nhwc=feat, proposals=props, counts=counts, offsets=offsets)
             return {"top_region_boxes": boxes, "top_scores": scores}, top, cd
-        # The samplers' draws: keys_fn(stage, B, n) -> fp32 [B, n]; of an image's positives (negatives) the ones with the
-        # SMALLEST keys are taken, lower index first on ties - a uniformly random subset for i.i.d. keys, like
-        # torchvision's positive[randperm(|positive|)[:k]].  Default: torch.rand on the device.
-        keys_fn = keys_fn or (lambda stage, B, n: torch.rand((B, n), dtype=torch.float32, device=images.device))
+        # The samplers' draws: of an image's positives (negatives) the ones with the SMALLEST keys are taken, lower index
+        # first on ties - a uniformly random subset for i.i.d. keys, like torchvision's positive[randperm(|positive|)[:k]].
+        # Default: Philox words generated in the kernel from a seed drawn from torch's CPU generator (torch.manual_seed
+        # governs it, no device round trip); keys_fn(stage, B, n) -> fp32 [B, n] injects the keys (tests).
         props, counts, offsets, head = self.rpn(feat, return_head=True, feat16=feat16, f16=f16)
         gt, gt_count, gt_labels = self._pad_targets(targets, images.device)
-        loss_obj, loss_rpn_box = self._rpn_losses(head, gt, gt_count, keys_fn)
-        props_s, offsets_s, labels_s, reg_s = self._select_training_samples(props, counts, gt, gt_count, gt_labels, keys_fn)
+        loss_obj, loss_rpn_box = self._rpn_losses(head, gt, gt_count, keys_fn, taps)
+        props_s, offsets_s, labels_s, reg_s = self._select_training_samples(props, counts, gt, gt_count, gt_labels, keys_fn, taps=taps)
         t2 = {} if taps is None else taps
         cd, scores, boxes, top = self.roi_heads(feat, props_s, offsets_s, t2, bf16)
         pred = t2.get("pred")
@@ -594,36 +523,71 @@ class HipEngine:
                    "rgrg_box_match_f32")
         return matched
 
-    def _encode(self, ref: Tensor, props: Tensor, weights) -> Tensor:
-        out = torch.empty_like(props)
-        _hip.check(self.lib.rgrg_box_encode_f32(_hip.ptr(ref.contiguous()), _hip.ptr(props.contiguous()), props.shape[0], *map(float, weights),
-                                                _hip.ptr(out), self._s()), "rgrg_box_encode_f32")
-        return out
+    def _sample(self, stage: str, matched: Tensor, gt_labels, box_count, batch: int, max_pos: int, keys_fn):
+        """BalancedPositiveNegativeSampler on the device (rgrg_balanced_sample): -> mask uint8 [B,n] (1 sampled positive,
+        2 sampled negative), list int32 [B,batch] (sampled indices ascending), count int32 [B]."""
+        B, n = matched.shape
+        dev = matched.device
+        keys = None if keys_fn is None else keys_fn(stage, B, n).to(device=dev, dtype=torch.float32).contiguous()
+        seed = 0 if keys is not None else int(torch.empty((), dtype=torch.int64).random_().item())
+        ws = torch.empty((B, n), dtype=torch.int32, device=dev)
+        mask = torch.empty((B, n), dtype=torch.uint8, device=dev)
+        lst = torch.empty((B, batch), dtype=torch.int32, device=dev)
+        cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+        G = 0 if gt_labels is None else gt_labels.shape[1]
+        _hip.check(self.lib.rgrg_balanced_sample(_hip.ptr(matched), _hip.ptr(gt_labels), G, _hip.ptr(box_count), _hip.ptr(keys), seed,
+                                                 {"rpn": 0, "roi": 1}[stage], B, n, batch, max_pos, _hip.ptr(ws), _hip.ptr(mask),
+                                                 _hip.ptr(lst), _hip.ptr(cnt), self._s()), "rgrg_balanced_sample")
+        return mask, lst, cnt
 
-    def _rpn_losses(self, head: Tensor, gt: Tensor, gt_count: Tensor, keys_fn):
+    def _rpn_losses(self, head: Tensor, gt: Tensor, gt_count: Tensor, keys_fn, taps=None):
         """RegionProposalNetwork.assign_targets_to_anchors + encode + compute_loss (custom_rpn.py:74-83;
-        object_detector.py:84-96: fg 0.7 / bg 0.3, low-quality matches, 256 anchors per image, half positive).  Matching,
-        encoding and the losses are HIP kernels; the sampler is a device-side mask (balanced_sample_mask) the loss kernel
-        reads directly - no index lists, no per-image loop, no host synchronisation."""
+        object_detector.py:84-96: fg 0.7 / bg 0.3, low-quality matches, 256 anchors per image, half positive): match ->
+        sample -> loss, three HIP entry points on the stream, no torch arithmetic and no host synchronisation; the loss
+        kernel derives label and regression target of the <= 256 sampled anchors per image itself."""
         B, FH, FW, ld = head.shape
         A = self.anchors.shape[0]
         m = self._match(gt, gt_count, self.anchors, 0, None, A, 0.7, 0.3, True)
-        labels = (m >= 0).to(torch.float32)
-        labels[m == -2] = -1.0  # between the thresholds: ignored (BELOW_LOW_THRESHOLD already maps to 0)
-        ref = torch.gather(gt, 1, m.clamp(min=0).to(torch.int64)[:, :, None].expand(B, A, 4))  # images without gt: zeros
-        reg = self._encode(ref.reshape(B * A, 4), self.anchors.repeat(B, 1), (1.0, 1.0, 1.0, 1.0))
-        sampled = balanced_sample_mask(labels, keys_fn("rpn", B, A), 256, 0.5).contiguous()
+        mask, lst, cnt = self._sample("rpn", m, None, None, 256, 128, keys_fn)
         out2 = torch.empty((2,), dtype=torch.float32, device=head.device)
-        _hip.check(self.lib.rgrg_rpn_loss_f32(_hip.ptr(head), ld, self.num_anchors, _hip.ptr(labels.contiguous()), _hip.ptr(reg),
-                                              _hip.ptr(sampled), B * A, _hip.ptr(out2), self._s()), "rgrg_rpn_loss_f32")
+        _hip.check(self.lib.rgrg_rpn_loss_sampled_f32(_hip.ptr(head), ld, self.num_anchors, _hip.ptr(m), _hip.ptr(gt), gt.shape[1],
+                                                      _hip.ptr(self.anchors), _hip.ptr(mask), _hip.ptr(lst), _hip.ptr(cnt), B, A, 256,
+                                                      _hip.ptr(out2), self._s()), "rgrg_rpn_loss_sampled_f32")
+        if taps is not None:
+            taps.update(rpn_matched=m, rpn_sampled=mask, rpn_sampled_list=lst, rpn_sampled_count=cnt)
         return out2[0], out2[1]
 
-    def _select_training_samples(self, props: Tensor, counts: Tensor, gt: Tensor, gt_count: Tensor, gt_labels: Tensor, keys_fn):
-        B, N = props.shape[0], props.shape[1] + gt.shape[1]
-        return select_training_samples_batched(
-            props, counts, gt, gt_count, gt_labels, keys_fn("roi", B, N),
-            lambda boxes, box_count: self._match(gt, gt_count, boxes, N * 4, box_count, N, 0.5, 0.5, False),
-            lambda ref, pr: self._encode(ref, pr, (10.0, 10.0, 5.0, 5.0)))
+    def _select_training_samples(self, props: Tensor, counts: Tensor, gt: Tensor, gt_count: Tensor, gt_labels: Tensor, keys_fn,
+                                 K: int = 512, taps=None):
+        """RoIHeads.select_training_samples (custom_roi_heads.py:225-226; object_detector.py:118-123: the ground-truth boxes
+        join the proposals, IoU 0.5, K = 512 per image, a quarter positive, BoxCoder weights (10,10,5,5)) for a whole batch
+        with static shapes and no host synchronisation: add_gt -> match -> sample -> gather, HIP kernels throughout.
+        props [B,P,4] with counts [B] valid rows, gt [B,G,4] / gt_labels [B,G] with gt_count [B] valid rows -> proposals
+        [B,K,4] (the sampled ones of an image first, in index order, zero padded), offsets int32 [B+1] (device), labels
+        int64 [B*K] and regression targets [B*K,4] in RoI order = image-major compaction (the first offsets[B] rows are
+        meaningful, the rest zero)."""
+        B, P = props.shape[:2]
+        G = gt.shape[1]
+        N = P + G
+        dev = props.device
+        props = props.to(torch.float32).contiguous()
+        boxes = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+        box_count = torch.empty((B,), dtype=torch.int32, device=dev)
+        _hip.check(self.lib.rgrg_roi_add_gt_f32(_hip.ptr(props), _hip.ptr(counts), P, _hip.ptr(gt), _hip.ptr(gt_count), G, B,
+                                                _hip.ptr(boxes), _hip.ptr(box_count), self._s()), "rgrg_roi_add_gt_f32")
+        m = self._match(gt, gt_count, boxes, N * 4, box_count, N, 0.5, 0.5, False)
+        mask, lst, cnt = self._sample("roi", m, gt_labels, box_count, K, K // 4, keys_fn)
+        props_s = torch.empty((B, K, 4), dtype=torch.float32, device=dev)
+        offsets = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+        labels_flat = torch.zeros((B * K,), dtype=torch.int64, device=dev)
+        reg = torch.zeros((B * K, 4), dtype=torch.float32, device=dev)
+        _hip.check(self.lib.rgrg_roi_gather_samples_f32(_hip.ptr(boxes), _hip.ptr(m), _hip.ptr(gt), _hip.ptr(gt_labels), _hip.ptr(gt_count),
+                                                        G, _hip.ptr(lst), _hip.ptr(cnt), B, N, K, 10.0, 10.0, 5.0, 5.0, _hip.ptr(props_s),
+                                                        _hip.ptr(offsets), _hip.ptr(labels_flat), _hip.ptr(reg), self._s()),
+                   "rgrg_roi_gather_samples_f32")
+        if taps is not None:
+            taps.update(roi_boxes=boxes, roi_box_count=box_count, roi_matched=m, roi_sampled=mask, roi_sampled_list=lst)
+        return props_s, offsets, labels_flat, reg
 
     # ------------------------------------------------------------------ selection
     def classifier_logits(self, mlp, x: Tensor) -> Tensor:
