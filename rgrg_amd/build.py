@@ -52,6 +52,7 @@ def _compile(hipcc: str, src: str, tmpdir: str, verbose: bool) -> str:
     obj = os.path.join(tmpdir, src.replace(".hip", ".o"))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
            "-Wno-pass-failed", "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd[1:1] = os.environ.get("RGRG_HIPCC_FLAGS", "").split()   # experiments (-D switches of a kernel under study)
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

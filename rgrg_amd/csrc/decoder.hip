@@ -36,8 +36,14 @@ int launch_gemm_dense(const float* A, const float* W, const float* shift, const 
 int init_gemm_attrs();
 int init_gemm_bf16_attrs();
 // (gemm_bf16.hip; f16: the 16-bit type - 0 bf16, 1 IEEE fp16)
+struct GemmLnFold {   // LayerNorm folded around the 16-bit GEMMs (gemm_bf16.hip: GemmBf16Params)
+    void* Yb16 = nullptr;               // producer: 16-bit copy of the fp32 result (the raw residual stream) ...
+    float* stats_out = nullptr;         // ... and per-row (sum, sum of squares) slots [M][32][2]
+    const float* ln_stats = nullptr;    // consumer: those slots
+    const float* ln_colsum = nullptr;   // consumer: column sums of the gain-scaled rounded weights
+};
 int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const float* shift, const float* R, float* Y, void* Y16,
-                         int M, int N, int K, int ldy, int act, hipStream_t st, int f16);
+                         int M, int N, int K, int ldy, int act, hipStream_t st, int f16, const GemmLnFold* ln = nullptr);
 int launch_gemm_bf16w(const float* A, const void* Wb, const float* shift, const float* R, float* Y, int M, int N, int K,
                       int ldy, int act, hipStream_t st, int f16);
 int convert_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st, int f16);
@@ -353,13 +359,23 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
                                                        int ld_ids, const int* __restrict__ step, const float* __restrict__ g,
                                                        const float* __restrict__ b, float* __restrict__ x,
                                                        float* __restrict__ xn, int D, const int* __restrict__ tok_override,
-                                                       unsigned short* __restrict__ xn16, int f16, const int* __restrict__ pos_override) {
+                                                       unsigned short* __restrict__ xn16, int f16, const int* __restrict__ pos_override,
+                                                       float* __restrict__ stats) {
     __shared__ float sh[4];
     const int s = blockIdx.x, tid = threadIdx.x;
     const int t = pos_override ? pos_override[s] : *step;   // forward(position_ids=...): the caller's position of this row
     const long long tok = tok_override ? (long long)tok_override[s] : ids[(size_t)s * ld_ids + *step];  // beam search feeds the beam tokens
     const f32x4 v = reinterpret_cast<const f32x4*>(wte + (size_t)tok * D)[tid] + reinterpret_cast<const f32x4*>(wte + (size_t)t * D)[tid];
     reinterpret_cast<f32x4*>(x + (size_t)s * D)[tid] = v;
+    if (stats) {
+        // LayerNorm folded into the consuming GEMM (16-bit many-sequence path): the RAW row as 16 bit plus its (sum, sum of
+        // squares) in slot 0 of the row's 32 slots - the layout the GEMM epilogues write (gemm_bf16.hip)
+        store_16x4(xn16 + (size_t)s * D + 4 * tid, v, f16);
+        const float s1 = block_sum_256((v[0] + v[1]) + (v[2] + v[3]), sh);
+        const float s2 = block_sum_256((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]), sh);
+        if (tid < 32) reinterpret_cast<float2*>(stats)[(size_t)s * 32 + tid] = tid ? make_float2(0.f, 0.f) : make_float2(s1, s2);
+        return;
+    }
     const f32x4 o = ln_row(v, g, b, sh, D);
     if (xn16) store_16x4(xn16 + (size_t)s * D + 4 * tid, o, f16);  // 16-bit-activation mode: the GEMMs read only this copy
     else reinterpret_cast<f32x4*>(xn + (size_t)s * D)[tid] = o;
@@ -1318,6 +1334,29 @@ __global__ __launch_bounds__(256) void ce_valid_kernel(const float* __restrict__
     }
 }
 
+// LayerNorm(gain, beta) folded into the [N,K] weight of the GEMM behind it, 16-bit flavour (one wave per output column):
+// wb[n][k] = round16(gain[k] w[n][k]); cs[n] = sum_k wb[n][k] of the rounded values - what the GEMM really multiplies the
+// mean with -, c2[n] = b[n] + sum_k beta[k] w[n][k].  LN(x) W^T + b = rstd (x wb^T - mean cs) + c2 up to the 16-bit
+// rounding of x instead of LN(x) (both relative roundings of the same magnitude as long as |mean| is not >> std).
+__global__ __launch_bounds__(256) void ln_fold16_kernel(const float* __restrict__ w, const float* __restrict__ gain,
+                                                        const float* __restrict__ beta, const float* __restrict__ b,
+                                                        unsigned short* __restrict__ wb, float* __restrict__ cs,
+                                                        float* __restrict__ c2, int N, int K, int f16) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float a = 0.f, c = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = w[(size_t)n * K + k];
+        const unsigned short r = (unsigned short)to16_rt(gain[k] * wv, f16);
+        wb[(size_t)n * K + k] = r;
+        a += from16_rt(r, f16);
+        c += beta[k] * wv;
+    }
+    a = wave_sum(a);
+    c = wave_sum(c);
+    if (lane == 0) { cs[n] = a; c2[n] = (b ? b[n] : 0.f) + c; }
+}
+
 // ------------------------------------------------------------------ decoder object
 struct Lin {
     const float* w = nullptr;  // [N,K]
@@ -1327,6 +1366,11 @@ struct Lin {
     float* wT = nullptr;       // [K][Np] transposed copy, Np = N rounded up to 256 (backward pass: dX = dY W)
     void* wTb = nullptr;       // 16-bit copy of wT (training under autocast)
     int wb_f16 = 0, wTb_f16 = 0;   // the 16-bit type wb / wTb currently hold (0 bf16, 1 fp16)
+    // 16-bit many-sequence decode with the LayerNorm in front of this GEMM folded in (enqueue_step): wb_ln[n][k] =
+    // round16(gain[k] w[n][k]), cs16[n] = sum_k wb_ln[n][k] (of the ROUNDED values), c2_16[n] = b[n] + sum_k beta[k] w[n][k]
+    void* wb_ln = nullptr;
+    float *cs16 = nullptr, *c2_16 = nullptr;
+    int wb_ln_f16 = -1;
     int N = 0, K = 0, NT = 0, KS = 1, ntile = 32;
     // fused decode plan (skinny_direct.inc): `packed` holds 16-column fragments, pre-scaled by the LayerNorm weight of
     // the LayerNorm this GEMM consumes when lnf is set; c1 / c2 are the folded vectors of that LayerNorm
@@ -1396,6 +1440,8 @@ struct rgrg_decoder {
     int bf16_gemms = 0;  // 1 (bf16) / 2 (fp16): 16-bit-weight MFMA GEMMs on the many-sequence path (not bit-exact; opt-in)
     int f16() const { return bf16_gemms == 2 ? 1 : 0; }   // the 16-bit type of that mode
     unsigned short *xn16 = nullptr, *att16 = nullptr, *ff16 = nullptr;  // bf16 activations of that path (GEMM inputs)
+    float* ln_stat = nullptr;   // [rows][32][2]: per-row (sum, sum of squares) slots of the residual stream (folded LayerNorm)
+    bool ln_fold = true;        // 16-bit path: LayerNorms folded into the GEMMs around them; RGRG_LN_FOLD=0: ln_rows launches (A/B)
     int gemm_launches_per_step = 0;
     void* a16_scratch = nullptr;   // bf16 copy of an fp32 GEMM input (teacher-forced / training passes under autocast)
     size_t a16_bytes = 0;
@@ -1506,7 +1552,7 @@ static bool kv_is_bf16(const rgrg_decoder* d, int rows) { return d->bf16_gemms &
 // reduce kernel when the layer splits K over workgroups); everything else: tiled MFMA GEMM (fp32, or the bf16-weight
 // kernel in the opt-in bf16 mode, optionally with bf16 activations in / out).
 static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R, float* Y, int M, int ldy, int act,
-                  bool count, const unsigned short* X16 = nullptr, unsigned short* Y16 = nullptr) {
+                  bool count, const unsigned short* X16 = nullptr, unsigned short* Y16 = nullptr, const GemmLnFold* ln = nullptr) {
     if (M <= skinny_max_rows() && l.packed && !l.direct) {
         // up to 4 row tiles of 32 sequences in ONE launch: the weights stay in registers across the tiles
         SkinnyArgs a{X, l.packed, l.b, R, Y, d->part, M, l.K, l.N, l.NT, l.KS, ldy, act};
@@ -1530,7 +1576,13 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
     }
     if (d->bf16_gemms && l.wb && l.K % 256 == 0) {
         if (count) d->gemm_bytes_per_step += (size_t)l.N * l.K * 2;
-        return launch_gemm_bf16w_ex(X16 ? nullptr : X, X16, l.wb, l.b, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream, d->f16());
+        if (ln && ln->ln_colsum) {   // the LayerNorm in front of this GEMM is folded in: gain-scaled weights, folded shift
+            if (!l.wb_ln || !X16) { set_error("decoder: folded LayerNorm weights missing"); return RGRG_EINVAL; }
+            GemmLnFold f = *ln;
+            f.ln_colsum = l.cs16;
+            return launch_gemm_bf16w_ex(nullptr, X16, l.wb_ln, l.c2_16, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream, d->f16(), &f);
+        }
+        return launch_gemm_bf16w_ex(X16 ? nullptr : X, X16, l.wb, l.b, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream, d->f16(), ln);
     }
     if (count) d->gemm_bytes_per_step += (size_t)l.N * l.K * sizeof(float);
     return launch_gemm_dense(X, l.w, l.b, R, Y, M, l.N, l.K, ldy, act, d->gemm_ws, d->gemm_ws_floats, d->stream);
@@ -1761,22 +1813,39 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
     unsigned short* xn16 = (kv_is_bf16(d, S) && d->xn16) ? d->xn16 : nullptr;
     unsigned short* att16 = xn16 ? d->att16 : nullptr;
     unsigned short* ff16 = xn16 ? d->ff16 : nullptr;
+    // ... and the LayerNorms between the GEMMs are FOLDED into them (no launch of their own): the GEMMs that write the
+    // residual stream x (attn_proj, mlp_proj; the embedding for layer 0) also leave x as 16 bit in xn16 and per-row
+    // (sum, sum of squares) slots in ln_stat; the GEMM behind the LayerNorm (c_attn, c_fc) multiplies the raw 16-bit x with
+    // gain-scaled weights and finishes rstd (acc - mean colsum) + shift in its epilogue (gemm_bf16.hip).  ln_f in front of
+    // the lm_head stays a launch: the slot reads cost its 3144 workgroups more than the one ln_rows per step
+    const bool fold = xn16 && d->ln_fold && d->ln_stat && d->layers[0].c_attn.wb_ln && D == 1024;
+    static const float cons_tag = 0.f;   // any non-null pointer: linear() substitutes the GEMM's own column sums
+    GemmLnFold prod{}, cons{};
+    prod.Yb16 = xn16; prod.stats_out = d->ln_stat;
+    cons.ln_stats = d->ln_stat; cons.ln_colsum = &cons_tag;
+    const GemmLnFold* pf = fold ? &prod : nullptr;
+    const GemmLnFold* cf = fold ? &cons : nullptr;
     hipLaunchKernelGGL(embed_ln_kernel, dim3(S), dim3(256), 0, st, d->wte, d->ids, d->max_len, d->step,
-                       d->layers[0].ln1_g, d->layers[0].ln1_b, d->x, d->xn, D, tok_override, xn16, d->f16(), d->pos_override_cur);
+                       d->layers[0].ln1_g, d->layers[0].ln1_b, d->x, d->xn, D, tok_override, xn16, d->f16(), d->pos_override_cur,
+                       fold ? d->ln_stat : (float*)nullptr);
     RGRG_LAUNCH_CHECK();
     for (int l = 0; l < d->n_layer; ++l) {
         const LayerW& w = d->layers[l];
         const float* ng = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_g : d->lnf_g;
         const float* nb = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_b : d->lnf_b;
-        if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, count, xn16))) return rc;
+        if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, count, xn16, nullptr, cf))) return rc;
         if ((rc = launch_attention(d, l, S, src, att16))) return rc;
-        if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count, att16))) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3((S + 3) / 4), dim3(256), 0, st, d->x, w.ln2_g, w.ln2_b, d->xn, D, xn16, d->f16(), S);
-        RGRG_LAUNCH_CHECK();
-        if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, count, xn16, ff16))) return rc;
-        if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->x, S, D, RGRG_ACT_NONE, count, ff16))) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3((S + 3) / 4), dim3(256), 0, st, d->x, ng, nb, d->xn, D, xn16, d->f16(), S);
-        RGRG_LAUNCH_CHECK();
+        if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count, att16, nullptr, pf))) return rc;
+        if (!fold) {
+            hipLaunchKernelGGL(ln_rows_kernel, dim3((S + 3) / 4), dim3(256), 0, st, d->x, w.ln2_g, w.ln2_b, d->xn, D, xn16, d->f16(), S);
+            RGRG_LAUNCH_CHECK();
+        }
+        if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, count, xn16, ff16, cf))) return rc;
+        if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->x, S, D, RGRG_ACT_NONE, count, ff16, nullptr, pf))) return rc;
+        if (!fold || l + 1 == d->n_layer) {
+            hipLaunchKernelGGL(ln_rows_kernel, dim3((S + 3) / 4), dim3(256), 0, st, d->x, ng, nb, d->xn, D, xn16, d->f16(), S);
+            RGRG_LAUNCH_CHECK();
+        }
     }
     if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, xn16))) return rc;
     if (beam) return RGRG_OK;  // the caller ranks the logits (beam_row_topk / beam_merge)
@@ -2749,6 +2818,27 @@ extern "C" int rgrg_decoder_set_precision(rgrg_decoder* d, int mode) {
         for (auto& w : d->layers) {
             if ((rc2 = mk(w.c_attn)) || (rc2 = mk(w.attn_proj)) || (rc2 = mk(w.c_fc)) || (rc2 = mk(w.mlp_proj))) return rc2;
         }
+        // the gain-scaled copies of the GEMMs that sit behind a LayerNorm (c_attn: ln_1, c_fc: ln_2, lm_head: ln_f)
+        if (const char* e = getenv("RGRG_LN_FOLD")) d->ln_fold = atoi(e) != 0;
+        if (d->ln_fold && d->D == 1024) {
+            auto mkln = [&](Lin& l, const float* g, const float* be) -> int {
+                if (l.wb_ln && l.wb_ln_f16 == d->f16()) return RGRG_OK;
+                int r;
+                if (!l.wb_ln && ((r = dmalloc(d, &l.wb_ln, (size_t)l.N * l.K * 2, false)) ||
+                                 (r = dmalloc(d, (void**)&l.cs16, (size_t)l.N * sizeof(float), false)) ||
+                                 (r = dmalloc(d, (void**)&l.c2_16, (size_t)l.N * sizeof(float), false))))
+                    return r;
+                l.wb_ln_f16 = d->f16();
+                hipLaunchKernelGGL(ln_fold16_kernel, dim3((l.N + 3) / 4), dim3(256), 0, d->stream, l.w, g, be, l.b,
+                                   reinterpret_cast<unsigned short*>(l.wb_ln), l.cs16, l.c2_16, l.N, l.K, d->f16());
+                RGRG_LAUNCH_CHECK();
+                return RGRG_OK;
+            };
+            if (!d->ln_stat && (rc2 = dmalloc(d, (void**)&d->ln_stat, (size_t)d->rows * 64 * sizeof(float), true))) return rc2;
+            for (auto& w : d->layers) {
+                if ((rc2 = mkln(w.c_attn, w.ln1_g, w.ln1_b)) || (rc2 = mkln(w.c_fc, w.ln2_g, w.ln2_b))) return rc2;
+            }
+        }
         RGRG_HIP(hipStreamSynchronize(d->stream));
     }
     // captured graphs bake the GEMM choice in: drop them
@@ -2784,6 +2874,14 @@ extern "C" int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, i
     unsigned short* xn16 = (bf && d->xn16) ? d->xn16 : nullptr;
     unsigned short* att16 = xn16 ? d->att16 : nullptr;
     unsigned short* ff16 = xn16 ? d->ff16 : nullptr;
+    // the folded-LayerNorm variants the step launches in the 16-bit mode
+    const bool fold = xn16 && d->ln_fold && d->ln_stat && d->layers[0].c_attn.wb_ln && D == 1024;
+    static const float cons_tag = 0.f;
+    GemmLnFold prod{}, cons{};
+    prod.Yb16 = xn16; prod.stats_out = d->ln_stat;
+    cons.ln_stats = d->ln_stat; cons.ln_colsum = &cons_tag;
+    const GemmLnFold* pf = fold ? &prod : nullptr;
+    const GemmLnFold* cf = fold ? &cons : nullptr;
     int rc = RGRG_OK;
     float tg = 0.f, ta = 0.f;
     d->gemm_bytes_per_step = 0; d->gemm_flops_per_step = 0.0; d->gemm_launches_per_step = 0;
@@ -2797,10 +2895,10 @@ extern "C" int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, i
                 if ((rc = enqueue_layer_gemms(d, l, S, c, nullptr, d->x, d->x2, 1))) break;
                 continue;
             }
-            if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, c, xn16))) break;
-            if ((rc = linear(d, w.attn_proj, d->att, d->x, d->h1, S, D, RGRG_ACT_NONE, c, att16))) break;
-            if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, c, xn16, ff16))) break;
-            if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->h1, S, D, RGRG_ACT_NONE, c, ff16))) break;
+            if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, c, xn16, nullptr, cf))) break;
+            if ((rc = linear(d, w.attn_proj, d->att, d->x, d->h1, S, D, RGRG_ACT_NONE, c, att16, nullptr, pf))) break;
+            if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, c, xn16, ff16, cf))) break;
+            if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->h1, S, D, RGRG_ACT_NONE, c, ff16, nullptr, pf))) break;
         }
         if (!rc && fused) {
             DirectArgs h{};

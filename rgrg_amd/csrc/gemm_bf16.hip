@@ -18,6 +18,14 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
+// optional LayerNorm-fold operands of launch_gemm_bf16w_ex (see GemmBf16Params)
+struct GemmLnFold {
+    void* Yb16 = nullptr;
+    float* stats_out = nullptr;
+    const float* ln_stats = nullptr;
+    const float* ln_colsum = nullptr;
+};
+
 struct GemmBf16Params {
     const float* A;    // fp32 activations (rounded to bf16 while staged) ...
     const u16* A16;    // ... or activations already rounded to bf16 by their producer (A16 kernels)
@@ -33,7 +41,20 @@ struct GemmBf16Params {
     int cH = 0, cW = 0, cCin = 0, cKH = 0, cKW = 0, cStride = 1, cPad = 0, cOH = 0, cOW = 0;
     const u16* R16 = nullptr;  // residual as bf16 [M, ldy] (CONV: the bottleneck's identity branch)
     int f16 = 0;               // the 16-bit type of A16 / Wb / Y16 / R16: 0 = bf16, 1 = IEEE fp16 (common.h)
+    // LayerNorm folded around the GEMMs of the decode step (LDS-DMA kernel, decoder.hip enqueue_step):
+    //  * producer side (the GEMMs that write the residual stream x, N = the normalised width = 1024): besides Y (fp32) the
+    //    result is stored as 16 bit in Yb16 [M, ldy] and every 32-column block leaves its per-row (sum, sum of squares) in
+    //    stats_out [M][32][2];
+    //  * consumer side (the GEMM behind the LayerNorm, K = 1024): A16 is the RAW 16-bit x, Wb holds gain-scaled weights, and
+    //    the epilogue applies  rstd_m * (acc - mean_m * colsum_n) + shift_n  with mean / rstd of row m reduced (fixed order)
+    //    from ln_stats [M][32][2]; colsum_n = the sum over k of the ROUNDED scaled weights, shift_n = bias + beta . W.
+    u16* Yb16 = nullptr;
+    float* stats_out = nullptr;
+    const float* ln_stats = nullptr;
+    const float* ln_colsum = nullptr;
 };
+
+constexpr float LN_EPS16 = 1e-5f;   // nn.LayerNorm(eps=1e-5) of GPT-2
 
 constexpr int BK16 = 64;                 // k per tile
 constexpr int LDB = (BK16 * 2 + 16) / 2;  // padded LDS row in bf16 elements (144 B)
@@ -329,7 +350,10 @@ __device__ __forceinline__ void glds_compute(const unsigned char* sa, const unsi
 // (oy * stride + kh - pad, ox * stride + kw - pad): still one contiguous 128-byte line per row, so the LDS-DMA path is
 // unchanged; only the per-lane source offset is recomputed per K tile (tap = kt * 64 / Cin, a handful of integer
 // instructions), and taps outside the image read the zero line that precedes the tensor.
-template <int BM, int BN, int NST, bool CONV, bool F16>
+// LNF: 0 plain; 1 producer of a folded LayerNorm (Yb16 + stats_out); 2 consumer (ln_stats + ln_colsum) - GemmBf16Params.
+// Compile-time so that the plain kernel carries none of it (as runtime branches the conditional loads made hipcc drain
+// the whole operand prologue - vmcnt(0) - at the join in front of the K loop of EVERY variant).
+template <int BM, int BN, int NST, bool CONV, bool F16, int LNF>
 __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Params p, const int mtiles, const int ntiles) {
     constexpr int BK = 64;
     constexpr int MI = BM / 64, NI = BN / 64;   // 32x32 MFMA blocks per wave
@@ -389,9 +413,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
                 const bool in_ = (unsigned)iy_ < (unsigned)p.cH && (unsigned)ix_ < (unsigned)p.cW;                     \
                 va[j] = (in_ ? 256 + (cpix[j] + iy_ * p.cW + ix_) * p.cCin * 2 + c0_ * 2 : 0) + cswz[j];               \
             }                                                                                                          \
-            glds_issue<BM, LA, LB, NST * 4 + 2 + (F16 ? 1 : 0)>(abase, wbase, glds_smem + (STAGE_) * STAGE + wave * 1024, va, vb, 0, (KT_) * (BK * 2)); \
+            glds_issue<BM, LA, LB, LNF * 64 + NST * 4 + 2 + (F16 ? 1 : 0)>(abase, wbase, glds_smem + (STAGE_) * STAGE + wave * 1024, va, vb, 0, (KT_) * (BK * 2)); \
         } else {                                                                                                       \
-            glds_issue<BM, LA, LB, NST * 4 + (F16 ? 1 : 0)>(abase, wbase, glds_smem + (STAGE_) * STAGE + wave * 1024, va, vb, (KT_) * (BK * 2),       \
+            glds_issue<BM, LA, LB, LNF * 64 + NST * 4 + (F16 ? 1 : 0)>(abase, wbase, glds_smem + (STAGE_) * STAGE + wave * 1024, va, vb, (KT_) * (BK * 2),       \
                                             (KT_) * (BK * 2));                                                         \
         }                                                                                                              \
     }
@@ -415,15 +439,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
     // counted vmcnt waits of the pipeline below are unaffected.  In-place residual (R == Y) is fine: an element is read and
     // written by the same thread only.)
     const int ccol = lane & 31, crow4 = 4 * (lane >> 5);
-    float sh_pre[MI][NI];
+    float sh_pre[MI][NI], cs_pre[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int colc = min(n0 + wn * (BN / 2) + ni * 32 + ccol, p.N - 1);
             sh_pre[mi][ni] = p.shift ? p.shift[colc] : 0.f;
+            cs_pre[mi][ni] = LNF == 2 ? p.ln_colsum[colc] : 0.f;
         }
-    constexpr bool PRE_R = MI * NI == 1;
+    constexpr bool PRE_R = MI * NI == 1 && LNF != 2;   // (a consumer of a folded LayerNorm has no residual: the launcher checks)
     float rv_pre[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) rv_pre[r] = 0.f;
@@ -437,6 +462,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
                 rv_pre[r] = p.R[(size_t)row * p.ldy + colc];
             }
         }
+    }
+
+    // consumer of a folded LayerNorm: the (sum, sum of squares) slots of this tile's rows, requested ahead of the operand
+    // stream like the other epilogue operands (the oldest loads: the counted waits of the pipeline are unaffected) and not
+    // looked at before the K loop is through - reduced in front of the loop they held up its first barrier by a cold miss.
+    // 256 / BM threads share a row, each adds its slots in index order.
+    constexpr int TPR = 256 / BM, PER = 32 / TPR;
+    f32x4 lsq[PER / 2];
+    if constexpr (LNF == 2) {
+        const int srow = min(m0 + tid / TPR, p.M - 1);
+        const f32x4* sp = reinterpret_cast<const f32x4*>(p.ln_stats + ((size_t)srow * 32 + (tid % TPR) * PER) * 2);
+#pragma unroll
+        for (int j = 0; j < PER / 2; ++j) lsq[j] = sp[j];
     }
 
 #define RGRG_GLDS_COMPUTE(STAGE_)                                                                         \
@@ -471,6 +509,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
 #undef RGRG_GLDS_ISSUE
 #undef RGRG_GLDS_COMPUTE
 
+    // folded LayerNorm: (mean, rstd) of the tile's rows -> LDS behind the stages (the last stage may still be read by slower
+    // waves), from where the epilogue fetches the 16 rows of its C layout
+    float2* row_stat = reinterpret_cast<float2*>(glds_smem + NST * STAGE);   // [BM]
+    if constexpr (LNF == 2) {
+        float ls1 = 0.f, ls2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < PER / 2; ++j) { ls1 += lsq[j][0]; ls2 += lsq[j][1]; ls1 += lsq[j][2]; ls2 += lsq[j][3]; }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) { ls1 += __shfl_xor(ls1, o, 64); ls2 += __shfl_xor(ls2, o, 64); }
+        const float mean = ls1 * (1.0f / 1024.0f);
+        const float var = fmaxf(ls2 * (1.0f / 1024.0f) - mean * mean, 0.f);
+        if (tid % TPR == 0) row_stat[tid / TPR] = make_float2(mean, 1.0f / sqrtf(var + LN_EPS16));
+        __syncthreads();
+    }
+
     // epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  Residual reads use
     // clamped rows and are issued together; only the stores are predicated.  Offsets are 32-bit inside the tile's rows.
 #pragma unroll
@@ -484,32 +537,72 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
             float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) rv[r] = rv_pre[r];   // 64 x 64 tiles: the residual prefetched above (zeros otherwise)
-            if (!PRE_R && p.R) {
+            if (!PRE_R && LNF != 2 && p.R) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
                     rv[r] = p.R[(size_t)row * p.ldy + colc];
                 }
             }
-            if (p.R16) {
+            if (LNF != 2 && p.R16) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
                     rv[r] = from16<F16>(p.R16[(size_t)row * p.ldy + colc]);
                 }
             }
+            float vv[16];
+            if constexpr (LNF == 2) {
+                const float cs = cs_pre[mi][ni];
+                const int lrow0 = wm * (BM / 2) + mi * 32 + crow4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float2 st = row_stat[lrow0 + (r & 3) + 8 * (r >> 2)];
+                    vv[r] = apply_act_fast(st.y * (acc[mi][ni][r] - st.x * cs) + sh + rv[r], p.act);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vv[r] = apply_act_fast(acc[mi][ni][r] + sh + rv[r], p.act);
+            }
             if (col < p.N) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dr = (r & 3) + 8 * (r >> 2);
-                    const float v = apply_act_fast(acc[mi][ni][r] + sh + rv[r], p.act);
+                    const float v = vv[r];
                     if (rbase + dr < p.M) {
                         const size_t o = (size_t)rbase * p.ldy + col + (size_t)(dr * p.ldy);
                         if (p.Y16) p.Y16[o] = (u16)to16<F16>(v);
                         else if (p.N > 8192) __builtin_nontemporal_store(v, &p.Y[o]);  // logits: streamed, keep A / W in L2
                         else p.Y[o] = v;
+                        if constexpr (LNF == 1) p.Yb16[o] = (u16)to16<F16>(v);
                     }
                 }
+            }
+            if constexpr (LNF == 1) {
+                // per-row (sum, sum of squares) of this 32-column block: a halving butterfly over the 32 lanes that share the
+                // block's rows (16 -> 8 -> 4 -> 2 -> 1 rows per lane, then the pair), fixed order.  (Written with constant
+                // steps: as nested loops hipcc kept the arrays indexed dynamically - ~900 v_cndmask, 1.5 us per launch.)
+                float a1[16], a2[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { a1[r] = vv[r]; a2[r] = vv[r] * vv[r]; }
+#define RGRG_BFLY(H, BIT)                                                                         \
+                {                                                                                         \
+                    const bool up = (lane & (BIT)) != 0;                                                  \
+                    _Pragma("unroll") for (int i = 0; i < (H); ++i) {                                     \
+                        const float s1 = up ? a1[i] : a1[i + (H)], s2 = up ? a2[i] : a2[i + (H)];         \
+                        const float k1 = up ? a1[i + (H)] : a1[i], k2 = up ? a2[i + (H)] : a2[i];         \
+                        a1[i] = k1 + __shfl_xor(s1, (BIT), 64);                                           \
+                        a2[i] = k2 + __shfl_xor(s2, (BIT), 64);                                           \
+                    }                                                                                     \
+                }
+                RGRG_BFLY(8, 16) RGRG_BFLY(4, 8) RGRG_BFLY(2, 4) RGRG_BFLY(1, 2)
+#undef RGRG_BFLY
+                a1[0] += __shfl_xor(a1[0], 1, 64);
+                a2[0] += __shfl_xor(a2[0], 1, 64);
+                const int r = (lane >> 1) & 15, row = rbase + (r & 3) + 8 * (r >> 2);
+                if (!(lane & 1) && row < p.M && col < p.N)
+                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)row * 32 + (n0 + wn * (BN / 2) + ni * 32) / 32) * 2) =
+                        make_float2(a1[0], a2[0]);
             }
         }
 }
@@ -546,14 +639,11 @@ static int bf16_attr() {
 
 template <int BM, int BN, int NST>
 static int glds_attr() {
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST, false, false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, NST * (BM + BN) * 128));
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST, true, false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, NST * (BM + BN) * 128));
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST, false, true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, NST * (BM + BN) * 128));
-    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST, true, true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, NST * (BM + BN) * 128));
+    constexpr int lds = NST * (BM + BN) * 128 + BM * 8;
+#define RGRG_G_ATTR(...) RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST, __VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+    RGRG_G_ATTR(false, false, 0); RGRG_G_ATTR(true, false, 0); RGRG_G_ATTR(false, true, 0); RGRG_G_ATTR(true, true, 0);
+    RGRG_G_ATTR(false, false, 1); RGRG_G_ATTR(false, true, 1); RGRG_G_ATTR(false, false, 2); RGRG_G_ATTR(false, true, 2);
+#undef RGRG_G_ATTR
     return RGRG_OK;
 }
 template <int BM, int BN>
@@ -576,9 +666,11 @@ int init_gemm_bf16_attrs() {
 template <int BM, int BN, int NST>
 static int launch_glds_cfg(const GemmBf16Params& p, hipStream_t st) {
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
-#define RGRG_G_LAUNCH(CONV_, F16_) hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, NST, CONV_, F16_>), dim3(mtiles * ntiles), dim3(256), NST * (BM + BN) * 128, st, p, mtiles, ntiles)
-    if (p.cCin) { if (p.f16) RGRG_G_LAUNCH(true, true); else RGRG_G_LAUNCH(true, false); }
-    else { if (p.f16) RGRG_G_LAUNCH(false, true); else RGRG_G_LAUNCH(false, false); }
+#define RGRG_G_LAUNCH(CONV_, F16_, LNF_) hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, NST, CONV_, F16_, LNF_>), dim3(mtiles * ntiles), dim3(256), NST * (BM + BN) * 128 + BM * 8, st, p, mtiles, ntiles)
+    if (p.cCin) { if (p.f16) RGRG_G_LAUNCH(true, true, 0); else RGRG_G_LAUNCH(true, false, 0); }
+    else if (p.Yb16) { if (p.f16) RGRG_G_LAUNCH(false, true, 1); else RGRG_G_LAUNCH(false, false, 1); }
+    else if (p.ln_colsum) { if (p.f16) RGRG_G_LAUNCH(false, true, 2); else RGRG_G_LAUNCH(false, false, 2); }
+    else { if (p.f16) RGRG_G_LAUNCH(false, true, 0); else RGRG_G_LAUNCH(false, false, 0); }
 #undef RGRG_G_LAUNCH
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
@@ -625,11 +717,19 @@ static int launch_glds(const GemmBf16Params& p, int tile, hipStream_t st) {
 
 // A16 / Y16 (either may be null): bf16 activations in / out, see GemmBf16Params
 int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const float* shift, const float* R, float* Y, void* Y16,
-                         int M, int N, int K, int ldy, int act, hipStream_t st, int f16) {
+                         int M, int N, int K, int ldy, int act, hipStream_t st, int f16, const GemmLnFold* ln) {
     RGRG_CHECK_ARG((A || A16) && Wb && (Y || Y16) && M > 0 && N > 0 && K > 0 && K % (4 * BK16) == 0 && ldy >= N);  // 4 = depth NS
     GemmBf16Params p{A, reinterpret_cast<const u16*>(A16), reinterpret_cast<const u16*>(Wb), shift, R, Y,
                      reinterpret_cast<u16*>(Y16), M, N, K, ldy, act};
     p.f16 = f16 ? 1 : 0;
+    if (ln) {   // LayerNorm folded around the GEMM (GemmBf16Params): LDS-DMA kernel only
+        RGRG_CHECK_ARG(A16 && (size_t)128 * K * 2 < ((size_t)1 << 31));
+        RGRG_CHECK_ARG((ln->Yb16 != nullptr) != (ln->ln_colsum != nullptr));
+        RGRG_CHECK_ARG(!ln->Yb16 || (Y && ln->stats_out && N == 1024));
+        RGRG_CHECK_ARG(!ln->ln_colsum || (ln->ln_stats && K == 1024 && !R));
+        p.Yb16 = reinterpret_cast<u16*>(ln->Yb16); p.stats_out = ln->stats_out;
+        p.ln_stats = ln->ln_stats; p.ln_colsum = ln->ln_colsum;
+    }
     if (A16 && (size_t)128 * K * 2 < ((size_t)1 << 31)) return launch_glds(p, 0, st);  // both operands bf16: LDS-DMA kernel
     // fp32 activations (rounded to bf16 while they are staged through registers)
     const long tiles_big = (long)((M + 127) / 128) * ((N + 127) / 128);
@@ -638,7 +738,7 @@ int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const 
 
 int launch_gemm_bf16w(const float* A, const void* Wb, const float* shift, const float* R, float* Y, int M, int N, int K,
                       int ldy, int act, hipStream_t st, int f16) {
-    return launch_gemm_bf16w_ex(A, nullptr, Wb, shift, R, Y, nullptr, M, N, K, ldy, act, st, f16);
+    return launch_gemm_bf16w_ex(A, nullptr, Wb, shift, R, Y, nullptr, M, N, K, ldy, act, st, f16, nullptr);
 }
 
 __global__ __launch_bounds__(256) void bf16_to_f32_kernel(const u16* __restrict__ src, float* __restrict__ dst, size_t n, int f16) {
@@ -682,7 +782,7 @@ extern "C" int rgrg_linear_bf16_f32(const uint16_t* A16, const uint16_t* Wb, con
     int rc = init_gemm_bf16_attrs();
     if (rc) return rc;
     RGRG_CHECK_ARG(A16 && ((Y != nullptr) != (Y16 != nullptr)));
-    return launch_gemm_bf16w_ex(nullptr, A16, Wb, shift, R, Y, Y16, M, N, K, ldy, act, as_stream(stream), fp16);
+    return launch_gemm_bf16w_ex(nullptr, A16, Wb, shift, R, Y, Y16, M, N, K, ldy, act, as_stream(stream), fp16, nullptr);
 }
 
 extern "C" int rgrg_debug_linear_bf16_tile(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
