@@ -303,59 +303,65 @@ __global__ void prefix_counts_kernel(const int* __restrict__ counts, int* __rest
 
 // ----------------------------------------------------------------------------------
 // RoIAlign(8x8, sampling_ratio 2, aligned=False) + AvgPool2d(8), NHWC.
-// Workgroup = (128-channel slab, RoI chunk, image).  The slab of the WHOLE feature
-// map (FH*FW positions x 128 channels fp32 = 128 KiB at 16x16) is staged in LDS once
-// and every RoI of the chunk is then served from LDS: 16 weighted ds_read_b128 per
-// output float4, output rows written as 512-B coalesced runs in [bin][channel] order.
+// Workgroup = (64-channel slab, 32 RoIs, image), 512 threads, TWO per CU (the slab of the WHOLE feature map - FH*FW
+// positions x 64 channels fp32 = 64 KiB at 16x16 - plus 12 KiB of sampling tables is 76 KiB of LDS): while one stages its
+// slab the other computes.  A 16-lane group owns ONE RoI (all 64 bins of its 4 channels per lane): 32 RoIs in flight per
+// workgroup, no barrier inside, the 8x8 average stays in registers; 16 weighted ds_read_b128 per output float4, output
+// rows written as 256-B runs in [bin][channel] order.  (Rounds 1-3: a 128-channel slab with 1024 threads, one workgroup
+// per CU, RoIs dealt out in 32 even chunks per image - 26 of 32 lane groups busy at 831 RoIs and nobody computing while a
+// slab was staged; measured 0.39 / 0.21 of HBM for fp32 / 16-bit maps.  The arithmetic - VALU - bounds this kernel, not
+// the stores: see DESIGN.md.)
 // ----------------------------------------------------------------------------------
-// Sampling tables of one RoI: per y / x sample (bin*2 + sample) one 16-byte record
-// {lo, hi (int bits: BYTE offsets of that row / column inside the LDS slab: y * FW * 512, x * 512), l, h}; a sample
-// outside the map ("dead") gets l = h = 0, so all four of its bilinear weights are exactly 0 and it adds exactly 0 -
-// same result as skipping it.  (Round 4: the records carry byte offsets, so a corner address is one add - the inner
-// loop is VALU bound, ~150 instructions per 4-channel bin of which a third was address arithmetic.)
+// Sampling tables of one RoI, per y / x sample (bin*2 + sample):
+//   y: 8 bytes  {lo (BYTE offset of the row in the slab: y * FW * 256; bit 31 = dead), l}
+//   x: 16 bytes {lo (byte offset of the column: x * 256) as int bits, l, h, -}
+// h = 1 - l as torchvision computes it; a sample outside the map ("dead") gets l = h = 0, so all four of its bilinear
+// weights are exactly 0 and it adds exactly 0 - same result as skipping it.  The HIGH neighbour is not stored: it is always
+// lo + one column / one row.  At the right / bottom border torchvision uses hi = lo with l = 0, i.e. the high taps carry
+// weight 0; here they read the next position (the next row's first column, or the finite table words behind the slab)
+// and 0 * finite is the same 0: four address adds per bin instead of sixteen, the rest are instruction offsets.
 struct RoiTables {
-    f32x4 y[16];
+    uint2 y[16];
     f32x4 x[16];
 };
-constexpr int ROI_THREADS = 1024;  // 16 waves per CU hide the LDS latency of the 16-tap gathers
-constexpr int ROI_SUB = 32;        // RoIs per sub-chunk = 32-lane groups per workgroup: all processed concurrently
+constexpr int ROI_THREADS = 512;   // 8 waves; two workgroups per CU
+constexpr int ROI_SUB = 32;        // RoIs per workgroup = 16-lane groups
 
 // OUT16 (1 bf16, 2 fp16; 0 = fp32 maps): the [roi][bin][channel] maps are stored as 16-bit values (round to nearest even) - under torch.autocast the box head
 // runs in reduced precision, and fc6 (81 % of the detector's FLOPs) then reads its A operand through the LDS-DMA GEMM at
 // half the bytes; the 8x8 average (top_region_features) is still formed from the unrounded values.
-template <int OUT16>
-__global__ __launch_bounds__(ROI_THREADS) void roi_align_avg_kernel(const float* __restrict__ feat,
+// RSB: bytes per slab row when known at compile time (FW = 16: 4096; the tap offsets are then instruction immediates), 0 = FW * 256 at run time.
+template <int OUT16, int RSB>
+__global__ __launch_bounds__(ROI_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void roi_align_avg_kernel(const float* __restrict__ feat,
                                                             const float* __restrict__ proposals,
                                                             const int* __restrict__ offsets, float* __restrict__ out,
                                                             float* __restrict__ pooled, int FH, int FW, int C,
                                                             int max_props, float spatial_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int npos = FH * FW;
-    float* slab = reinterpret_cast<float*>(smem_raw);                          // [npos][128]
-    RoiTables* tabs = reinterpret_cast<RoiTables*>(slab + (size_t)npos * 128);  // [ROI_SUB]
+    float* slab = reinterpret_cast<float*>(smem_raw);                         // [npos][64]
+    RoiTables* tabs = reinterpret_cast<RoiTables*>(slab + (size_t)npos * 64);  // [ROI_SUB]; also what taps past the slab's end read
     const int tid = threadIdx.x;
-    const int slab_i = blockIdx.x, chunk = blockIdx.y, nchunk = gridDim.y, b = blockIdx.z;
+    const int slab_i = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
     const int off = offsets[b], nb = offsets[b + 1] - off;
-    const int per = (nb + nchunk - 1) / nchunk;
-    const int r0 = chunk * per, r1 = (r0 + per < nb) ? r0 + per : nb;
-    if (r0 >= r1) return;
+    const int s0 = chunk * ROI_SUB;
+    if (s0 >= nb) return;
+    const int ns = (nb - s0 < ROI_SUB) ? nb - s0 : ROI_SUB;
 
-    const float* fsrc = feat + (size_t)b * npos * C + slab_i * 128;
-    for (int i = tid; i < npos * 32; i += ROI_THREADS) {
-        const int pos = i >> 5, c4 = i & 31;
-        *reinterpret_cast<f32x4*>(slab + pos * 128 + c4 * 4) =
+    const float* fsrc = feat + (size_t)b * npos * C + slab_i * 64;
+    for (int i = tid; i < npos * 16; i += ROI_THREADS) {
+        const int pos = i >> 4, c4 = i & 15;
+        *reinterpret_cast<f32x4*>(slab + pos * 64 + c4 * 4) =
             *reinterpret_cast<const f32x4*>(fsrc + (size_t)pos * C + c4 * 4);
     }
-    // a 32-lane group owns ONE RoI (all 64 bins of its 4 channels): 32 RoIs in flight per workgroup, no
-    // barrier inside the RoI loop, the 8x8 average stays in registers
-    const int c4 = tid & 31, grp = tid >> 5;
-    for (int s0 = r0; s0 < r1; s0 += ROI_SUB) {
-        const int ns = (r1 - s0 < ROI_SUB) ? r1 - s0 : ROI_SUB;
-        __syncthreads();  // previous sub-chunk's tables are no longer read (also orders the slab fill)
-        for (int i = tid; i < ns * 32; i += ROI_THREADS) {
-            const int rr = i >> 5, t32 = i & 31;
-            const int ax = t32 >> 4;  // 0: y, 1: x
-            const int sidx = t32 & 15, bin = sidx >> 1, g = sidx & 1;
+    // all 32 tables are written (zeros behind the last RoI): the words behind the slab must be finite
+    for (int i = tid; i < ROI_SUB * 32; i += ROI_THREADS) {
+        const int rr = i >> 5, t32 = i & 31;
+        const int ax = t32 >> 4;  // 0: y, 1: x
+        const int sidx = t32 & 15, bin = sidx >> 1, g = sidx & 1;
+        int lo = 0, dead = 1;
+        float l = 0.f;
+        if (rr < ns) {
             const float* pb = proposals + ((size_t)b * max_props + s0 + rr) * 4;
             const float start = (ax ? pb[0] : pb[1]) * spatial_scale;
             const float end = (ax ? pb[2] : pb[3]) * spatial_scale;
@@ -363,73 +369,99 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_avg_kernel(const float*
             const float bsz = roi / 8.0f;
             const int size = ax ? FW : FH;
             float v = start + (float)bin * bsz + ((float)g + 0.5f) * bsz / 2.0f;
-            const int dead = (v < -1.0f || v > (float)size) ? 1 : 0;
+            dead = (v < -1.0f || v > (float)size) ? 1 : 0;
             v = fmaxf(v, 0.0f);
-            int lo = (int)v, hi;
-            if (lo >= size - 1) { lo = hi = size - 1; v = (float)lo; } else { hi = lo + 1; }
-            const float l = v - (float)lo;
-            f32x4 rec;
-            const int step = ax ? 512 : FW * 512;   // bytes per column / per row of the [pos][128 floats] slab
-            rec[0] = __int_as_float(lo * step); rec[1] = __int_as_float(hi * step);
-            rec[2] = dead ? 0.0f : l; rec[3] = dead ? 0.0f : 1.0f - l;
-            if (ax) tabs[rr].x[sidx] = rec; else tabs[rr].y[sidx] = rec;
+            lo = (int)v;
+            if (lo >= size - 1) { lo = size - 1; v = (float)lo; }
+            l = v - (float)lo;
         }
-        __syncthreads();
-        const unsigned char* slab_lane = reinterpret_cast<const unsigned char*>(slab) + c4 * 16;   // this lane's 4 channels of position 0
-        for (int rr = grp; rr < ns; rr += ROI_THREADS / 32) {
-            const RoiTables& T = tabs[rr];
-            const int r = s0 + rr;
-            const size_t oidx = (size_t)(off + r) * 64 * C + slab_i * 128 + c4 * 4;
-            float* obase = out + oidx;
-            unsigned short* obase16 = reinterpret_cast<unsigned short*>(out) + oidx;
-            f32x4 total = {0.f, 0.f, 0.f, 0.f};
-            for (int ph = 0; ph < 8; ++ph) {
-                f32x4 psum = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 ty0 = T.y[ph * 2], ty1 = T.y[ph * 2 + 1];
-                for (int pw = 0; pw < 8; ++pw) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    const f32x4 tx0 = T.x[pw * 2], tx1 = T.x[pw * 2 + 1];
-#pragma unroll
-                    for (int iy = 0; iy < 2; ++iy) {
-                        const f32x4 ty = iy ? ty1 : ty0;
-                        const int ylo = __float_as_int(ty[0]), yhi = __float_as_int(ty[1]);
-                        const float ly = ty[2], hy = ty[3];
-#pragma unroll
-                        for (int ix = 0; ix < 2; ++ix) {
-                            const f32x4 tx = ix ? tx1 : tx0;
-                            const int xlo = __float_as_int(tx[0]), xhi = __float_as_int(tx[1]);
-                            const float lx = tx[2], hx = tx[3];
-                            const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-                            const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab_lane + ylo + xlo);
-                            const f32x4 v2 = *reinterpret_cast<const f32x4*>(slab_lane + ylo + xhi);
-                            const f32x4 v3 = *reinterpret_cast<const f32x4*>(slab_lane + yhi + xlo);
-                            const f32x4 v4 = *reinterpret_cast<const f32x4*>(slab_lane + yhi + xhi);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float val = w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
-                                acc[e] = acc[e] + val;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { acc[e] = acc[e] / 4.0f; psum[e] += acc[e]; }
-                    if constexpr (OUT16) {
-                        uint2 pk;
-                        pk.x = to16<OUT16 == 2>(acc[0]) | (to16<OUT16 == 2>(acc[1]) << 16);
-                        pk.y = to16<OUT16 == 2>(acc[2]) | (to16<OUT16 == 2>(acc[3]) << 16);
-                        *reinterpret_cast<uint2*>(obase16 + (size_t)(ph * 8 + pw) * C) = pk;
-                    } else {
-                        *reinterpret_cast<f32x4*>(obase + (size_t)(ph * 8 + pw) * C) = acc;
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) total[e] += psum[e];  // row sums added in row order (same association as before)
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) total[e] = total[e] / 64.0f;
-            *reinterpret_cast<f32x4*>(pooled + (size_t)(off + r) * C + slab_i * 128 + c4 * 4) = total;
+        if (ax) {
+            f32x4 rec;
+            rec[0] = __int_as_float(lo * 256); rec[1] = dead ? 0.0f : l; rec[2] = dead ? 0.0f : 1.0f - l; rec[3] = 0.0f;
+            tabs[rr].x[sidx] = rec;
+        } else {
+            tabs[rr].y[sidx] = make_uint2((unsigned)(lo * FW * 256) | (dead ? 0x80000000u : 0u), __float_as_uint(l));
         }
     }
+    __syncthreads();
+    const int c4 = tid & 15, rr = tid >> 4;
+    if (rr >= ns) return;
+    const int rsb = RSB ? RSB : FW * 256;
+    const unsigned char* slab_lane = reinterpret_cast<const unsigned char*>(slab) + c4 * 16;   // this lane's 4 channels of position 0
+    const RoiTables& T = tabs[rr];
+    const int r = s0 + rr;
+    const size_t oidx = (size_t)(off + r) * 64 * C + slab_i * 64 + c4 * 4;
+    float* obase = out + oidx;
+    unsigned short* obase16 = reinterpret_cast<unsigned short*>(out) + oidx;
+    f32x4 total = {0.f, 0.f, 0.f, 0.f};
+    for (int ph = 0; ph < 8; ++ph) {
+        f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+        int ylo[2];
+        float ly[2], hy[2];
+#pragma unroll
+        for (int iy = 0; iy < 2; ++iy) {
+            const uint2 ry = T.y[ph * 2 + iy];
+            const bool dead = (ry.x >> 31) != 0;
+            const float l = __uint_as_float(ry.y);
+            ylo[iy] = (int)(ry.x & 0x7fffffffu);
+            ly[iy] = dead ? 0.0f : l;
+            hy[iy] = dead ? 0.0f : 1.0f - l;
+        }
+        // The column records of bin pw + 1 are fetched while bin pw is computed, and the 16 taps of a bin are all requested
+        // before the first product (pinned with a scheduling barrier).
+        f32x4 tx0 = T.x[0], tx1 = T.x[1];
+#pragma unroll 1
+        for (int pw = 0; pw < 8; ++pw) {
+            const int pn = (pw + 1) & 7;
+            const f32x4 nx0 = T.x[pn * 2], nx1 = T.x[pn * 2 + 1];
+            f32x4 v[16];
+#pragma unroll
+            for (int iy = 0; iy < 2; ++iy) {
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix) {
+                    const unsigned char* a = slab_lane + ylo[iy] + __float_as_int(ix ? tx1[0] : tx0[0]);
+                    const int k = (iy * 2 + ix) * 4;
+                    v[k + 0] = *reinterpret_cast<const f32x4*>(a);
+                    v[k + 1] = *reinterpret_cast<const f32x4*>(a + 256);
+                    v[k + 2] = *reinterpret_cast<const f32x4*>(a + rsb);
+                    v[k + 3] = *reinterpret_cast<const f32x4*>(a + rsb + 256);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (without it: 0.470 instead of 0.488 of HBM, profiles/r04_roialign_variants.log)
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int iy = 0; iy < 2; ++iy) {
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix) {
+                    const f32x4 tx = ix ? tx1 : tx0;
+                    const float lx = tx[1], hx = tx[2];
+                    const float w1 = hy[iy] * hx, w2 = hy[iy] * lx, w3 = ly[iy] * hx, w4 = ly[iy] * lx;
+                    const int k = (iy * 2 + ix) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float val = w1 * v[k][e] + w2 * v[k + 1][e] + w3 * v[k + 2][e] + w4 * v[k + 3][e];
+                        acc[e] = acc[e] + val;
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] = acc[e] / 4.0f; psum[e] += acc[e]; }
+            if constexpr (OUT16) {
+                uint2 pk;
+                pk.x = to16<OUT16 == 2>(acc[0]) | (to16<OUT16 == 2>(acc[1]) << 16);
+                pk.y = to16<OUT16 == 2>(acc[2]) | (to16<OUT16 == 2>(acc[3]) << 16);
+                *reinterpret_cast<uint2*>(obase16 + (size_t)(ph * 8 + pw) * C) = pk;
+            } else {
+                *reinterpret_cast<f32x4*>(obase + (size_t)(ph * 8 + pw) * C) = acc;
+            }
+            tx0 = nx0; tx1 = nx1;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) total[e] += psum[e];  // row sums added in row order (same association as before)
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) total[e] = total[e] / 64.0f;
+    *reinterpret_cast<f32x4*>(pooled + (size_t)(off + r) * C + slab_i * 64 + c4 * 4) = total;
 }
 
 // ----------------------------------------------------------------------------------
@@ -714,29 +746,33 @@ extern "C" int rgrg_rpn_proposals_f32(const float* head_out, const float* anchor
 static int roi_align_launch(const float* feat, const float* proposals, const int32_t* offsets, void* out, int out16,
                             float* pooled, int B, int FH, int FW, int C, int max_props, int R_total,
                             float spatial_scale, void* stream) {
-    RGRG_CHECK_ARG(feat && proposals && offsets && out && pooled && B > 0 && C % 128 == 0);
-    const size_t lds = (size_t)FH * FW * 128 * 4 + ROI_SUB * sizeof(RoiTables);
-    RGRG_CHECK_ARG(lds <= 160 * 1024);
+    RGRG_CHECK_ARG(feat && proposals && offsets && out && pooled && B > 0 && C % 64 == 0 && FH > 0 && FW > 0);
+    const size_t lds = (size_t)FH * FW * 64 * 4 + ROI_SUB * sizeof(RoiTables);
+    // taps of the last row / column read up to one row + one column past the slab: that must stay inside the tables
+    RGRG_CHECK_ARG(lds <= 160 * 1024 && (size_t)(FW + 2) * 256 <= ROI_SUB * sizeof(RoiTables));
     if (R_total <= 0) return RGRG_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_avg_kernel<0>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_avg_kernel<1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_avg_kernel<2>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define ROI_ATTR(O_, R_) RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_avg_kernel<O_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        ROI_ATTR(0, 4096); ROI_ATTR(1, 4096); ROI_ATTR(2, 4096); ROI_ATTR(0, 0); ROI_ATTR(1, 0); ROI_ATTR(2, 0);
+#undef ROI_ATTR
         attr_set = true;
     }
-    const int slabs = C / 128;
-    // chunks of <= 32 RoIs (one per 32-lane group); chunks beyond an image's RoI count exit immediately
+    const int slabs = C / 64;
+    // chunks of 32 RoIs (one per 16-lane group); chunks beyond an image's RoI count exit immediately
     int nchunk = (max_props + ROI_SUB - 1) / ROI_SUB;
     if (nchunk < 1) nchunk = 1;
-#define ROI_LAUNCH(O_) hipLaunchKernelGGL(roi_align_avg_kernel<O_>, dim3(slabs, nchunk, B), dim3(ROI_THREADS), lds, as_stream(stream), feat, proposals, \
-                                          offsets, reinterpret_cast<float*>(out), pooled, FH, FW, C, max_props, spatial_scale)
-    if (out16 == 2) ROI_LAUNCH(2);
-    else if (out16 == 1) ROI_LAUNCH(1);
-    else ROI_LAUNCH(0);
+#define ROI_LAUNCH(O_, R_) hipLaunchKernelGGL((roi_align_avg_kernel<O_, R_>), dim3(slabs, nchunk, B), dim3(ROI_THREADS), lds, as_stream(stream), feat, proposals, \
+                                              offsets, reinterpret_cast<float*>(out), pooled, FH, FW, C, max_props, spatial_scale)
+    if (FW == 16) {
+        if (out16 == 2) ROI_LAUNCH(2, 4096);
+        else if (out16 == 1) ROI_LAUNCH(1, 4096);
+        else ROI_LAUNCH(0, 4096);
+    } else {
+        if (out16 == 2) ROI_LAUNCH(2, 0);
+        else if (out16 == 1) ROI_LAUNCH(1, 0);
+        else ROI_LAUNCH(0, 0);
+    }
 #undef ROI_LAUNCH
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;

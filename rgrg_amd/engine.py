@@ -897,9 +897,20 @@ class HipEngine:
                                           "of this model (the cache lives in the HIP decoder)")
             dec = self._decoder
         if past_len + T > self._decoder_caps[1]:
-            raise NotImplementedError(f"the K/V cache of this call chain holds {self._decoder_caps[1]} tokens (sized when forward(use_cache=True) "
-                                      f"first ran: min(1024, what half of the free memory held for {S} rows)); a sequence of {past_len + T} "
-                                      "was requested")
+            # the chain outgrows the cache: a larger decoder (at least twice the slots, at most what the memory budget holds) takes
+            # over the cached keys / values; presents handed out so far keep their (old) tensor and would be adopted by copy
+            need = past_len + T
+            fit = self.cache_tokens_that_fit(S, max(cache_len, need))
+            if need > fit:
+                raise NotImplementedError(f"a K/V cache of {need} tokens for {S} rows does not fit in half of the free device memory "
+                                          f"({fit} tokens do)")
+            old = self._kv
+            dec = self._get_decoder(S, min(max(2 * self._decoder_caps[1], need), fit))
+            if past_len:
+                self._kv[:, :, :S, :, :1 + past_len].copy_(old[:, :, :S, :, :1 + past_len])
+                torch.cuda.current_stream(self.device).synchronize()   # the decoder's own stream reads the cache next
+            del old
+            self._cached = {"S": S, "tokens": past_len}
         _hip.check(self.lib.rgrg_decoder_set_precision(dec, 0), "rgrg_decoder_set_precision")
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
         f = None if past_len else feats.to(torch.float32).contiguous()

@@ -861,6 +861,12 @@ def test_incremental_forward_with_use_cache_reproduces_the_oracles_cached_steps(
     m = gpu_model("ragged")
     lm = m.language_model
     sd = synth_sd("ragged")
+    # start from a decoder whose cache holds exactly the prompt (as a generate(max_length=3) would leave it): the chain below
+    # outgrows it, and the engine has to move the cached keys / values into a larger one
+    eng = m.engine()
+    eng.close()
+    eng._decoder_caps = (0, 0)
+    eng._get_decoder(3, 3)
     g = torch.Generator().manual_seed(21)
     feats = torch.randn((3, 1024), generator=g)
     prompt = torch.randint(0, 50000, (3, 3), generator=g)
