@@ -314,7 +314,8 @@ __global__ void prefix_counts_kernel(const int* __restrict__ counts, int* __rest
 // ----------------------------------------------------------------------------------
 // Sampling tables of one RoI, per y / x sample (bin*2 + sample):
 //   y: 8 bytes  {lo (BYTE offset of the row in the slab: y * FW * 256; bit 31 = dead), l}
-//   x: 16 bytes {lo (byte offset of the column: x * 256) as int bits, l, h, -}
+//   x: 16 bytes {h, l, lo (byte offset of the column: x * 256) as int bits, -}   ((h, l) is an aligned register pair: the four
+//      bilinear weights of a sample are two packed products)
 // h = 1 - l as torchvision computes it; a sample outside the map ("dead") gets l = h = 0, so all four of its bilinear
 // weights are exactly 0 and it adds exactly 0 - same result as skipping it.  The HIGH neighbour is not stored: it is always
 // lo + one column / one row.  At the right / bottom border torchvision uses hi = lo with l = 0, i.e. the high taps carry
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(ROI_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         }
         if (ax) {
             f32x4 rec;
-            rec[0] = __int_as_float(lo * 256); rec[1] = dead ? 0.0f : l; rec[2] = dead ? 0.0f : 1.0f - l; rec[3] = 0.0f;
+            rec[0] = dead ? 0.0f : 1.0f - l; rec[1] = dead ? 0.0f : l; rec[2] = __int_as_float(lo * 256); rec[3] = 0.0f;
             tabs[rr].x[sidx] = rec;
         } else {
             tabs[rr].y[sidx] = make_uint2((unsigned)(lo * FW * 256) | (dead ? 0x80000000u : 0u), __float_as_uint(l));
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(ROI_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             for (int iy = 0; iy < 2; ++iy) {
 #pragma unroll
                 for (int ix = 0; ix < 2; ++ix) {
-                    const unsigned char* a = slab_lane + ylo[iy] + __float_as_int(ix ? tx1[0] : tx0[0]);
+                    const unsigned char* a = slab_lane + ylo[iy] + __float_as_int(ix ? tx1[2] : tx0[2]);
                     const int k = (iy * 2 + ix) * 4;
                     v[k + 0] = *reinterpret_cast<const f32x4*>(a);
                     v[k + 1] = *reinterpret_cast<const f32x4*>(a + 256);
@@ -434,13 +435,24 @@ __global__ __launch_bounds__(ROI_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 #pragma unroll
                 for (int ix = 0; ix < 2; ++ix) {
                     const f32x4 tx = ix ? tx1 : tx0;
-                    const float lx = tx[1], hx = tx[2];
-                    const float w1 = hy[iy] * hx, w2 = hy[iy] * lx, w3 = ly[iy] * hx, w4 = ly[iy] * lx;
+                    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                    const f32x2_t hl = {tx[0], tx[1]};                                   // (hx, lx)
+                    const f32x2_t w12 = f32x2_t{hy[iy], hy[iy]} * hl, w34 = f32x2_t{ly[iy], ly[iy]} * hl;   // v_pk_mul_f32
+                    const float w1 = w12[0], w2 = w12[1], w3 = w34[0], w4 = w34[1];
                     const int k = (iy * 2 + ix) * 4;
+                    if constexpr (OUT16) {
+                        // 16-bit maps (torch.autocast): the result is rounded to 11 / 8 bits anyway and the reference's own
+                        // GPU kernel contracts - fused multiply-adds, half the VALU work (this kernel is VALU / power bound)
+                        acc = __builtin_elementwise_fma(f32x4{w1, w1, w1, w1}, v[k], acc);
+                        acc = __builtin_elementwise_fma(f32x4{w2, w2, w2, w2}, v[k + 1], acc);
+                        acc = __builtin_elementwise_fma(f32x4{w3, w3, w3, w3}, v[k + 2], acc);
+                        acc = __builtin_elementwise_fma(f32x4{w4, w4, w4, w4}, v[k + 3], acc);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float val = w1 * v[k][e] + w2 * v[k + 1][e] + w3 * v[k + 2][e] + w4 * v[k + 3][e];
-                        acc[e] = acc[e] + val;
+                        for (int e = 0; e < 4; ++e) {   // torchvision's CPU order, unfused: bit-exact with the oracle
+                            const float val = w1 * v[k][e] + w2 * v[k + 1][e] + w3 * v[k + 2][e] + w4 * v[k + 3][e];
+                            acc[e] = acc[e] + val;
+                        }
                     }
                 }
             }

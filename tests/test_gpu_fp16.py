@@ -128,9 +128,13 @@ def test_detector_under_fp16_autocast_close_to_fp32():
     pspan = p32["pred"].abs().max().item()
     perr = (p16["pred"] - p32["pred"]).abs().max().item()
     assert 0.0 < perr <= 5e-3 * pspan, (perr, pspan)
-    assert p16["pooled_maps"].dtype == torch.int16 and torch.equal(p16["pooled"], p32["pooled"])
-    # the stored maps ARE fp16 roundings of the fp32 maps
-    assert torch.equal(p16["pooled_maps"].view(torch.float16), p32["pooled_maps"].to(torch.float16))
+    # the 8x8 average is formed from the unrounded bins: fp32-accurate (the 16-bit variants of the kernel contract their
+    # multiply-adds - like the reference's own GPU kernel -, so not bit-identical to the unfused fp32 variant)
+    assert p16["pooled_maps"].dtype == torch.int16
+    assert torch.allclose(p16["pooled"], p32["pooled"], rtol=1e-5, atol=1e-6)
+    # the stored maps ARE fp16 roundings of fp32-accurate bins: within one fp16 ulp of the rounded fp32 maps, mostly identical
+    a16, b16 = p16["pooled_maps"].view(torch.float16).float(), p32["pooled_maps"].to(torch.float16).float()
+    assert bool(((a16 - b16).abs() <= 2.0 ** -10 * b16.abs().clamp(min=2.0 ** -14)).all()) and float((a16 == b16).float().mean()) > 0.99
     assert torch.equal(cd16, cd32)
     with torch.autocast("cuda", dtype=torch.float16):
         _, det_a, _, cd_a = m.object_detector(images)
