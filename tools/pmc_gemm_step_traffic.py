@@ -17,7 +17,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_traffic import per_kernel  # noqa: E402
 
 # glds instance -> launches per decode step at M = 923 (launch_glds heuristic, gemm_bf16.hip)
-STEP_MIX = {"<64, 64, 4, false>": 48, "<128, 64, 3, false>": 24, "<64, 64, 3, false>": 24, "<128, 128, 2, false>": 1}
+# (round 4: the kernel has two more template arguments - the 16-bit type and the LayerNorm-fold role; the micro-benchmark runs
+# the plain bf16 instances, the decode step their producer / consumer variants of the same tile - one more 16-bit store or a
+# 256-B statistics read per row on top of the same operand stream)
+STEP_MIX = {"<64, 64, 4, false, false, 0>": 48, "<128, 64, 3, false, false, 0>": 24, "<64, 64, 3, false, false, 0>": 24,
+            "<128, 128, 2, false, false, 0>": 1}
 
 
 def main(fetch_dir, write_dir, out):
