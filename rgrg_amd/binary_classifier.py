@@ -4,7 +4,7 @@
 (binary_classifier_region_selection.py:24-68) and, with its loss, inside the eval-mode
 ``forward()``; ``BinaryClassifierRegionAbnormal`` runs in ``forward()`` only
 (report_generation_model.py:67-69,104-106).  In ``train()`` mode both return only their loss, with a ``grad_fn``
-whose backward runs on the HIP kernels (DESIGN.md 6e).
+whose backward runs on the HIP kernels (DESIGN.md 7.4).
 """
 from __future__ import annotations
 

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16w_kernel(const GemmBf16Param
 //   * buffer descriptors are rebased to the tile (32-bit offsets stay small: fc6's A is 6.9 GB), rows past M / N read
 //     the last valid row (never stored);
 //   * tile id -> XCD-aware band (every XCD's L2 holds A plus one band of W), bijective for any tile count.
-// What bounds it (profiles/r03_gemm_bf16_bench_*.log, r03_pmc_gemm_bf16_v1.md): a workgroup spends about as
+// What bounds it (profiles/HISTORY.md 6c, profiles/r03_gemm_bf16_bench_*.log, r03_pmc_gemm_bf16_v1.md): a workgroup spends about as
 // long in its prologue (first tiles: HBM / cross-XCD latency) and epilogue as in its 16 K tiles, and a CU delivers
 // ~25-45 GB/s of operands to ONE workgroup whatever its wave organisation (4 waves, 8 waves as two K halves, 4 + 4 loader
 // waves, an L2-prefetch wave, K rotation, padded pitches: all measured within +-5 %, the prefetch wave -20 %).  What helps

@@ -151,7 +151,7 @@ class LanguageModel(EngineOwner):
         if self.training and torch.is_grad_enabled():
             # training pass: loss with a grad_fn; loss.backward() fills .grad of uk/uv/feature_space_transformation_nn
             # (what the reference trains in the decoder).  GPT-2's four dropout sites are active with self.dropout_p
-            # (0.1 as in the reference; 0 = deterministic), bf16 GEMMs under torch.autocast (DESIGN.md 6e).
+            # (0.1 as in the reference; 0 = deterministic), bf16 GEMMs under torch.autocast (DESIGN.md 7.4).
             self.sync_trainable_if_stale()
             loss = _TeacherForcedLoss.apply(self, ids2, am2, image_hidden_states, *self.trainable_parameters())
         else:

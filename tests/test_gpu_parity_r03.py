@@ -130,7 +130,7 @@ def test_bf16_beam_search_130_tokens_against_bf16_oracle():
     assert res.returncode == 0, res.stderr[-2000:]
     r = json.loads(res.stdout.strip().splitlines()[-1])
     assert r["shape"] == [12, 130], r
-    # bf16 noise (two correct bf16 evaluations differ by ~1-2 % of the logit range after 24 blocks): the
+    # bf16 noise (two correct bf16 evaluations differ by ~1-2 % of the logit range after 24 blocks, DESIGN 7.2, profiles/HISTORY.md 6c): the
     # top-2*nb membership is tested with a 3 % margin and must hold almost everywhere, equally in the later chunks
     assert r["inside"] >= 0.97 and r["inside_second_chunk"] >= 0.97 and r["inside_loop_chunk"] >= 0.97, r
     assert r["last_err"] <= 2e-2 * r["range"], r

@@ -1,5 +1,5 @@
 """The persistent decode kernel (csrc/persistent.inc; opt-in through RGRG_PERSISTENT - measured slower than the launch chain,
-DESIGN.md section 5, so never the default) against the same reference-generated fixtures and the launch chain itself:
+DESIGN.md 5.3, so never the default) against the same reference-generated fixtures and the launch chain itself:
 the phases repeat the launch plan's arithmetic per workgroup, so token ids are bit-exact and logits agree to fp32 rounding
 of differently contracted epilogues (<= 1e-5 on logits of O(1)).  Modes: 3 = attention .. mlp_proj of a layer in one
 launch (three grid barriers), 5 = a whole decode step in one launch (24 x 5 + 1 barriers, lm_head' and arg-max inside)."""
