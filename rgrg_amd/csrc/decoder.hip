@@ -441,9 +441,56 @@ __device__ __forceinline__ float group16_sum_dpp(float v) {  // sum over the 16 
     return v;
 }
 
-// ATT_NI = keys per group per chunk: 9 (one chunk up to 144 keys, everything in flight at once) when the grid is a
-// fraction of a wave of workgroups per CU and the kernel is latency bound; 2 when thousands of workgroups queue up
-// (throughput bound: fewer registers -> more resident workgroups, no loads wasted on keys beyond nkeys)
+// one chunk of 16 * NI keys starting at `base` (see the kernel below)
+template <bool HAS_SRC, int NI>
+__device__ __forceinline__ void attn_chunk(const float* __restrict__ kc, const float* __restrict__ vc, const int* __restrict__ srow, int s,
+                                           int hd, int H, int T, int base, int nkeys, int slot, int wave, int g, int d4,
+                                           const f32x4& q4, const f32x4& k4, const f32x4& v4, float& m, float& l, f32x4& acc) {
+    int rowi[NI];  // beam search: the table entries are the oldest loads of the chunk, so that waiting for them waits for nothing else
+#pragma unroll
+    for (int i = 0; i < NI; ++i) rowi[i] = HAS_SRC ? srow[min(base + (i * 4 + wave) * 4 + g, nkeys - 1)] : s;
+    // slot t + 1 of the table is stale: that key comes from k4 / v4 below
+    f32x4 kk[NI], vv[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int jc = min(base + (i * 4 + wave) * 4 + g, nkeys - 1);
+        const size_t off = (((size_t)rowi[i] * H + hd) * T + jc) * 64 + d4 * 4;
+        kk[i] = *reinterpret_cast<const f32x4*>(kc + off);
+        vv[i] = *reinterpret_cast<const f32x4*>(vc + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // all 2 * NI loads are in flight before the first dot product waits
+    float sc[NI];
+    float cmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int j = base + (i * 4 + wave) * 4 + g;
+        if (j == slot) { kk[i] = k4; vv[i] = v4; }  // selects, not branches: the new token's key / value
+        const float dot = group16_sum_dpp((q4[0] * kk[i][0] + q4[1] * kk[i][1]) + (q4[2] * kk[i][2] + q4[3] * kk[i][3]));
+        sc[i] = j < nkeys ? dot / 8.0f : -INFINITY;
+        cmax = fmaxf(cmax, sc[i]);
+    }
+    const float m_new = fmaxf(m, cmax);
+    const float scale = (m == -INFINITY) ? 0.f : expf(m - m_new);  // 1 on the first chunk's empty start, never NaN
+    l *= scale;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] *= scale;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int j = base + (i * 4 + wave) * 4 + g;
+        const float p = j < nkeys ? expf(sc[i] - m_new) : 0.f;
+        l += p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += p * (j < nkeys ? vv[i][e] : 0.f);
+    }
+    m = m_new;
+}
+
+// ATT_NI = keys per group per FULL chunk: 9 (up to 144 keys with everything in flight at once) when the grid is a
+// fraction of a wave of workgroups per CU and the kernel is latency bound - the last (usually only) chunk is then sized
+// to the keys that exist in steps of 16 (a wave-uniform switch; round 4: it used to request, dot and exponentiate 144
+// rows whatever the step, 2.2x what a 128-token decode needs on average); 2 when thousands of workgroups queue up
+// (throughput bound: fewer registers -> more resident workgroups).  A key's group and register do not depend on the
+// chunk size: results are unchanged bit for bit.
 template <bool HAS_SRC, int ATT_NI>  // HAS_SRC (beam search): per-slot ancestor table (one more dependent load per key, requested first)
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                           float* __restrict__ kc, float* __restrict__ vc,
@@ -461,53 +508,30 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     // (src[s][j]); the cache is never physically re-ordered (the reference's _reorder_cache, :492-496)
     const int* srow = HAS_SRC ? src + (size_t)s * T : nullptr;
     constexpr int ATT_CHUNK = 16 * ATT_NI;
-    int rowi[ATT_NI];  // first chunk's table entries: the oldest loads, so that waiting for them waits for nothing else
-#pragma unroll
-    for (int i = 0; i < ATT_NI; ++i) rowi[i] = HAS_SRC ? srow[min((i * 4 + wave) * 4 + g, nkeys - 1)] : s;
     const f32x4 q4 = *reinterpret_cast<const f32x4*>(row + hd * 64 + d4 * 4);
     const f32x4 k4 = *reinterpret_cast<const f32x4*>(row + D + hd * 64 + d4 * 4);
     const f32x4 v4 = *reinterpret_cast<const f32x4*>(row + 2 * D + hd * 64 + d4 * 4);
     float m = -INFINITY, l = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int base = 0; base < nkeys; base += ATT_CHUNK) {
-        if (HAS_SRC && base > 0) {
-#pragma unroll
-            for (int i = 0; i < ATT_NI; ++i) rowi[i] = srow[min(base + (i * 4 + wave) * 4 + g, nkeys - 1)];
-        }  // slot t + 1 of the table is stale: that key comes from k4 / v4 below
-        f32x4 kk[ATT_NI], vv[ATT_NI];
-#pragma unroll
-        for (int i = 0; i < ATT_NI; ++i) {
-            const int jc = min(base + (i * 4 + wave) * 4 + g, nkeys - 1);
-            const size_t off = (((size_t)rowi[i] * H + hd) * T + jc) * 64 + d4 * 4;
-            kk[i] = *reinterpret_cast<const f32x4*>(kc + off);
-            vv[i] = *reinterpret_cast<const f32x4*>(vc + off);
+#define ATT_CHUNK_CALL(NI_, BASE_) attn_chunk<HAS_SRC, NI_>(kc, vc, srow, s, hd, H, T, BASE_, nkeys, slot, wave, g, d4, q4, k4, v4, m, l, acc)
+    if constexpr (ATT_NI == 9) {
+        int base = 0;
+        for (; nkeys - base > ATT_CHUNK; base += ATT_CHUNK) ATT_CHUNK_CALL(9, base);
+        switch ((nkeys - base + 15) >> 4) {
+            case 1: ATT_CHUNK_CALL(1, base); break;
+            case 2: ATT_CHUNK_CALL(2, base); break;
+            case 3: ATT_CHUNK_CALL(3, base); break;
+            case 4: ATT_CHUNK_CALL(4, base); break;
+            case 5: ATT_CHUNK_CALL(5, base); break;
+            case 6: ATT_CHUNK_CALL(6, base); break;
+            case 7: ATT_CHUNK_CALL(7, base); break;
+            case 8: ATT_CHUNK_CALL(8, base); break;
+            default: ATT_CHUNK_CALL(9, base); break;
         }
-        __builtin_amdgcn_sched_barrier(0);  // all 2 * ATT_NI loads are in flight before the first dot product waits
-        float sc[ATT_NI];
-        float cmax = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < ATT_NI; ++i) {
-            const int j = base + (i * 4 + wave) * 4 + g;
-            if (j == slot) { kk[i] = k4; vv[i] = v4; }  // selects, not branches: the new token's key / value
-            const float dot = group16_sum_dpp((q4[0] * kk[i][0] + q4[1] * kk[i][1]) + (q4[2] * kk[i][2] + q4[3] * kk[i][3]));
-            sc[i] = j < nkeys ? dot / 8.0f : -INFINITY;
-            cmax = fmaxf(cmax, sc[i]);
-        }
-        const float m_new = fmaxf(m, cmax);
-        const float scale = (m == -INFINITY) ? 0.f : expf(m - m_new);  // 1 on the first chunk's empty start, never NaN
-        l *= scale;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] *= scale;
-#pragma unroll
-        for (int i = 0; i < ATT_NI; ++i) {
-            const int j = base + (i * 4 + wave) * 4 + g;
-            const float p = j < nkeys ? expf(sc[i] - m_new) : 0.f;
-            l += p;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += p * (j < nkeys ? vv[i][e] : 0.f);
-        }
-        m = m_new;
+    } else {
+        for (int base = 0; base < nkeys; base += ATT_CHUNK) ATT_CHUNK_CALL(ATT_NI, base);
     }
+#undef ATT_CHUNK_CALL
     if (wave == 0 && g == 0) {
         *reinterpret_cast<f32x4*>(kc + (((size_t)s * H + hd) * T + slot) * 64 + d4 * 4) = k4;
         *reinterpret_cast<f32x4*>(vc + (((size_t)s * H + hd) * T + slot) * 64 + d4 * 4) = v4;
@@ -667,18 +691,32 @@ __global__ __launch_bounds__(256) void attn_decode_kv16_wave_kernel(const float*
     const __amdgpu_buffer_rsrc_t rk = dx_rsrc(kc), rv = dx_rsrc(vc);
 #define KV16_CHUNK(NI_, FIRST_, BASE_) \
     kv16_wave_chunk<NI_, HAS_SRC, FIRST_, F16>(rk, rv, srow, s, hd, H, T, BASE_, nkeys, slot, g, d8, r, q, kn16, vn16, m, l, acc)
-    // chunks of 72 keys while more than 48 remain, then one of 48 or 24 (nkeys >= 2: at least one chunk runs)
-    if (nkeys > 48) {
+    // chunks of 72 keys while more than 72 remain, then ONE chunk sized to what is left in steps of 8 keys (a wave-uniform
+    // switch around fully unrolled, unconditional, clamped load blocks - never a branch around a single load).  Round 4:
+    // the tail used to be 24 / 48 / 72 keys, i.e. 18 % more rows requested (and exponentiated) than a 128-token decode
+    // needs on average; in steps of 8 it is 5 %.  (nkeys >= 2: at least one chunk runs; a key's group and register do not
+    // depend on the chunk size, so the result does not change.)
+#define KV16_TAIL(FIRST_, BASE_, REM_)                                                                   \
+    switch (((REM_) + 7) >> 3) {                                                                         \
+        case 1: KV16_CHUNK(1, FIRST_, BASE_); break;                                                     \
+        case 2: KV16_CHUNK(2, FIRST_, BASE_); break;                                                     \
+        case 3: KV16_CHUNK(3, FIRST_, BASE_); break;                                                     \
+        case 4: KV16_CHUNK(4, FIRST_, BASE_); break;                                                     \
+        case 5: KV16_CHUNK(5, FIRST_, BASE_); break;                                                     \
+        case 6: KV16_CHUNK(6, FIRST_, BASE_); break;                                                     \
+        case 7: KV16_CHUNK(7, FIRST_, BASE_); break;                                                     \
+        case 8: KV16_CHUNK(8, FIRST_, BASE_); break;                                                     \
+        default: KV16_CHUNK(9, FIRST_, BASE_); break;                                                    \
+    }
+    if (nkeys > 72) {
         KV16_CHUNK(9, true, 0);
         int base = 72;
-        for (; nkeys - base > 48; base += 72) KV16_CHUNK(9, false, base);
-        if (nkeys - base > 24) KV16_CHUNK(6, false, base);
-        else if (nkeys - base > 0) KV16_CHUNK(3, false, base);
-    } else if (nkeys > 24) {
-        KV16_CHUNK(6, true, 0);
+        for (; nkeys - base > 72; base += 72) KV16_CHUNK(9, false, base);
+        KV16_TAIL(false, base, nkeys - base)
     } else {
-        KV16_CHUNK(3, true, 0);
+        KV16_TAIL(true, 0, nkeys)
     }
+#undef KV16_TAIL
 #undef KV16_CHUNK
     if (g == 0) {  // the new token's key / value -> cache slot t + 1 (8 lanes x 16 B = the 128-byte row)
         const size_t o = (((size_t)s * H + hd) * T + slot) * 64 + d8 * 8;
