@@ -311,6 +311,18 @@ int rgrg_linear_bf16_f32(const uint16_t* A16, const uint16_t* Wb, const float* s
  * pitches lda / ldw in elements (0 = K). */
 int rgrg_debug_linear_bf16_tile(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
                                 int M, int N, int K, int ldy, int act, int tile, int lda, int ldw, int fp16, void* stream);
+/* Test hooks for the LayerNorm folded around the 16-bit decode GEMMs (transformers GPT2Block: ln_1 -> c_attn, ln_2 -> c_fc;
+ * src/language_model/language_model.py:338-366 runs them as separate modules).  rgrg_debug_ln_fold16: wb[n][k] =
+ * round16(gain[k] w[n][k]), colsum[n] = sum_k wb[n][k] (of the ROUNDED values), shift[n] = bias[n] + sum_k beta[k] w[n][k].
+ * rgrg_debug_linear_bf16_ln: the LDS-DMA GEMM as PRODUCER of the residual stream (Yb16 [M, ldy] = the fp32 result as 16 bit,
+ * stats_out [M][32][2] = per-row (sum, sum of squares) of every 32-column block; N == 1024) or as CONSUMER (A16 = the raw
+ * 16-bit rows, Wb = the scaled weights, ln_stats = those slots, ln_colsum; K == 1024, no residual):
+ * Y = act(rstd_m (A16 Wb^T - mean_m colsum) + shift). */
+int rgrg_debug_ln_fold16(const float* w, const float* gain, const float* beta, const float* bias, uint16_t* wb, float* colsum,
+                         float* shift, int N, int K, int fp16, void* stream);
+int rgrg_debug_linear_bf16_ln(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
+                              uint16_t* Yb16, float* stats_out, const float* ln_stats, const float* ln_colsum, int M, int N,
+                              int K, int ldy, int act, int fp16, void* stream);
 /* ---- detector targets and losses: ObjectDetector.forward(images, targets), the detector half of
  * ReportGenerationModel.forward(images, image_targets, ...) (src/full_model/report_generation_model.py:55,91 ->
  * src/object_detector/object_detector.py:216-224 -> custom_rpn.py:74-83, custom_roi_heads.py:225-242, and underneath

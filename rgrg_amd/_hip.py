@@ -16,7 +16,7 @@ c_float_p = C.c_void_p  # device pointers travel as void*
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p
 
 ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
-ABI_VERSION = 14  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
+ABI_VERSION = 15  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
 
 
 class RgrgHipError(RuntimeError):
@@ -76,6 +76,8 @@ SIGNATURES = {
     "rgrg_linear_bf16w_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "rgrg_linear_bf16_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "rgrg_debug_linear_bf16_tile": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "rgrg_debug_ln_fold16": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "rgrg_debug_linear_bf16_ln": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "rgrg_decoder_copy_last_logits": (_i, [_p, _p, _i, _p]),
     "rgrg_box_match_f32": (_i, [_p, _p, _i, _p, C.c_int64, _p, _i, _i, _f, _f, _i, _p, _p, _p]),
     "rgrg_balanced_sample": (_i, [_p, _p, _i, _p, _p, C.c_uint64, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),

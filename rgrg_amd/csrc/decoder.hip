@@ -2827,6 +2827,16 @@ extern "C" int rgrg_decoder_refresh_trainable(rgrg_decoder* d, void* stream) {
     return RGRG_OK;
 }
 
+// Test hook: the weight side of the folded LayerNorm (ln_fold16_kernel, used by rgrg_decoder_set_precision).
+extern "C" int rgrg_debug_ln_fold16(const float* w, const float* gain, const float* beta, const float* bias, uint16_t* wb,
+                                    float* colsum, float* shift, int N, int K, int fp16, void* stream) {
+    RGRG_CHECK_ARG(w && gain && beta && wb && colsum && shift && N > 0 && K > 0);
+    hipLaunchKernelGGL(ln_fold16_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream), w, gain, beta, bias, wb, colsum, shift, N, K,
+                       fp16 ? 1 : 0);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
 extern "C" int rgrg_decoder_set_precision(rgrg_decoder* d, int mode) {
     RGRG_CHECK_ARG(d && mode >= 0 && mode <= 2);
     if (mode == d->bf16_gemms) return RGRG_OK;

@@ -796,6 +796,19 @@ extern "C" int rgrg_debug_linear_bf16_tile(const uint16_t* A16, const uint16_t* 
     return launch_glds(p, tile, as_stream(stream));
 }
 
+// Test hook for the LayerNorm-folded variants of the LDS-DMA kernel (the decoder uses them internally, decoder.hip
+// enqueue_step): producer when Yb16 / stats_out are given (N == 1024), consumer when ln_stats / ln_colsum are (K == 1024).
+extern "C" int rgrg_debug_linear_bf16_ln(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
+                                         uint16_t* Yb16, float* stats_out, const float* ln_stats, const float* ln_colsum, int M,
+                                         int N, int K, int ldy, int act, int fp16, void* stream) {
+    int rc = init_gemm_bf16_attrs();
+    if (rc) return rc;
+    RGRG_CHECK_ARG(A16 && Wb && Y);
+    GemmLnFold f{};
+    f.Yb16 = Yb16; f.stats_out = stats_out; f.ln_stats = ln_stats; f.ln_colsum = ln_colsum;
+    return launch_gemm_bf16w_ex(nullptr, A16, Wb, shift, R, Y, nullptr, M, N, K, ldy, act, as_stream(stream), fp16, &f);
+}
+
 // nn.Conv2d (+ folded eval BatchNorm + residual + ReLU) as an implicit GEMM on the bf16 matrix core, for the detector
 // under torch.autocast (the reference runs trunk / RPN in half precision there, generate_reports_for_images.py:108).
 //   X16 [B,H,W,Cin] bf16 NHWC with 128 zero elements in front of it (X16[-128 .. -1] == 0), Cin % 64 == 0

@@ -429,6 +429,73 @@ def test_linear_bf16_lds_dma_kernel(eng, M, N, K, act, res, out16, fp16):
         close(y2, ref, tol[0], tol[1], f"bf16 LDS-DMA linear {M}x{N}x{K} tile {tile}")
 
 
+@pytest.mark.parametrize("fp16", [0, 1])
+@pytest.mark.parametrize("M,N2,act", [(923, 3072, 0), (923, 4096, 2), (131, 192, 0), (64, 64, 2)])
+def test_layernorm_folded_gemm_pair_against_layernorm_then_linear(eng, M, N2, act, fp16):
+    """The LayerNorm folded around the 16-bit decode GEMMs (round 4; transformers GPT2Block ln_1 -> c_attn, ln_2 -> c_fc):
+      producer  x = A16 W1^T + b1 + R (N = 1024) also stores x as 16 bit and per-row (sum, sum of squares) slots per 32 columns;
+      consumer  y = act(LN(x; gain, beta) W2^T + b2) computed as act(rstd (x16 Wg^T - mean colsum) + shift), Wg = round16(gain o W2).
+    Checked piece by piece: the fold vectors against torch (rounded weights bit-exact), the slots against exact row sums of
+    the producer's own fp32 output, the 16-bit copy bit-exact, the consumer against a float64 evaluation of its OWN formula on
+    the same rounded operands (2e-5), and against LayerNorm -> round -> matmul (what the unfolded path and the oracle do) at the
+    16-bit noise level.  Rows with a large mean and an outlier column are included (the fold rounds x, not LN(x))."""
+    g = torch.Generator().manual_seed(M + N2 + 7 * fp16)
+    t16 = T16[fp16]
+    K1, D = 1024, 1024
+    A = torch.randn((M, K1), generator=g)
+    W1 = torch.randn((D, K1), generator=g) / math.sqrt(K1)
+    b1 = torch.randn((D,), generator=g)
+    R = torch.randn((M, D), generator=g) * 2.0
+    R[::3] += 1.5                    # rows with mean / std ~ 0.6
+    R[:, 77] += 40.0                 # an outlier feature, as GPT-2 residual streams have
+    gain = 1.0 + 0.2 * torch.randn((D,), generator=g)
+    beta = 0.3 * torch.randn((D,), generator=g)
+    W2 = torch.randn((N2, D), generator=g) / math.sqrt(D)
+    b2 = torch.randn((N2,), generator=g)
+    dev = lambda t: t.to(DEV).contiguous()  # noqa: E731
+    # --- weight side
+    wg = torch.empty((N2, D), dtype=torch.int16, device=DEV)
+    cs = torch.empty((N2,), device=DEV)
+    sh = torch.empty((N2,), device=DEV)
+    dW2, dgain, dbeta, db2 = dev(W2), dev(gain), dev(beta), dev(b2)
+    _hip.check(eng.lib.rgrg_debug_ln_fold16(dW2.data_ptr(), dgain.data_ptr(), dbeta.data_ptr(), db2.data_ptr(), wg.data_ptr(),
+                                            cs.data_ptr(), sh.data_ptr(), N2, D, fp16, _stream()))
+    wg_ref = (W2 * gain[None, :]).to(t16)
+    assert torch.equal(wg.cpu().view(t16), wg_ref)
+    close(cs, wg_ref.double().sum(1), 1e-6, 1e-5, "column sums of the rounded scaled weights")
+    close(sh, b2.double() + W2.double() @ beta.double(), 1e-6, 1e-5, "folded shift")
+    # --- producer
+    A16, W1b = dev(A.to(t16).view(torch.int16)), dev(W1.to(t16).view(torch.int16))
+    x = torch.empty((M, D), device=DEV)
+    x16 = torch.empty((M, D), dtype=torch.int16, device=DEV)
+    slots = torch.full((M, 32, 2), float("nan"), device=DEV)
+    dR, db1 = dev(R), dev(b1)
+    _hip.check(eng.lib.rgrg_debug_linear_bf16_ln(A16.data_ptr(), W1b.data_ptr(), db1.data_ptr(), dR.data_ptr(), x.data_ptr(), x16.data_ptr(),
+                                                 slots.data_ptr(), None, None, M, D, K1, D, 0, fp16, _stream()))
+    x_ref = A.to(t16).double() @ W1.to(t16).double().t() + b1.double() + R.double()
+    close(x, x_ref, 2e-5, 2e-6, "producer output")
+    xc = x.cpu()
+    assert torch.equal(x16.cpu().view(t16), xc.to(t16))
+    blocks = xc.double().view(M, 32, 32)
+    close(slots[:, :, 0], blocks.sum(2), 1e-6, 1e-4, "per-block row sums")
+    close(slots[:, :, 1], (blocks * blocks).sum(2), 1e-6, 1e-3, "per-block row sums of squares")
+    # --- consumer
+    y = torch.empty((M, N2), device=DEV)
+    _hip.check(eng.lib.rgrg_debug_linear_bf16_ln(x16.data_ptr(), wg.data_ptr(), sh.data_ptr(), None, y.data_ptr(), None, None,
+                                                 slots.data_ptr(), cs.data_ptr(), M, N2, D, N2, act, fp16, _stream()))
+    actf = {0: lambda v: v, 2: lambda v: F.gelu(v, approximate="tanh")}[act]
+    mean = xc.double().mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(xc.double().var(1, unbiased=False, keepdim=True) + 1e-5)
+    own = actf(rstd * (xc.to(t16).double() @ wg_ref.double().t() - mean * wg_ref.double().sum(1)[None, :])
+               + (b2.double() + W2.double() @ beta.double())[None, :])
+    close(y, own, 5e-5, 2e-5, "consumer against its own formula in float64")
+    ln = F.layer_norm(xc, (D,), gain, beta, 1e-5)
+    unfolded = actf(ln.to(t16).double() @ W2.to(t16).double().t() + b2.double())
+    span = unfolded.abs().max().item()
+    err = (y.cpu().double() - unfolded).abs().max().item()
+    assert err <= (4e-3 if fp16 else 3e-2) * span, (err, span)     # two roundings of the same magnitude at different places
+
+
 # ------------------------------------------------------------------------- image preprocessing (SURVEY 8(f) rank 4)
 @pytest.mark.parametrize("h,w", [(3056, 2544), (2544, 3056), (1024, 1024), (1536, 1536), (768, 512), (512, 512), (700, 513),
                                  (300, 200), (200, 300), (256, 256), (511, 3), (37, 41)])
