@@ -68,7 +68,7 @@ def rooflines(eng, S_dec, dtype, max_length):
     algorithmic bytes = the fp32 weights of the step, each read once); above: MFMA bound (2 M N K flops against the
     dense peak of the compute dtype).  Attention is HBM bound on the K/V cache bytes it must read."""
     nkeys = (2 + (max_length + 1)) // 2
-    p = eng.time_step_parts(S_dec, nkeys, iters=3)
+    p = eng.time_step_parts(S_dec, nkeys, iters=10)   # (3 replays read 3-6 % slow: the first one runs on ramping clocks)
     n = max(p["gemm_launches"], 1)
     g_traffic, g_src = pmc_traffic("gemm", S_dec, dtype)
     a_traffic, a_src = pmc_traffic("attn", S_dec, dtype)

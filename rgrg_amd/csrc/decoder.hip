@@ -2933,9 +2933,11 @@ extern "C" int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, i
     int rc = RGRG_OK;
     float tg = 0.f, ta = 0.f;
     d->gemm_bytes_per_step = 0; d->gemm_flops_per_step = 0.0; d->gemm_launches_per_step = 0;
-    for (int it = 0; it < iters && !rc; ++it) {
-        const bool c = it == 0;
-        RGRG_HIP(hipEventRecord(e0, d->stream));
+    // ONE event pair around all `iters` replays (plus an untimed one in front): a pair per replay with a host wait in
+    // between lets the GPU go idle between replays, and each then starts on ramping clocks (read 3-6 % slow)
+    for (int it = -1; it < iters && !rc; ++it) {
+        const bool c = it == -1;   // the untimed replay also counts the step's bytes / flops / launches
+        if (it == 0) RGRG_HIP(hipEventRecord(e0, d->stream));
         for (int l = 0; l < d->n_layer && !rc; ++l) {
             const LayerW& w = d->layers[l];
             if (fused) {
@@ -2955,24 +2957,20 @@ extern "C" int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, i
         } else if (!rc) {
             rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, c, xn16);
         }
-        if (rc) break;
-        RGRG_HIP(hipEventRecord(e1, d->stream));
-        RGRG_HIP(hipEventSynchronize(e1));
-        float ms = 0.f;
-        RGRG_HIP(hipEventElapsedTime(&ms, e0, e1));
-        tg += ms;
     }
     if (!rc) {
+        RGRG_HIP(hipEventRecord(e1, d->stream));
+        RGRG_HIP(hipEventSynchronize(e1));
+        RGRG_HIP(hipEventElapsedTime(&tg, e0, e1));
         hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, d->stream, d->step, nkeys - 2);
-        for (int it = 0; it < iters && !rc; ++it) {
-            RGRG_HIP(hipEventRecord(e0, d->stream));
+        for (int it = -1; it < iters && !rc; ++it) {
+            if (it == 0) RGRG_HIP(hipEventRecord(e0, d->stream));
             for (int l = 0; l < d->n_layer && !rc; ++l) rc = launch_attention(d, l, S, nullptr, att16, fused ? 1 : 0);
-            if (rc) break;
+        }
+        if (!rc) {
             RGRG_HIP(hipEventRecord(e1, d->stream));
             RGRG_HIP(hipEventSynchronize(e1));
-            float ms = 0.f;
-            RGRG_HIP(hipEventElapsedTime(&ms, e0, e1));
-            ta += ms;
+            RGRG_HIP(hipEventElapsedTime(&ta, e0, e1));
         }
         hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, d->stream, d->step, 0);
         (void)hipStreamSynchronize(d->stream);
