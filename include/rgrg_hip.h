@@ -315,7 +315,7 @@ int rgrg_debug_linear_bf16_tile(const uint16_t* A16, const uint16_t* Wb, const f
  * src/language_model/language_model.py:338-366 runs them as separate modules).  rgrg_debug_ln_fold16: wb[n][k] =
  * round16(gain[k] w[n][k]), colsum[n] = sum_k wb[n][k] (of the ROUNDED values), shift[n] = bias[n] + sum_k beta[k] w[n][k].
  * rgrg_debug_linear_bf16_ln: the LDS-DMA GEMM as PRODUCER of the residual stream (Yb16 [M, ldy] = the fp32 result as 16 bit,
- * stats_out [M][32][2] = per-row (sum, sum of squares) of every 32-column block; N == 1024) or as CONSUMER (A16 = the raw
+ * stats_out [M][16][2] = per-row (sum, sum of squares) of every 64-column block; N == 1024) or as CONSUMER (A16 = the raw
  * 16-bit rows, Wb = the scaled weights, ln_stats = those slots, ln_colsum; K == 1024, no residual):
  * Y = act(rstd_m (A16 Wb^T - mean_m colsum) + shift). */
 int rgrg_debug_ln_fold16(const float* w, const float* gain, const float* beta, const float* bias, uint16_t* wb, float* colsum,

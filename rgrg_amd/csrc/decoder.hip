@@ -38,7 +38,7 @@ int init_gemm_bf16_attrs();
 // (gemm_bf16.hip; f16: the 16-bit type - 0 bf16, 1 IEEE fp16)
 struct GemmLnFold {   // LayerNorm folded around the 16-bit GEMMs (gemm_bf16.hip: GemmBf16Params)
     void* Yb16 = nullptr;               // producer: 16-bit copy of the fp32 result (the raw residual stream) ...
-    float* stats_out = nullptr;         // ... and per-row (sum, sum of squares) slots [M][32][2]
+    float* stats_out = nullptr;         // ... and per-row (sum, sum of squares) slots [M][16][2]
     const float* ln_stats = nullptr;    // consumer: those slots
     const float* ln_colsum = nullptr;   // consumer: column sums of the gain-scaled rounded weights
 };
@@ -369,11 +369,11 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
     reinterpret_cast<f32x4*>(x + (size_t)s * D)[tid] = v;
     if (stats) {
         // LayerNorm folded into the consuming GEMM (16-bit many-sequence path): the RAW row as 16 bit plus its (sum, sum of
-        // squares) in slot 0 of the row's 32 slots - the layout the GEMM epilogues write (gemm_bf16.hip)
+        // squares) in slot 0 of the row's 16 slots - the layout the GEMM epilogues write (gemm_bf16.hip)
         store_16x4(xn16 + (size_t)s * D + 4 * tid, v, f16);
         const float s1 = block_sum_256((v[0] + v[1]) + (v[2] + v[3]), sh);
         const float s2 = block_sum_256((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]), sh);
-        if (tid < 32) reinterpret_cast<float2*>(stats)[(size_t)s * 32 + tid] = tid ? make_float2(0.f, 0.f) : make_float2(s1, s2);
+        if (tid < 16) reinterpret_cast<float2*>(stats)[(size_t)s * 16 + tid] = tid ? make_float2(0.f, 0.f) : make_float2(s1, s2);
         return;
     }
     const f32x4 o = ln_row(v, g, b, sh, D);
@@ -1478,7 +1478,7 @@ struct rgrg_decoder {
     int bf16_gemms = 0;  // 1 (bf16) / 2 (fp16): 16-bit-weight MFMA GEMMs on the many-sequence path (not bit-exact; opt-in)
     int f16() const { return bf16_gemms == 2 ? 1 : 0; }   // the 16-bit type of that mode
     unsigned short *xn16 = nullptr, *att16 = nullptr, *ff16 = nullptr;  // bf16 activations of that path (GEMM inputs)
-    float* ln_stat = nullptr;   // [rows][32][2]: per-row (sum, sum of squares) slots of the residual stream (folded LayerNorm)
+    float* ln_stat = nullptr;   // [rows][16][2]: per-row (sum, sum of squares) slots (one per 64 columns) of the residual stream (folded LayerNorm)
     bool ln_fold = true;        // 16-bit path: LayerNorms folded into the GEMMs around them; RGRG_LN_FOLD=0: ln_rows launches (A/B)
     int gemm_launches_per_step = 0;
     void* a16_scratch = nullptr;   // bf16 copy of an fp32 GEMM input (teacher-forced / training passes under autocast)
@@ -2882,7 +2882,7 @@ extern "C" int rgrg_decoder_set_precision(rgrg_decoder* d, int mode) {
                 RGRG_LAUNCH_CHECK();
                 return RGRG_OK;
             };
-            if (!d->ln_stat && (rc2 = dmalloc(d, (void**)&d->ln_stat, (size_t)d->rows * 64 * sizeof(float), true))) return rc2;
+            if (!d->ln_stat && (rc2 = dmalloc(d, (void**)&d->ln_stat, (size_t)d->rows * 32 * sizeof(float), true))) return rc2;
             for (auto& w : d->layers) {
                 if ((rc2 = mkln(w.c_attn, w.ln1_g, w.ln1_b)) || (rc2 = mkln(w.c_fc, w.ln2_g, w.ln2_b))) return rc2;
             }

@@ -43,11 +43,11 @@ struct GemmBf16Params {
     int f16 = 0;               // the 16-bit type of A16 / Wb / Y16 / R16: 0 = bf16, 1 = IEEE fp16 (common.h)
     // LayerNorm folded around the GEMMs of the decode step (LDS-DMA kernel, decoder.hip enqueue_step):
     //  * producer side (the GEMMs that write the residual stream x, N = the normalised width = 1024): besides Y (fp32) the
-    //    result is stored as 16 bit in Yb16 [M, ldy] and every 32-column block leaves its per-row (sum, sum of squares) in
-    //    stats_out [M][32][2];
+    //    result is stored as 16 bit in Yb16 [M, ldy] and every 64-column block leaves its per-row (sum, sum of squares) in
+    //    stats_out [M][16][2];
     //  * consumer side (the GEMM behind the LayerNorm, K = 1024): A16 is the RAW 16-bit x, Wb holds gain-scaled weights, and
     //    the epilogue applies  rstd_m * (acc - mean_m * colsum_n) + shift_n  with mean / rstd of row m reduced (fixed order)
-    //    from ln_stats [M][32][2]; colsum_n = the sum over k of the ROUNDED scaled weights, shift_n = bias + beta . W.
+    //    from ln_stats [M][16][2]; colsum_n = the sum over k of the ROUNDED scaled weights, shift_n = bias + beta . W.
     u16* Yb16 = nullptr;
     float* stats_out = nullptr;
     const float* ln_stats = nullptr;
@@ -468,11 +468,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
     // stream like the other epilogue operands (the oldest loads: the counted waits of the pipeline are unaffected) and not
     // looked at before the K loop is through - reduced in front of the loop they held up its first barrier by a cold miss.
     // 256 / BM threads share a row, each adds its slots in index order.
-    constexpr int TPR = 256 / BM, PER = 32 / TPR;
+    constexpr int TPR = 256 / BM, PER = 16 / TPR;   // 16 slots per row (64-column blocks of the 1024-wide producer)
     f32x4 lsq[PER / 2];
     if constexpr (LNF == 2) {
         const int srow = min(m0 + tid / TPR, p.M - 1);
-        const f32x4* sp = reinterpret_cast<const f32x4*>(p.ln_stats + ((size_t)srow * 32 + (tid % TPR) * PER) * 2);
+        const f32x4* sp = reinterpret_cast<const f32x4*>(p.ln_stats + ((size_t)srow * 16 + (tid % TPR) * PER) * 2);
 #pragma unroll
         for (int j = 0; j < PER / 2; ++j) lsq[j] = sp[j];
     }
@@ -524,6 +524,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
         __syncthreads();
     }
 
+    float blk1[MI], blk2[MI];   // producer of a folded LayerNorm: this wave's row sums over its column blocks
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) { blk1[mi] = 0.f; blk2[mi] = 0.f; }
     // epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  Residual reads use
     // clamped rows and are issued together; only the stores are predicated.  Offsets are 32-bit inside the tile's rows.
 #pragma unroll
@@ -599,12 +602,37 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
 #undef RGRG_BFLY
                 a1[0] += __shfl_xor(a1[0], 1, 64);
                 a2[0] += __shfl_xor(a2[0], 1, 64);
-                const int r = (lane >> 1) & 15, row = rbase + (r & 3) + 8 * (r >> 2);
-                if (!(lane & 1) && row < p.M && col < p.N)
-                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)row * 32 + (n0 + wn * (BN / 2) + ni * 32) / 32) * 2) =
-                        make_float2(a1[0], a2[0]);
+                // lane L (and L ^ 1) now holds row (L >> 1) & 15 of its half of the block; blocks of one row block add up in ni order
+                blk1[mi] += a1[0];
+                blk2[mi] += a2[0];
             }
         }
+    if constexpr (LNF == 1) {
+        // one slot per 64 columns: a 128-wide tile's wave already covers 64 (its two blocks were added above); in a 64-wide tile
+        // the two waves of a row block each hold 32 columns and meet in LDS (behind the stages), wn = 0 adds and stores
+        float2* xch = reinterpret_cast<float2*>(glds_smem + NST * STAGE);   // [4 waves][MI][32 rows]
+        const int r = (lane >> 1) & 15, lrow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if constexpr (NI == 1) {
+            if (wn == 1 && !(lane & 1)) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) xch[(wave * MI + mi) * 32 + lrow] = make_float2(blk1[mi], blk2[mi]);
+            }
+            __syncthreads();
+        }
+        if (!(lane & 1) && (NI == 2 || wn == 0)) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                float s1 = blk1[mi], s2 = blk2[mi];
+                if constexpr (NI == 1) {
+                    const float2 o = xch[((wave + 1) * MI + mi) * 32 + lrow];
+                    s1 += o.x; s2 += o.y;
+                }
+                const int row = m0 + wm * (BM / 2) + mi * 32 + lrow;
+                const int slot = NI == 2 ? (n0 + wn * 64) / 64 : n0 / 64;
+                if (row < p.M) *reinterpret_cast<float2*>(p.stats_out + ((size_t)row * 16 + slot) * 2) = make_float2(s1, s2);
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, size_t n, int f16) {
@@ -639,7 +667,7 @@ static int bf16_attr() {
 
 template <int BM, int BN, int NST>
 static int glds_attr() {
-    constexpr int lds = NST * (BM + BN) * 128 + BM * 8;
+    constexpr int lds = NST * (BM + BN) * 128 + BM * 16;
 #define RGRG_G_ATTR(...) RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<BM, BN, NST, __VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
     RGRG_G_ATTR(false, false, 0); RGRG_G_ATTR(true, false, 0); RGRG_G_ATTR(false, true, 0); RGRG_G_ATTR(true, true, 0);
     RGRG_G_ATTR(false, false, 1); RGRG_G_ATTR(false, true, 1); RGRG_G_ATTR(false, false, 2); RGRG_G_ATTR(false, true, 2);
@@ -666,7 +694,7 @@ int init_gemm_bf16_attrs() {
 template <int BM, int BN, int NST>
 static int launch_glds_cfg(const GemmBf16Params& p, hipStream_t st) {
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
-#define RGRG_G_LAUNCH(CONV_, F16_, LNF_) hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, NST, CONV_, F16_, LNF_>), dim3(mtiles * ntiles), dim3(256), NST * (BM + BN) * 128 + BM * 8, st, p, mtiles, ntiles)
+#define RGRG_G_LAUNCH(CONV_, F16_, LNF_) hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, NST, CONV_, F16_, LNF_>), dim3(mtiles * ntiles), dim3(256), NST * (BM + BN) * 128 + BM * 16, st, p, mtiles, ntiles)
     if (p.cCin) { if (p.f16) RGRG_G_LAUNCH(true, true, 0); else RGRG_G_LAUNCH(true, false, 0); }
     else if (p.Yb16) { if (p.f16) RGRG_G_LAUNCH(false, true, 1); else RGRG_G_LAUNCH(false, false, 1); }
     else if (p.ln_colsum) { if (p.f16) RGRG_G_LAUNCH(false, true, 2); else RGRG_G_LAUNCH(false, false, 2); }

@@ -433,7 +433,7 @@ def test_linear_bf16_lds_dma_kernel(eng, M, N, K, act, res, out16, fp16):
 @pytest.mark.parametrize("M,N2,act", [(923, 3072, 0), (923, 4096, 2), (131, 192, 0), (64, 64, 2)])
 def test_layernorm_folded_gemm_pair_against_layernorm_then_linear(eng, M, N2, act, fp16):
     """The LayerNorm folded around the 16-bit decode GEMMs (round 4; transformers GPT2Block ln_1 -> c_attn, ln_2 -> c_fc):
-      producer  x = A16 W1^T + b1 + R (N = 1024) also stores x as 16 bit and per-row (sum, sum of squares) slots per 32 columns;
+      producer  x = A16 W1^T + b1 + R (N = 1024) also stores x as 16 bit and per-row (sum, sum of squares) slots per 64 columns;
       consumer  y = act(LN(x; gain, beta) W2^T + b2) computed as act(rstd (x16 Wg^T - mean colsum) + shift), Wg = round16(gain o W2).
     Checked piece by piece: the fold vectors against torch (rounded weights bit-exact), the slots against exact row sums of
     the producer's own fp32 output, the 16-bit copy bit-exact, the consumer against a float64 evaluation of its OWN formula on
@@ -468,7 +468,7 @@ def test_layernorm_folded_gemm_pair_against_layernorm_then_linear(eng, M, N2, ac
     A16, W1b = dev(A.to(t16).view(torch.int16)), dev(W1.to(t16).view(torch.int16))
     x = torch.empty((M, D), device=DEV)
     x16 = torch.empty((M, D), dtype=torch.int16, device=DEV)
-    slots = torch.full((M, 32, 2), float("nan"), device=DEV)
+    slots = torch.full((M, 16, 2), float("nan"), device=DEV)
     dR, db1 = dev(R), dev(b1)
     _hip.check(eng.lib.rgrg_debug_linear_bf16_ln(A16.data_ptr(), W1b.data_ptr(), db1.data_ptr(), dR.data_ptr(), x.data_ptr(), x16.data_ptr(),
                                                  slots.data_ptr(), None, None, M, D, K1, D, 0, fp16, _stream()))
@@ -476,7 +476,7 @@ def test_layernorm_folded_gemm_pair_against_layernorm_then_linear(eng, M, N2, ac
     close(x, x_ref, 2e-5, 2e-6, "producer output")
     xc = x.cpu()
     assert torch.equal(x16.cpu().view(t16), xc.to(t16))
-    blocks = xc.double().view(M, 32, 32)
+    blocks = xc.double().view(M, 16, 64)
     close(slots[:, :, 0], blocks.sum(2), 1e-6, 1e-4, "per-block row sums")
     close(slots[:, :, 1], (blocks * blocks).sum(2), 1e-6, 1e-3, "per-block row sums of squares")
     # --- consumer
