@@ -194,3 +194,41 @@ def test_select_training_samples_kernels_equal_the_oracle_per_image():
     # logf / IEEE division on the device against the CPU's: a few ulp
     assert torch.allclose(got[fin], o[fin], rtol=2e-6, atol=2e-6)
     assert bool((reg[R:] == 0).all())
+
+
+def _philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: Parallel random numbers - as easy as 1, 2, 3, SC'11), plain Python."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c, k = list(ctr), list(key)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xffffffff, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xffffffff]
+        k = [(k[0] + W0) & 0xffffffff, (k[1] + W1) & 0xffffffff]
+    return c
+
+
+def test_sampler_keys_are_philox4x32_10_words():
+    """The keys the sampler draws when none are injected are word 0 of Philox4x32-10 over counter (index, image, stage, 0)
+    and key = the call's 64-bit seed: checked against the generator's published known-answer vector and a plain Python
+    evaluation (the keys are left in the caller's work space)."""
+    assert _philox4x32_10((0, 0, 0, 0), (0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]        # Random123 kat_vectors
+    assert _philox4x32_10((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    import ctypes as C
+    from rgrg_amd import _hip
+    lib = _hip.load()
+    B, n = 3, 1000
+    matched = torch.zeros((B, n), dtype=torch.int32, device=DEV)
+    for seed, stage in ((0, 0), (0x0123456789abcdef, 1)):
+        ws = torch.zeros((B, n), dtype=torch.int32, device=DEV)
+        mask = torch.empty((B, n), dtype=torch.uint8, device=DEV)
+        lst = torch.empty((B, 64), dtype=torch.int32, device=DEV)
+        cnt = torch.empty((B,), dtype=torch.int32, device=DEV)
+        _hip.check(lib.rgrg_balanced_sample(matched.data_ptr(), None, 0, None, None, C.c_uint64(seed), stage, B, n, 64, 32, ws.data_ptr(),
+                                            mask.data_ptr(), lst.data_ptr(), cnt.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "rgrg_balanced_sample")
+        got = ws.cpu().to(torch.int64) & 0xffffffff
+        for b, i in ((0, 0), (0, 1), (1, 0), (2, 999), (1, 517)):
+            want = _philox4x32_10((i, b, stage, 0), (seed & 0xffffffff, seed >> 32))[0]
+            assert int(got[b, i]) == want, (seed, stage, b, i, hex(int(got[b, i])), hex(want))
+    assert int(got[0, 0]) != 0x6627e8d5                                 # the second call used another seed and stage
