@@ -248,6 +248,32 @@ def test_roi_align_edge_boxes(eng):
     assert torch.equal(out, ref), f"max abs diff {(out - ref).abs().max().item():.3e}"
 
 
+@pytest.mark.parametrize("FH,FW,C", [(8, 8, 128), (12, 20, 64), (20, 12, 192)])
+def test_roi_align_other_map_sizes_and_partial_chunks(eng, FH, FW, C):
+    """Maps that are not 16 x 16 take the kernel variant with a run-time row stride (the 16-wide one has its tap offsets
+    as instruction immediates); RoI counts around the 32-RoI chunk size (1, 31, 33 per image, an empty image in between),
+    boxes on every border and samples outside the map (dead samples).  Bit-exact like the 16 x 16 case."""
+    g = torch.Generator().manual_seed(FH * 100 + FW)
+    feat = torch.randn((4, C, FH, FW), generator=g)
+    W, H = FW * 32.0, FH * 32.0
+
+    def boxes(n):
+        xy = torch.rand((n, 2), generator=g) * torch.tensor([W, H]) * 0.9
+        wh = torch.rand((n, 2), generator=g) * torch.tensor([W, H]) * 0.6 + 1.0
+        b = torch.cat([xy, torch.minimum(xy + wh, torch.tensor([W, H]))], 1)
+        b[0] = torch.tensor([0.0, 0.0, W, H])                      # the whole image: last row / column taps
+        if n > 2:
+            b[1] = torch.tensor([W - 3.0, H - 3.0, W, H])          # bottom-right corner
+            b[2] = torch.tensor([-40.0, -40.0, 20.0, 20.0])        # starts outside: samples below -1 are dead
+        return b
+    plist = [boxes(33), torch.zeros((0, 4)), boxes(1), boxes(31)]
+    out, pooled = _run_roi(eng, feat, plist)
+    rois = torch.cat([torch.cat([torch.full((p.shape[0], 1), float(i)), p], 1) for i, p in enumerate(plist)], 0)
+    ref = tv013.roi_align(feat, rois, 1.0 / 32, 8, 2)
+    assert torch.equal(out, ref), f"max abs diff {(out - ref).abs().max().item():.3e}"
+    close(pooled, F.avg_pool2d(ref, 8).flatten(1), 1e-6, 1e-6, "8x8 average pool")
+
+
 # ------------------------------------------------------------------------- top-1 per class
 def test_top1_per_class_on_oracle_inputs(eng, oracle_bench):
     plist = oracle_bench["_proposals"]
