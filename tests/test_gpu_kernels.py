@@ -456,7 +456,7 @@ def test_linear_bf16_lds_dma_kernel(eng, M, N, K, act, res, out16, fp16):
 
 
 @pytest.mark.parametrize("fp16", [0, 1])
-@pytest.mark.parametrize("M,N2,act", [(923, 3072, 0), (923, 4096, 2), (131, 192, 0), (64, 64, 2)])
+@pytest.mark.parametrize("M,N2,act", [(923, 3072, 0), (923, 4096, 2), (131, 192, 0), (64, 64, 2), (4100, 192, 0), (16400, 64, 0)])
 def test_layernorm_folded_gemm_pair_against_layernorm_then_linear(eng, M, N2, act, fp16):
     """The LayerNorm folded around the 16-bit decode GEMMs (round 4; transformers GPT2Block ln_1 -> c_attn, ln_2 -> c_fc):
       producer  x = A16 W1^T + b1 + R (N = 1024) also stores x as 16 bit and per-row (sum, sum of squares) slots per 64 columns;
@@ -464,7 +464,9 @@ def test_layernorm_folded_gemm_pair_against_layernorm_then_linear(eng, M, N2, ac
     Checked piece by piece: the fold vectors against torch (rounded weights bit-exact), the slots against exact row sums of
     the producer's own fp32 output, the 16-bit copy bit-exact, the consumer against a float64 evaluation of its OWN formula on
     the same rounded operands (2e-5), and against LayerNorm -> round -> matmul (what the unfolded path and the oracle do) at the
-    16-bit noise level.  Rows with a large mean and an outlier column are included (the fold rounds x, not LN(x))."""
+    16-bit noise level.  Rows with a large mean and an outlier column are included (the fold rounds x, not LN(x)).  The row
+    counts pick every producer tile: 64 x 64 (two waves of a row block meet in LDS), 128 x 64 at 4100 rows (two row blocks per
+    wave), 128 x 128 at 16 400 rows (a wave covers 64 columns itself)."""
     g = torch.Generator().manual_seed(M + N2 + 7 * fp16)
     t16 = T16[fp16]
     K1, D = 1024, 1024
