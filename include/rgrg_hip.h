@@ -223,9 +223,9 @@ int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, const int64_t* 
  *   loss_scale    d(total_loss)/d(language_model_loss), e.g. the loss weight (and an AMP scale)
  *   dropout_p     0 = deterministic pass.  > 0: GPT-2's four dropout sites of train mode (embedding `drop` :311,
  *                 attn_dropout on the probabilities :116, resid_dropout :178, the MLP's dropout) with a counter-based
- *                 generator: mask = f(dropout_seed, layer*4 + site, element index) (Philox4x32-10), recomputed by the
- *                 backward pass; torch's generator stream cannot be reproduced, so the masks differ from the
- *                 reference's (rgrg_dropout_mask_f32 exports them for checks).
+ *                 generator: mask = f(dropout_seed, layer*4 + site, element index) (Philox4x32-10: counter = index / 4,
+ *                 word index % 4), recomputed by the backward pass; torch's generator stream cannot be reproduced, so
+ *                 the masks differ from the reference's (rgrg_dropout_mask_f32 exports them for checks).
  *   dropout_seed  a fresh value per call
  *   loss_out      one f32, the unscaled loss
  *   grad_ukv_w    f32 [n_layer*2*1024, 1024]  rows = [uk_0; uv_0; uk_1; uv_1; ...]      grad_ukv_b  f32 [n_layer*2*1024]
@@ -237,8 +237,9 @@ int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, const int64_t
                               float* grad_fst2_b, void* stream);
 /* The dropout mask of one site as the training pass computes it: out[i] = 0 (dropped, probability p) or 1/(1-p), for the
  * flat element index i of the site's tensor ([S*T,1024] for sites 0/2/3, [S,16,T,T+1] for the attention probabilities);
- * stream_id = layer*4 + site. */
-int rgrg_dropout_mask_f32(uint64_t seed, uint32_t stream_id, float p, int64_t n, float* out, void* stream);
+ * stream_id = layer*4 + site; row_len = T + 1 for the attention probabilities (their generator index pads a row of keys to
+ * a multiple of 4), 0 otherwise. */
+int rgrg_dropout_mask_f32(uint64_t seed, uint32_t stream_id, float p, int64_t n, int row_len, float* out, void* stream);
 /* Replaces the INCREMENTAL form of LanguageModel.forward - use_cache=True with or without past_key_values
  * (src/language_model/language_model.py:258-366, :396-399), the call the reference's own generate loop makes every step -
  * over this decoder's pre-allocated K/V cache instead of concatenated tensors.  past_len = number of tokens already in the
@@ -307,10 +308,19 @@ int rgrg_linear_bf16w_f32(const float* A, const uint16_t* Wb, const float* shift
 int rgrg_linear_bf16_f32(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
                          uint16_t* Y16, int M, int N, int K, int ldy, int act, int fp16, void* stream);
 /* Measurement hook (tools/gemm_bf16_bench.py): the LDS-DMA kernel with a forced configuration: tile = shape + 16 * stages
- * (shape 0 heuristic, 1 128x128, 2 64x64, 3 128x64, 4 64x128; stages 0 = 4, or 2 / 3 / 4 LDS stages) and operand row
+ * (shape 0 heuristic, 1 128x128, 2 64x64, 3 128x64, 4 64x128, 5 the 256x256 ping-pong kernel; stages 0 = 4, or 2 / 3 / 4 LDS
+ * stages) and operand row
  * pitches lda / ldw in elements (0 = K). */
 int rgrg_debug_linear_bf16_tile(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
                                 int M, int N, int K, int ldy, int act, int tile, int lda, int ldw, int fp16, void* stream);
+/* Test / measurement hook for the 16-bit training pass (torch.autocast around the reference's training step,
+ * src/full_model/train_full_model.py:172-237): the same GEMM on a forced tile (as above; 5 = the 256 x 256 ping-pong kernel
+ * of the large shapes) with the training epilogues - Y (f32) or Y16 (16 bit) = act(A16 Wb^T + shift + R); Ypre16 (optional):
+ * the 16-bit value BEFORE the activation (c_fc keeps it for gelu_new'); G16 (optional, no R / act): the result is multiplied
+ * by gelu_new'(G16[m, n]) - the activation gradient of GPT2MLP lands directly as d(c_fc output). */
+int rgrg_debug_linear_bf16_train(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
+                                 uint16_t* Y16, uint16_t* Ypre16, const uint16_t* G16, int M, int N, int K, int ldy, int act,
+                                 int tile, int fp16, void* stream);
 /* Test hooks for the LayerNorm folded around the 16-bit decode GEMMs (transformers GPT2Block: ln_1 -> c_attn, ln_2 -> c_fc;
  * src/language_model/language_model.py:338-366 runs them as separate modules).  rgrg_debug_ln_fold16: wb[n][k] =
  * round16(gain[k] w[n][k]), colsum[n] = sum_k wb[n][k] (of the ROUNDED values), shift[n] = bias[n] + sum_k beta[k] w[n][k].

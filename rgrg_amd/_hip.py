@@ -60,7 +60,7 @@ SIGNATURES = {
     "rgrg_decoder_set_precision": (_i, [_p, _i]),
     "rgrg_decoder_lm_forward": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "rgrg_decoder_lm_loss_grad": (_i, [_p, _p, _p, _p, _i, _i, C.c_float, C.c_float, C.c_uint64, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "rgrg_dropout_mask_f32": (_i, [C.c_uint64, C.c_uint32, C.c_float, C.c_int64, _p, _p]),
+    "rgrg_dropout_mask_f32": (_i, [C.c_uint64, C.c_uint32, C.c_float, C.c_int64, _i, _p, _p]),
     "rgrg_decoder_refresh_trainable": (_i, [_p, _p]),
     "rgrg_decoder_take_id_error": (_i, [_p, C.POINTER(_i)]),
     "rgrg_decoder_forward_cached": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
@@ -76,6 +76,7 @@ SIGNATURES = {
     "rgrg_linear_bf16w_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "rgrg_linear_bf16_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "rgrg_debug_linear_bf16_tile": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "rgrg_debug_linear_bf16_train": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rgrg_debug_ln_fold16": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "rgrg_debug_linear_bf16_ln": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "rgrg_decoder_copy_last_logits": (_i, [_p, _p, _i, _p]),

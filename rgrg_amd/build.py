@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "librgrg_hip.so")
-SOURCES = ("runtime.hip", "gemm_f32.hip", "gemm_bf16.hip", "detector_ops.hip", "det_train.hip", "decoder.hip", "train_ops.hip")
+SOURCES = ("runtime.hip", "gemm_f32.hip", "gemm_bf16.hip", "detector_ops.hip", "det_train.hip", "decoder.hip", "train_ops.hip", "attn_train16.hip")
 ARCH = "gfx950"
 
 
@@ -26,7 +26,7 @@ def _hipcc() -> str:
 
 
 HASH_PATH = os.path.join(LIB_DIR, "librgrg_hip.srchash")
-HEADERS = ("common.h", "skinny_direct.inc")
+HEADERS = ("common.h", "skinny_direct.inc", "persistent.inc")
 
 
 def _source_hash() -> str:

@@ -106,16 +106,19 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 
-// Counter-based dropout (training pass): Philox4x32-10 keyed by the call's seed, counter = (element index, stream id).
-// Every element's mask is a pure function of (seed, stream, index), so the backward pass recomputes exactly the
-// mask of the forward pass without storing it, in any kernel and in any order.  Returns 0 (dropped) or 1/(1-p).
+// Counter-based dropout (training pass): Philox4x32-10 keyed by the call's seed, counter = (element index / 4, stream id),
+// element i takes word i % 4 of its call - a kernel that owns 4 consecutive elements pays ONE generator call for them (round 5:
+// one call per element made the row kernels and the attention kernels generator-bound: ~440 cycles of quarter-rate integer
+// multiplies per wave call).  Every element's mask is a pure function of (seed, stream, index), so the backward pass
+// recomputes exactly the mask of the forward pass without storing it, in any kernel and in any order.  0 (dropped) or 1/(1-p).
 struct DropoutParams {
     unsigned long long seed;
     unsigned stream;  // layer * 4 + site (0 embedding, 1 attention probabilities, 2 attn c_proj output, 3 mlp c_proj output)
     float p;          // 0: no dropout (every helper short-circuits)
 };
-__host__ __device__ __forceinline__ unsigned philox_first_word(unsigned long long seed, unsigned stream, unsigned long long idx) {
-    unsigned c0 = (unsigned)idx, c1 = (unsigned)(idx >> 32), c2 = stream, c3 = 0u;
+struct Philox4 { unsigned w[4]; };
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsigned stream, unsigned long long ctr) {
+    unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = stream, c3 = 0u;
     unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -125,12 +128,45 @@ __host__ __device__ __forceinline__ unsigned philox_first_word(unsigned long lon
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    return c0;
+    return Philox4{{c0, c1, c2, c3}};
+}
+__host__ __device__ __forceinline__ float dropout_word_mask(const DropoutParams& d, unsigned w) {
+    const float u = (float)(w >> 8) * (1.0f / 16777216.0f);  // [0,1), 24 bits
+    return u < d.p ? 0.f : 1.0f / (1.0f - d.p);
+}
+// masks of the elements 4 * idx4 .. 4 * idx4 + 3
+__host__ __device__ __forceinline__ void dropout_mask4(const DropoutParams& d, unsigned long long idx4, float (&m)[4]) {
+    if (d.p <= 0.f) { m[0] = m[1] = m[2] = m[3] = 1.f; return; }
+    const Philox4 w = philox4x32_10(d.seed, d.stream, idx4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = dropout_word_mask(d, w.w[e]);
 }
 __host__ __device__ __forceinline__ float dropout_mask(const DropoutParams& d, unsigned long long idx) {
     if (d.p <= 0.f) return 1.f;
-    const float u = (float)(philox_first_word(d.seed, d.stream, idx) >> 8) * (1.0f / 16777216.0f);  // [0,1), 24 bits
-    return u < d.p ? 0.f : 1.0f / (1.0f - d.p);
+    const Philox4 w = philox4x32_10(d.seed, d.stream, idx >> 2);
+    const unsigned e = (unsigned)idx & 3u;
+    return dropout_word_mask(d, e == 0 ? w.w[0] : e == 1 ? w.w[1] : e == 2 ? w.w[2] : w.w[3]);
 }
+// Attention-probability masks (site 1) are indexed [sentence][head][query][key] with the key pitch rounded up to a multiple of 4,
+// so that 4 consecutive keys of one query share a generator call whatever T is.
+__host__ __device__ __forceinline__ int dropout_key_pitch(int n_keys) { return (n_keys + 3) & ~3; }
+
+#ifdef __HIPCC__
+// 4 x 4 transpose inside the lanes of a quad: lane i ends up with (lane 0's a_i, lane 1's a_i, lane 2's a_i, lane 3's a_i)
+template <int CTRL>
+__device__ __forceinline__ float quad_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ void quad_transpose4(float& a0, float& a1, float& a2, float& a3, bool odd, bool hi) {
+    float x = odd ? a0 : a1, y = quad_dpp<0xB1>(x);   // quad_perm [1,0,3,2]
+    if (odd) a0 = y; else a1 = y;
+    x = odd ? a2 : a3; y = quad_dpp<0xB1>(x);
+    if (odd) a2 = y; else a3 = y;
+    x = hi ? a0 : a2; y = quad_dpp<0x4E>(x);          // quad_perm [2,3,0,1]
+    if (hi) a0 = y; else a2 = y;
+    x = hi ? a1 : a3; y = quad_dpp<0x4E>(x);
+    if (hi) a1 = y; else a3 = y;
+}
+#endif
 
 }  // namespace rgrg

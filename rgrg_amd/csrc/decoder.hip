@@ -41,6 +41,8 @@ struct GemmLnFold {   // LayerNorm folded around the 16-bit GEMMs (gemm_bf16.hip
     float* stats_out = nullptr;         // ... and per-row (sum, sum of squares) slots [M][16][2]
     const float* ln_stats = nullptr;    // consumer: those slots
     const float* ln_colsum = nullptr;   // consumer: column sums of the gain-scaled rounded weights
+    void* Ypre16 = nullptr;             // training pass: 16-bit pre-activation copy next to the activated Y16 (c_fc)
+    const void* G16 = nullptr;          // training pass: saved 16-bit pre-activations, result *= gelu_new'(G16) (mlp_proj dgrad)
 };
 int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const float* shift, const float* R, float* Y, void* Y16,
                          int M, int N, int K, int ldy, int act, hipStream_t st, int f16, const GemmLnFold* ln = nullptr);
@@ -1068,7 +1070,8 @@ constexpr int TF_MAX_T = 1023;  // T + 1 keys <= the 1024 positions of GPT-2's c
 template <int NT>  // key tiles held in registers: T + 1 <= 32 * NT
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
                                                            int kcol, const float* __restrict__ am, float* __restrict__ out,
-                                                           int S, int H, int T, float* __restrict__ lse, const DropoutParams drop) {
+                                                           int S, int H, int T, float* __restrict__ lse, const DropoutParams drop,
+                                                           unsigned short* __restrict__ out16, int f16) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int QT = (T + 31) / 32;
     const int item = blockIdx.x * 4 + wave;
@@ -1159,7 +1162,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
             for (int j = 0; j < 16; ++j) {
                 float pj = sc[kt][j] / sum;
                 if (drop.p > 0.f)  // attn_dropout on the probabilities (training pass); index = [s][head][query][key]
-                    pj *= dropout_mask(drop, (((unsigned long long)s * H + hd) * T + min(iq, T - 1)) * NK +
+                    pj *= dropout_mask(drop, (((unsigned long long)s * H + hd) * T + min(iq, T - 1)) * dropout_key_pitch(NK) +
                                                  min(kt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half, NK - 1));
                 o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[j], pj, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[j], pj, o1, 0, 0, 0);
@@ -1174,6 +1177,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
             op[dim] = o0[r];
             op[32 + dim] = o1[r];
         }
+        if (out16) {   // 16-bit training flow: the copy attn_proj's GEMM reads (4 consecutive dims per 8-byte store)
+            unsigned short* o16 = out16 + ((size_t)s * T + iq) * D + hd * 64 + 4 * half;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                store_16x4(o16 + 8 * q4, f32x4{o0[4 * q4], o0[4 * q4 + 1], o0[4 * q4 + 2], o0[4 * q4 + 3]}, f16);
+                store_16x4(o16 + 32 + 8 * q4, f32x4{o1[4 * q4], o1[4 * q4 + 1], o1[4 * q4 + 2], o1[4 * q4 + 3]}, f16);
+            }
+        }
     }
 }
 
@@ -1183,7 +1194,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
 // score MFMAs of the register kernel; only long reports take this path.
 __global__ __launch_bounds__(256) void attn_prefill_stream_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
                                                                   int kcol, const float* __restrict__ am, float* __restrict__ out,
-                                                                  int S, int H, int T, float* __restrict__ lse, const DropoutParams drop) {
+                                                                  int S, int H, int T, float* __restrict__ lse, const DropoutParams drop,
+                                                                  unsigned short* __restrict__ out16, int f16) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int QT = (T + 31) / 32;
     const int item = blockIdx.x * 4 + wave;
@@ -1260,7 +1272,7 @@ __global__ __launch_bounds__(256) void attn_prefill_stream_kernel(const float* _
         for (int j = 0; j < 16; ++j) {
             float pj = expf(w[j] - m) / sum;
             if (drop.p > 0.f)
-                pj *= dropout_mask(drop, (((unsigned long long)s * H + hd) * T + min(iq, T - 1)) * NK +
+                pj *= dropout_mask(drop, (((unsigned long long)s * H + hd) * T + min(iq, T - 1)) * dropout_key_pitch(NK) +
                                              min(kt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half, NK - 1));
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[j], pj, o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[j], pj, o1, 0, 0, 0);
@@ -1274,6 +1286,14 @@ __global__ __launch_bounds__(256) void attn_prefill_stream_kernel(const float* _
             op[dim] = o0[r];
             op[32 + dim] = o1[r];
         }
+        if (out16) {   // 16-bit training flow: the copy attn_proj's GEMM reads (4 consecutive dims per 8-byte store)
+            unsigned short* o16 = out16 + ((size_t)s * T + iq) * D + hd * 64 + 4 * half;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                store_16x4(o16 + 8 * q4, f32x4{o0[4 * q4], o0[4 * q4 + 1], o0[4 * q4 + 2], o0[4 * q4 + 3]}, f16);
+                store_16x4(o16 + 32 + 8 * q4, f32x4{o1[4 * q4], o1[4 * q4 + 1], o1[4 * q4 + 2], o1[4 * q4 + 3]}, f16);
+            }
+        }
     }
 }
 
@@ -1284,15 +1304,15 @@ static bool prefill_stream_forced() {
 }
 
 static int launch_attn_prefill(const float* qkv, const float* ukv, int ld_ukv, int kcol, const float* am, float* out, int S, int H,
-                               int T, float* lse, const DropoutParams& drop, hipStream_t st) {
+                               int T, float* lse, const DropoutParams& drop, hipStream_t st, unsigned short* out16 = nullptr, int f16 = 0) {
     const int items = S * H * ((T + 31) / 32);
     const dim3 grid((items + 3) / 4), block(256);
     if (T + 1 > 256 || prefill_stream_forced())
-        hipLaunchKernelGGL(attn_prefill_stream_kernel, grid, block, 0, st, qkv, ukv, ld_ukv, kcol, am, out, S, H, T, lse, drop);
+        hipLaunchKernelGGL(attn_prefill_stream_kernel, grid, block, 0, st, qkv, ukv, ld_ukv, kcol, am, out, S, H, T, lse, drop, out16, f16);
     else if (T + 1 <= 96)
-        hipLaunchKernelGGL(attn_prefill_kernel<3>, grid, block, 0, st, qkv, ukv, ld_ukv, kcol, am, out, S, H, T, lse, drop);
+        hipLaunchKernelGGL(attn_prefill_kernel<3>, grid, block, 0, st, qkv, ukv, ld_ukv, kcol, am, out, S, H, T, lse, drop, out16, f16);
     else
-        hipLaunchKernelGGL(attn_prefill_kernel<8>, grid, block, 0, st, qkv, ukv, ld_ukv, kcol, am, out, S, H, T, lse, drop);
+        hipLaunchKernelGGL(attn_prefill_kernel<8>, grid, block, 0, st, qkv, ukv, ld_ukv, kcol, am, out, S, H, T, lse, drop, out16, f16);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
@@ -1474,6 +1494,17 @@ struct rgrg_decoder {
           *tr_dh1 = nullptr, *tr_row_lse = nullptr, *tr_att = nullptr, *tr_lse = nullptr, *tr_delta = nullptr;
     int* tr_count = nullptr;
     size_t tr_rows = 0, tr_seqs = 0;
+    // 16-bit activation flow of the training pass (autocast, > 128 token rows; round 5): every GEMM input is written as 16 bit
+    // by its producer - LayerNorm outputs, attention outputs, gelu outputs + the saved c_fc pre-activations of every layer,
+    // masked gradients, d(c_fc output), d(qkv), d(logits) of the chunk
+    unsigned short *tr_xn16 = nullptr, *tr_att16 = nullptr, *tr_ff16 = nullptr, *tr_ffpre16 = nullptr, *tr_dx16 = nullptr,
+                   *tr_dff16 = nullptr, *tr_dqkv16 = nullptr, *tr_dl16 = nullptr;
+    // ... and, for T + 1 <= 128 keys, the 16-bit attention kernels (attn_train16.hip): q / k / v and the attention output of
+    // every layer kept as 16 bit, d(attention output) and the image key / value of slot 0 as 16 bit
+    unsigned short *tr_qkv16 = nullptr, *tr_datt16 = nullptr, *tr_ukv16 = nullptr;
+    bool tr_a16 = false;
+    bool tr_h16 = false;       // what the current training work space was reserved for
+    size_t tr_chunk = 0;       // token rows per lm_head / cross-entropy chunk of that reservation
     bool have_wT = false;
     int bf16_gemms = 0;  // 1 (bf16) / 2 (fp16): 16-bit-weight MFMA GEMMs on the many-sequence path (not bit-exact; opt-in)
     int f16() const { return bf16_gemms == 2 ? 1 : 0; }   // the 16-bit type of that mode
@@ -2522,7 +2553,20 @@ int launch_transpose_pad(const float* src, float* dst, int R, int Cc, int Rp, hi
 int launch_colsum(const float* src, float* out, int R, int Cc, hipStream_t st);
 int launch_attn_backward(const float* qkv, const float* ukv, int ld_ukv, int kcol, const float* am, const float* d_att,
                          const float* att, const float* lse, float* delta, float* d_qkv, float* d_ukv, int S, int H, int T,
-                         DropoutParams drop, hipStream_t st);
+                         DropoutParams drop, hipStream_t st, unsigned short* d_qkv16 = nullptr, int f16 = 0, float ukv_scale = 1.0f);
+bool attn16_supported(int T);
+int launch_attn16_forward(const unsigned short* qkv16, const unsigned short* ukv16, int ld_ukv, int kcol, const float* am,
+                          unsigned short* out16, float* lse, int S, int H, int T, DropoutParams drop, int f16, hipStream_t st);
+int launch_attn16_backward(const unsigned short* qkv16, const unsigned short* ukv16, int ld_ukv, int kcol, const float* am,
+                           const unsigned short* d_att16, const unsigned short* att16, const float* lse, unsigned short* d_qkv16,
+                           float* d_ukv, int S, int H, int T, DropoutParams drop, float ukv_scale, int f16, hipStream_t st);
+int launch_resid_dropout_ln16(const float* y, const float* resid, float* x, const float* g, const float* b, unsigned short* xn16,
+                              DropoutParams drop, int f16, int rows, int D, hipStream_t st);
+int launch_ln_backward16(const float* dy, const float* x, const float* g, float* out, unsigned short* out16, int rows, int D,
+                         int accumulate, DropoutParams drop, int f16, hipStream_t st);
+int launch_ce_backward16(const float* logits, size_t ld, int V, int row0, int rows, const long long* ids, const int* row_valid,
+                         const float* row_lse, const int* n_scored, float scale, const int* id_error, unsigned short* out16, int f16,
+                         hipStream_t st);
 int launch_dropout_add(const float* src, const float* resid, float* out, size_t n, DropoutParams drop, hipStream_t st);
 
 static int pad32(int n) { return (n + 31) / 32 * 32; }
@@ -2561,19 +2605,53 @@ static void tr_free(rgrg_decoder* d) {
     for (float** f : fs) { if (*f) (void)hipFree(*f); *f = nullptr; }
     if (d->tr_count) (void)hipFree(d->tr_count);
     d->tr_count = nullptr;
+    unsigned short** hs[] = {&d->tr_xn16, &d->tr_att16, &d->tr_ff16, &d->tr_ffpre16, &d->tr_dx16, &d->tr_dff16, &d->tr_dqkv16, &d->tr_dl16,
+                             &d->tr_qkv16, &d->tr_datt16, &d->tr_ukv16};
+    for (unsigned short** h : hs) { if (*h) (void)hipFree(*h); *h = nullptr; }
     d->tr_rows = d->tr_seqs = 0;
+    d->tr_chunk = 0;
 }
 
-static int tr_reserve(rgrg_decoder* d, size_t rows, size_t seqs) {
-    if (rows <= d->tr_rows && seqs <= d->tr_seqs) return RGRG_OK;
+// The 16-bit flow runs lm_head + cross entropy over up to 16 384 token rows at a time (a configs[4] step = 14 848 rows in ONE
+// chunk: 3.3 GB of fp32 logits + 1.65 GB of 16-bit d(logits), 116 x 394 tiles per GEMM instead of eight launches of 16 x 394)
+constexpr int TR_LOGIT_ROWS_H16 = 16384;
+
+static int tr_reserve(rgrg_decoder* d, size_t rows, size_t seqs, bool h16, bool a16) {
+    if (rows <= d->tr_rows && seqs <= d->tr_seqs && h16 == d->tr_h16 && a16 == d->tr_a16) return RGRG_OK;
+    const size_t keep = d->tr_rows;
     tr_free(d);
-    rows = rows > d->tr_rows ? rows : d->tr_rows;
+    rows = rows > keep ? rows : keep;
     const size_t D = (size_t)d->D, L = (size_t)d->n_layer, Sp = (size_t)pad32((int)seqs), VP = (size_t)pad256(d->V);
-    const size_t chunk = rows < (size_t)TF_LOGIT_ROWS ? rows : (size_t)TF_LOGIT_ROWS;
+    const size_t cap = h16 ? (size_t)TR_LOGIT_ROWS_H16 : (size_t)TF_LOGIT_ROWS;
+    const size_t chunk = rows < cap ? rows : cap;
+    d->tr_h16 = h16;
+    d->tr_a16 = a16;
+    d->tr_chunk = chunk;
     RGRG_HIP(hipMalloc((void**)&d->tr_xs, (2 * L + 1) * rows * D * 4));
-    RGRG_HIP(hipMalloc((void**)&d->tr_qkv, L * rows * 3 * D * 4));
-    RGRG_HIP(hipMalloc((void**)&d->tr_ffpre, L * rows * 4 * D * 4));
-    RGRG_HIP(hipMalloc((void**)&d->tr_ff, rows * 4 * D * 4));
+    if (a16) {
+        RGRG_HIP(hipMalloc((void**)&d->tr_qkv16, L * rows * 3 * D * 2));
+        RGRG_HIP(hipMalloc((void**)&d->tr_att16, L * rows * D * 2));
+        RGRG_HIP(hipMalloc((void**)&d->tr_datt16, rows * D * 2));
+        RGRG_HIP(hipMalloc((void**)&d->tr_ukv16, seqs * (size_t)d->ld_ukv * 2));
+    } else {
+        RGRG_HIP(hipMalloc((void**)&d->tr_qkv, L * rows * 3 * D * 4));
+        RGRG_HIP(hipMalloc((void**)&d->tr_att, L * rows * D * 4));
+        RGRG_HIP(hipMalloc((void**)&d->tr_delta, rows * (size_t)d->H * 4));
+        if (h16) RGRG_HIP(hipMalloc((void**)&d->tr_att16, rows * D * 2));
+    }
+    if (h16) {
+        RGRG_HIP(hipMalloc((void**)&d->tr_xn16, rows * D * 2));
+        RGRG_HIP(hipMalloc((void**)&d->tr_ff16, rows * 4 * D * 2));
+        RGRG_HIP(hipMalloc((void**)&d->tr_ffpre16, L * rows * 4 * D * 2));
+        RGRG_HIP(hipMalloc((void**)&d->tr_dx16, rows * D * 2));
+        RGRG_HIP(hipMalloc((void**)&d->tr_dff16, rows * 4 * D * 2));
+        RGRG_HIP(hipMalloc((void**)&d->tr_dqkv16, rows * 3 * D * 2));
+        RGRG_HIP(hipMalloc((void**)&d->tr_dl16, chunk * VP * 2));
+        RGRG_HIP(hipMemset(d->tr_dl16, 0, chunk * VP * 2));   // the K-padding columns stay 0 for the backward GEMM
+    } else {
+        RGRG_HIP(hipMalloc((void**)&d->tr_ffpre, L * rows * 4 * D * 4));
+        RGRG_HIP(hipMalloc((void**)&d->tr_ff, rows * 4 * D * 4));
+    }
     RGRG_HIP(hipMalloc((void**)&d->tr_dx, rows * D * 4));
     RGRG_HIP(hipMalloc((void**)&d->tr_dbig, rows * 4 * D * 4));
     RGRG_HIP(hipMalloc((void**)&d->tr_dxn, rows * D * 4));
@@ -2585,9 +2663,7 @@ static int tr_reserve(rgrg_decoder* d, size_t rows, size_t seqs) {
     RGRG_HIP(hipMalloc((void**)&d->tr_dimg, seqs * D * 4));
     RGRG_HIP(hipMalloc((void**)&d->tr_dh1, seqs * D * 4));
     RGRG_HIP(hipMalloc((void**)&d->tr_row_lse, rows * 4));
-    RGRG_HIP(hipMalloc((void**)&d->tr_att, L * rows * D * 4));
     RGRG_HIP(hipMalloc((void**)&d->tr_lse, L * rows * (size_t)d->H * 4));
-    RGRG_HIP(hipMalloc((void**)&d->tr_delta, rows * (size_t)d->H * 4));
     RGRG_HIP(hipMalloc((void**)&d->tr_count, 4));
     d->tr_rows = rows;
     d->tr_seqs = seqs;
@@ -2611,6 +2687,124 @@ static int tr_lin(rgrg_decoder* d, const Lin& l, bool transposed, const float* X
         return bf16_linear_f32in(d, X, Wb, b, R, Y, M, N, K, ldy, act);
     return launch_gemm_dense(X, W, b, R, Y, M, N, K, ldy, act, d->tf_ws, d->tf_ws_floats, d->stream);
 }
+// the same on 16-bit activations that their producer wrote (16-bit flow): no conversion pass, optional 16-bit output and the
+// training epilogues (GemmLnFold::Ypre16 / G16)
+static int tr_lin16(rgrg_decoder* d, const Lin& l, bool transposed, const unsigned short* A16, const float* R, float* Y,
+                    unsigned short* Y16, int M, int ldy, int act = RGRG_ACT_NONE, const GemmLnFold* ex = nullptr) {
+    const int N = transposed ? l.K : l.N, K = transposed ? pad256(l.N) : l.K;
+    const void* Wb = transposed ? l.wTb : l.wb;
+    if (!Wb || K % 256 != 0) { set_error("decoder: 16-bit weights missing for a training GEMM (N %d, K %d)", N, K); return RGRG_EINVAL; }
+    return launch_gemm_bf16w_ex(nullptr, A16, Wb, transposed ? nullptr : l.b, R, Y, Y16, M, N, K, ldy, act, d->stream, d->f16(), ex);
+}
+
+// Forward (keeping what the backward needs), lm_head + loss + d(logits), and the backward through the 24 frozen blocks of
+// rgrg_decoder_lm_loss_grad in the 16-bit activation flow (tr_h16).  Per layer, forward: c_attn (xn16 -> qkv fp32) ->
+// attention (-> att fp32 + att16) -> attn_proj (-> y) -> x_mid = x_in + dropout(y), xn16 = ln_2(x_mid) [one kernel] ->
+// c_fc (-> ffpre16 kept + ff16 = gelu) -> mlp_proj (-> y) -> x_out = x_mid + dropout(y), xn16 = next LayerNorm [one kernel].
+// Backward: mlp_proj^T with the gelu' epilogue (dx16 -> dff16) -> c_fc^T (-> dxn) -> ln_2 backward (dx +=, dx16 = masked copy)
+// -> attn_proj^T (-> d_att) -> attention backward (-> dqkv16, d_ukv) -> c_attn^T (-> dxn) -> ln_1 backward.
+// fp16: gradients carry an internal scale of 2^15 from d(logits) to d_ukv (where the attention backward removes it), like
+// the reference's GradScaler keeps fp16 gradients out of the flush-to-zero range (train_full_model.py:172-237).
+static int tr_body16(rgrg_decoder* d, const long long* ids, const float* attention_mask, int S, int T, float loss_scale,
+                     float dropout_p, uint64_t dropout_seed, float* loss_out) {
+    const int D = d->D, M = S * T, L = d->n_layer, V = d->V, VP = pad256(V), LD = d->ld_ukv, f16 = d->f16();
+    hipStream_t st = d->stream;
+    const size_t MD = (size_t)M * D;
+    int rc;
+    auto xs = [&](int i) { return d->tr_xs + (size_t)i * MD; };
+    auto dp = [&](int l, int site) { return DropoutParams{dropout_seed, (unsigned)(l * 4 + site), dropout_p}; };
+    const DropoutParams none{0ull, 0u, 0.f};
+    const float s_int = f16 ? 32768.0f : 1.0f;
+    float* y = d->tr_dbig;   // [M, D] scratch for a projection's output in front of the residual / dropout / LayerNorm kernel
+    const bool a16 = d->tr_a16;
+    if (a16 && (rc = convert_f32_to_bf16(d->ukv_out, d->tr_ukv16, (size_t)S * LD, st, f16))) return rc;
+
+    hipLaunchKernelGGL(embed_seq_ln_kernel, dim3(M), dim3(256), 0, st, d->wte, ids, T, d->layers[0].ln1_g, d->layers[0].ln1_b,
+                       xs(0), d->tf_xn, D, d->V, d->id_error);
+    RGRG_LAUNCH_CHECK();
+    // self.drop on the embeddings (language_model.py:311) and ln_1 of layer 0 as 16 bit
+    if ((rc = launch_resid_dropout_ln16(xs(0), nullptr, xs(0), d->layers[0].ln1_g, d->layers[0].ln1_b, d->tr_xn16, dp(0, 0), f16, M, D, st)))
+        return rc;
+    for (int l = 0; l < L; ++l) {
+        const LayerW& w = d->layers[l];
+        const float* ng = (l + 1 < L) ? d->layers[l + 1].ln1_g : d->lnf_g;
+        const float* nb = (l + 1 < L) ? d->layers[l + 1].ln1_b : d->lnf_b;
+        float* qkv = a16 ? nullptr : d->tr_qkv + (size_t)l * M * 3 * D;
+        unsigned short* ffpre16 = d->tr_ffpre16 + (size_t)l * M * 4 * D;
+        float* att = a16 ? nullptr : d->tr_att + (size_t)l * MD;
+        float* lse = d->tr_lse + (size_t)l * M * d->H;
+        if (a16) {
+            unsigned short* qkv16 = d->tr_qkv16 + (size_t)l * M * 3 * D;
+            unsigned short* att16 = d->tr_att16 + (size_t)l * MD;
+            if ((rc = tr_lin16(d, w.c_attn, false, d->tr_xn16, nullptr, nullptr, qkv16, M, 3 * D))) return rc;
+            if ((rc = launch_attn16_forward(qkv16, d->tr_ukv16, LD, l * 2 * D, attention_mask, att16, lse, S, d->H, T, dp(l, 1), f16, st)))
+                return rc;
+            if ((rc = tr_lin16(d, w.attn_proj, false, att16, nullptr, y, nullptr, M, D))) return rc;
+        } else {
+            if ((rc = tr_lin16(d, w.c_attn, false, d->tr_xn16, nullptr, qkv, nullptr, M, 3 * D))) return rc;
+            if ((rc = launch_attn_prefill(qkv, d->ukv_out, LD, l * 2 * D, attention_mask, att, S, d->H, T, lse, dp(l, 1), st, d->tr_att16, f16)))
+                return rc;
+            if ((rc = tr_lin16(d, w.attn_proj, false, d->tr_att16, nullptr, y, nullptr, M, D))) return rc;
+        }
+        if ((rc = launch_resid_dropout_ln16(y, xs(2 * l), xs(2 * l + 1), w.ln2_g, w.ln2_b, d->tr_xn16, dp(l, 2), f16, M, D, st))) return rc;
+        GemmLnFold pre{};
+        pre.Ypre16 = ffpre16;
+        if ((rc = tr_lin16(d, w.c_fc, false, d->tr_xn16, nullptr, nullptr, d->tr_ff16, M, 4 * D, RGRG_ACT_GELU_NEW, &pre))) return rc;
+        if ((rc = tr_lin16(d, w.mlp_proj, false, d->tr_ff16, nullptr, y, nullptr, M, D))) return rc;
+        if ((rc = launch_resid_dropout_ln16(y, xs(2 * l + 1), xs(2 * l + 2), ng, nb, d->tr_xn16, dp(l, 3), f16, M, D, st))) return rc;
+    }
+    // lm_head + loss + d(logits) + d(ln_f output), chunk by chunk
+    hipLaunchKernelGGL(ce_valid_kernel, dim3((M + 255) / 256), dim3(256), 0, st, attention_mask, T, M, d->tf_row_loss, d->tf_row_valid);
+    RGRG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, d->tf_row_loss, d->tf_row_valid, M, (float*)nullptr, d->tr_count);
+    RGRG_LAUNCH_CHECK();
+    const int chunk = (int)d->tr_chunk;
+    for (int r0 = 0; r0 < M; r0 += chunk) {
+        const int rows = (M - r0 < chunk) ? M - r0 : chunk;
+        if ((rc = tr_lin16(d, d->lm_head, false, d->tr_xn16 + (size_t)r0 * D, nullptr, d->tr_logits, nullptr, rows, VP))) return rc;
+        hipLaunchKernelGGL(ce_rows_kernel, dim3(rows), dim3(256), 0, st, d->tr_logits, (size_t)VP, V, r0, ids, attention_mask, T,
+                           d->tf_row_loss, d->tf_row_valid, d->tr_row_lse, d->id_error);
+        RGRG_LAUNCH_CHECK();
+        if ((rc = launch_ce_backward16(d->tr_logits, (size_t)VP, V, r0, rows, ids, d->tf_row_valid, d->tr_row_lse, d->tr_count,
+                                       loss_scale * s_int, d->id_error, d->tr_dl16, f16, st)))
+            return rc;
+        if ((rc = tr_lin16(d, d->lm_head, true, d->tr_dl16, nullptr, d->tr_dxn + (size_t)r0 * D, nullptr, rows, D))) return rc;
+    }
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, d->tf_row_loss, d->tf_row_valid, M, loss_out, (int*)nullptr,
+                       d->id_error);
+    RGRG_LAUNCH_CHECK();
+    if ((rc = id_error_end(d))) return rc;
+    // backward through ln_f and the 24 frozen blocks; dx16 always carries the mask of the branch the gradient enters next
+    if ((rc = launch_ln_backward16(d->tr_dxn, xs(2 * L), d->lnf_g, d->tr_dx, d->tr_dx16, M, D, 0, dp(L - 1, 3), f16, st))) return rc;
+    for (int l = L - 1; l >= 0; --l) {
+        const LayerW& w = d->layers[l];
+        float* qkv = a16 ? nullptr : d->tr_qkv + (size_t)l * M * 3 * D;
+        GemmLnFold gb{};
+        gb.G16 = d->tr_ffpre16 + (size_t)l * M * 4 * D;
+        if ((rc = tr_lin16(d, w.mlp_proj, true, d->tr_dx16, nullptr, nullptr, d->tr_dff16, M, 4 * D, RGRG_ACT_NONE, &gb))) return rc;
+        if ((rc = tr_lin16(d, w.c_fc, true, d->tr_dff16, nullptr, d->tr_dxn, nullptr, M, D))) return rc;
+        if ((rc = launch_ln_backward16(d->tr_dxn, xs(2 * l + 1), w.ln2_g, d->tr_dx, d->tr_dx16, M, D, 1, dp(l, 2), f16, st))) return rc;
+        if (a16) {
+            if ((rc = tr_lin16(d, w.attn_proj, true, d->tr_dx16, nullptr, nullptr, d->tr_datt16, M, D))) return rc;
+            if ((rc = launch_attn16_backward(d->tr_qkv16 + (size_t)l * M * 3 * D, d->tr_ukv16, LD, l * 2 * D, attention_mask, d->tr_datt16,
+                                             d->tr_att16 + (size_t)l * MD, d->tr_lse + (size_t)l * M * d->H, d->tr_dqkv16, d->tr_dukv, S,
+                                             d->H, T, dp(l, 1), 1.0f / s_int, f16, st)))
+                return rc;
+        } else {
+            if ((rc = tr_lin16(d, w.attn_proj, true, d->tr_dx16, nullptr, d->tf_att, nullptr, M, D))) return rc;
+            if ((rc = launch_attn_backward(qkv, d->ukv_out, LD, l * 2 * D, attention_mask, d->tf_att, d->tr_att + (size_t)l * MD,
+                                           d->tr_lse + (size_t)l * M * d->H, d->tr_delta, nullptr, d->tr_dukv, S, d->H, T, dp(l, 1), st,
+                                           d->tr_dqkv16, f16, 1.0f / s_int)))
+                return rc;
+        }
+        if ((rc = tr_lin16(d, w.c_attn, true, d->tr_dqkv16, nullptr, d->tr_dxn, nullptr, M, D))) return rc;
+        // the gradient enters layer l - 1 through its mlp branch (site 3); below layer 0 nothing reads the 16-bit copy
+        if ((rc = launch_ln_backward16(d->tr_dxn, xs(2 * l), w.ln1_g, d->tr_dx, l > 0 ? d->tr_dx16 : nullptr, M, D, 1,
+                                       l > 0 ? dp(l - 1, 3) : none, f16, st)))
+            return rc;
+    }
+    return RGRG_OK;
+}
 }  // namespace rgrg
 
 extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, const int64_t* input_ids,
@@ -2625,7 +2819,9 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
     const int D = d->D, M = S * T, L = d->n_layer, V = d->V, VP = pad256(V), Sp = pad32(S), LD = d->ld_ukv;
     int rc;
     if ((rc = check_id_error(d))) return rc;
-    if ((rc = tf_reserve(d, (size_t)M)) || (rc = tr_reserve(d, (size_t)M, (size_t)S))) return rc;
+    const bool h16 = d->bf16_gemms && M > skinny_max_rows();   // 16-bit activation flow (tr_body16)
+    const bool a16 = h16 && attn16_supported(T);               // ... with the 16-bit attention kernels
+    if ((rc = tf_reserve(d, (size_t)M)) || (rc = tr_reserve(d, (size_t)M, (size_t)S, h16, a16))) return rc;
     hipStream_t caller = as_stream(stream), st = d->stream;
     RGRG_HIP(hipEventRecord(d->ev_in, caller));
     RGRG_HIP(hipStreamWaitEvent(st, d->ev_in, 0));
@@ -2640,6 +2836,9 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
     if ((rc = linear(d, d->fst0, d->feats, nullptr, d->h1, S, D, RGRG_ACT_RELU, false))) return rc;
     if ((rc = linear(d, d->fst2, d->h1, nullptr, d->img, S, D, RGRG_ACT_NONE, false))) return rc;
     if ((rc = linear(d, d->ukv, d->img, nullptr, d->ukv_out, S, LD, RGRG_ACT_NONE, false))) return rc;
+    if (h16) {
+        if ((rc = tr_body16(d, ids, attention_mask, S, T, loss_scale, dropout_p, dropout_seed, loss_out))) return rc;
+    } else {
     hipLaunchKernelGGL(embed_seq_ln_kernel, dim3(M), dim3(256), 0, st, d->wte, ids, T, d->layers[0].ln1_g, d->layers[0].ln1_b,
                        xs(0), d->tf_xn, D, d->V, d->id_error);
     RGRG_LAUNCH_CHECK();
@@ -2728,6 +2927,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
         if ((rc = tr_lin(d, w.c_attn, true, d->tr_dbig, nullptr, d->tr_dxn, M, D))) return rc;
         if ((rc = launch_ln_backward(d->tr_dxn, xs(2 * l), w.ln1_g, d->tr_dx, M, D, 1, st))) return rc;
     }
+    }   // fp32-activation flow
     // ---------------- uk / uv of every layer (one stacked Linear) and feature_space_transformation_nn
     if ((rc = launch_colsum(d->tr_dukv, grad_ukv_b, S, LD, st))) return rc;
     if ((rc = tr_gemm(d, d->tr_dukv, d->ukv.wT, nullptr, nullptr, d->tr_dimg, S, D, pad256(LD), D))) return rc;

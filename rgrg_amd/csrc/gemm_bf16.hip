@@ -24,6 +24,8 @@ struct GemmLnFold {
     float* stats_out = nullptr;
     const float* ln_stats = nullptr;
     const float* ln_colsum = nullptr;
+    void* Ypre16 = nullptr;       // training pass: GemmBf16Params::Ypre16 / G16
+    const void* G16 = nullptr;
 };
 
 struct GemmBf16Params {
@@ -52,6 +54,16 @@ struct GemmBf16Params {
     float* stats_out = nullptr;
     const float* ln_stats = nullptr;
     const float* ln_colsum = nullptr;
+    // training pass (round 5, LDS-DMA kernel, plain variant): Ypre16 [M, ldy] receives the 16-bit PRE-activation value next to
+    // the activated Y16 (c_fc keeps what gelu_new' needs); G16 [M, ldy] holds 16-bit pre-activations whose gelu_new' multiplies
+    // the result (the dgrad of mlp_proj lands directly as d(c_fc output))
+    u16* Ypre16 = nullptr;
+    const u16* G16 = nullptr;
+    // tile order (LDS-DMA kernel): row tiles are walked in groups of gm (all column tiles of a group before the next group,
+    // rows fastest inside a column), so the ~64 workgroups an XCD runs at a time form a gm x (64 / gm) block of the tile grid
+    // and its L2 serves gm + 64 / gm operand panels instead of 65.  gm >= mtiles (or 0) = one group = column-major order.
+    int gm = 0;
+    int dbg = 0;   // ping-pong kernel, measurements only (RGRG_PP_DBG): 1 no fragment reads, 2 no refill DMAs, 4 no MFMAs, 8 no stores
 };
 
 constexpr float LN_EPS16 = 1e-5f;   // nn.LayerNorm(eps=1e-5) of GPT-2
@@ -288,6 +300,14 @@ __device__ __forceinline__ float gelu_new_fast(float x) {
     const float u = x * (1.0f + 0.044715f * x * x);
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.302208198f * u));  // -2 * sqrt(2/pi) * log2(e)
 }
+// gelu_new'(x) with s = sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3):  tanh u = 2s - 1, so
+//   0.5 (1 + tanh u) + 0.5 x (1 - tanh^2 u) u'  =  s + 2 x s (1 - s) sqrt(2/pi) (1 + 3 * 0.044715 x^2)
+__device__ __forceinline__ float gelu_new_grad_fast(float x) {
+    const float x2 = x * x;
+    const float u = x * (1.0f + 0.044715f * x2);
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.302208198f * u));
+    return sg + 2.0f * x * sg * (1.0f - sg) * 0.7978845608028654f * (1.0f + 0.134145f * x2);
+}
 __device__ __forceinline__ float apply_act_fast(float v, int act) {
     if (act == RGRG_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == RGRG_ACT_GELU_NEW) return gelu_new_fast(v);
@@ -371,7 +391,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
         const int total = mtiles * ntiles, q = total >> 3, r = total & 7, x = t & 7, i = t >> 3;
         t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
-    const int tn = t / mtiles, tm = t - tn * mtiles;
+    int tn, tm;
+    if (p.gm <= 0 || p.gm >= mtiles) {
+        tn = t / mtiles; tm = t - tn * mtiles;
+    } else {   // grouped order (GemmBf16Params::gm): all groups but the last hold gm row tiles
+        const int gsz = p.gm * ntiles, g = t / gsz, r = t - g * gsz;
+        const int rows = min(p.gm, mtiles - g * p.gm);
+        tn = r / rows; tm = g * p.gm + (r - tn * rows);
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int nk = p.K / BK;
     const int lda = p.lda ? p.lda : p.K, ldw = p.ldw ? p.ldw : p.K;
@@ -563,6 +590,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
                     const float2 st = row_stat[lrow0 + (r & 3) + 8 * (r >> 2)];
                     vv[r] = apply_act_fast(st.y * (acc[mi][ni][r] - st.x * cs) + sh + rv[r], p.act);
                 }
+            } else if constexpr (LNF == 0 && !CONV) {
+                if (p.G16) {   // dgrad through gelu_new: the result times gelu_new'(saved pre-activation)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+                        rv[r] = from16<F16>(p.G16[(size_t)row * p.ldy + colc]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) vv[r] = (acc[mi][ni][r] + sh) * gelu_new_grad_fast(rv[r]);
+                } else {
+                    if (p.Ypre16 && col < p.N) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int dr = (r & 3) + 8 * (r >> 2);
+                            if (rbase + dr < p.M)
+                                p.Ypre16[(size_t)rbase * p.ldy + col + (size_t)(dr * p.ldy)] = (u16)to16<F16>(acc[mi][ni][r] + sh + rv[r]);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) vv[r] = apply_act_fast(acc[mi][ni][r] + sh + rv[r], p.act);
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) vv[r] = apply_act_fast(acc[mi][ni][r] + sh + rv[r], p.act);
@@ -635,6 +683,306 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
     }
 }
 
+// ------------------------------------------------------------------ 256 x 256 ping-pong kernel (round 5): both operands 16-bit
+// The kernel for the LARGE GEMMs (training step at M = 14 848 rows, fc6, lm_head over thousands of rows).  What bounds the
+// 128 x 128 kernel above on such shapes is not the matrix core but operand delivery: a 128 x 128 x 64 K tile moves 32 KiB
+// L2 -> LDS for 16 MFMAs per wave, and the texture-address path of a CU takes 64 B per clock - with two workgroups per CU that
+// is 100 % of it for 100 % of the matrix core (measured ceiling ~0.35-0.4 of peak).  A 256 x 256 tile halves the bytes per flop.
+//   * 8 waves = two GROUPS of four (group g = rows g * 128 .. + 128 of the tile; wave wq of a group = columns wq * 64 .. + 64), a
+//     wave owns 128 x 64 = 4 x 2 blocks of v_mfma_f32_32x32x16 (128 accumulator registers); waves w and w + 4 share a SIMD;
+//   * PING-PONG: time is cut into slots by workgroup barriers; in every slot ONE group multiplies (16 MFMAs per wave on
+//     fragments already in registers) while the OTHER reads its next fragments from LDS and issues the LDS-DMA requests -
+//     every SIMD always has one wave in the matrix core and one on the LDS / DMA side, and the multiplying waves issue nothing
+//     but MFMAs.  A wave's K tile is split by ROWS: first its rows 0..63 against its 64 columns (A and W fragments of the whole
+//     K tile: 16 ds_read_b128), then its rows 64..127 (8 reads; the W fragments stay in registers):
+//         slot      group 0                         group 1
+//         4kt + 0   read A-lo[0:64], W  of kt       multiply rows 64.. of kt - 1
+//         4kt + 1   multiply rows 0..63             read A-hi[0:64], W of kt
+//         4kt + 2   read A-lo[64:128]               multiply rows 0..63
+//         4kt + 3   multiply rows 64..127           read A-hi[64:128]
+//   * two LDS stages of (256 + 256) rows x 128 B = 2 x 64 KiB (one workgroup per CU).  Every row group of a stage is read in
+//     exactly ONE slot of a K tile (W in two: slots 0 and 1), so it is REFILLED - with the rows of the K tile two ahead - by the
+//     reading group of a following slot, and every request has at least FOUR slots (~1 us) to land before its rows are read
+//     (measured: a request lands ~700 cycles after issue under this load, `profiles/r05_pp_ablation_*.log`):
+//         issued in slot    by        A rows (64 = 8 instructions of 1 KiB)     W rows
+//         4kt + 0           group 0   A-hi[64:128] of kt + 1                    -
+//         4kt + 1           group 1   A-lo[0:64]   of kt + 2                    -
+//         4kt + 2           group 0   A-hi[0:64]   of kt + 2                    W[0:128]   of kt + 2 (16 instructions)
+//         4kt + 3           group 1   A-lo[64:128] of kt + 2                    W[128:256] of kt + 2
+//     A reading wave issues its 2 or 6 requests behind its ds_reads and then waits `vmcnt(8)`: all but its requests of this and
+//     of its previous reading slot have landed (loads return in order); `lgkmcnt(0)` before the barrier frees the rows it read;
+//   * tile order as in the kernel above (XCD bands, grouped rows); shift, residual, activation, 16-bit outputs, gelu' multiplier.
+//     No LayerNorm fold, no convolution (the callers of those shapes have few row tiles).
+template <int TAG>
+__device__ __forceinline__ void pp_dma4(const u16* base, unsigned char* dst, const int (&v)[4], int soff) {
+    const __amdgpu_buffer_rsrc_t r = bf16_rsrc(base);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dst + j * 8192), 16, v[j], soff, 0, 0);
+}
+template <int TAG>
+__device__ __forceinline__ void pp_dma2(const u16* base, unsigned char* dst, int v0, int v1, int soff) {
+    const __amdgpu_buffer_rsrc_t r = bf16_rsrc(base);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, v0, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dst + 1024), 16, v1, soff, 0, 0);
+}
+template <bool F16>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmBf16Params p, const int mtiles, const int ntiles) {
+    constexpr int BM = 256, BN = 256, BK = 64, MI = 4, NI = 2;
+    constexpr int STAGE = (BM + BN) * 128, WOFF = BM * 128;
+    constexpr int TAG = F16 ? 901 : 900;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pp_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, wq = wave & 3;
+    int t = blockIdx.x;
+    {
+        const int total = mtiles * ntiles, q = total >> 3, r = total & 7, x = t & 7, i = t >> 3;
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    int tn, tm;
+    if (p.gm <= 0 || p.gm >= mtiles) {
+        tn = t / mtiles; tm = t - tn * mtiles;
+    } else {
+        const int gsz = p.gm * ntiles, gi = t / gsz, r = t - gi * gsz;
+        const int rows = min(p.gm, mtiles - gi * p.gm);
+        tn = r / rows; tm = gi * p.gm + (r - tn * rows);
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = p.K / BK;
+    const int lda = p.lda ? p.lda : p.K, ldw = p.ldw ? p.ldw : p.K;
+    const u16* abase = p.A16 + (size_t)m0 * lda;
+    const u16* wbase = p.Wb + (size_t)n0 * ldw;
+    const int lrow = lane >> 3, lch = lane & 7;
+    // per-lane source offset (bytes) of the 8 tile rows [row0, row0 + 8) of an operand: row clamp + XOR-swizzled 16-byte chunk
+    auto src_off = [&](int row0, int limit, int ld) { const int row = row0 + lrow; return min(row, limit) * ld * 2 + ((lch ^ ((row >> 1) & 7)) << 4); };
+    // steady state (table above): in its first reading slot of a K tile a wave refills 16 rows of one A unit, in its second
+    // 16 rows of another A unit and 16 rows of each of two 64-row W units
+    const int ra0 = (g == 0 ? 192 : 0) + wq * 16, ra1 = (g == 0 ? 128 : 64) + wq * 16;
+    const int rw0 = (g == 0 ? 0 : 128) + wq * 16, rw1 = rw0 + 64;
+    const int va00 = src_off(ra0, p.M - 1 - m0, lda), va01 = src_off(ra0 + 8, p.M - 1 - m0, lda);
+    const int va10 = src_off(ra1, p.M - 1 - m0, lda), va11 = src_off(ra1 + 8, p.M - 1 - m0, lda);
+    const int vw00 = src_off(rw0, p.N - 1 - n0, ldw), vw01 = src_off(rw0 + 8, p.N - 1 - n0, ldw);
+    const int vw10 = src_off(rw1, p.N - 1 - n0, ldw), vw11 = src_off(rw1 + 8, p.N - 1 - n0, ldw);
+    unsigned char* const da0 = pp_smem + ra0 * 128;          // + stage * STAGE
+    unsigned char* const da1 = pp_smem + ra1 * 128;
+    unsigned char* const dw0 = pp_smem + WOFF + rw0 * 128;
+    unsigned char* const dw1 = pp_smem + WOFF + rw1 * 128;
+    // fragment reads: lane -> (row = lane & 31, k half = lane >> 5) of a 32-row block, 4 K steps of 16 per tile
+    const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * 128 + (((2 * ks + fh) ^ fsw) << 4);
+    const unsigned char* const fa_base = pp_smem + g * (128 * 128);
+    const unsigned char* const fb_base = pp_smem + WOFF + wq * (64 * 128);
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    bf16x8 fa[4][2], fb[4][NI];   // [K step][32-row block of the current row half] / [K step][32-column block]
+    // the shift of this lane's two output columns, requested ahead of the operand stream (loaded in the epilogue, between the
+    // stores of two blocks, a load's wait also waits for every store issued before it: one counter, in order)
+    float esh[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) esh[ni] = p.shift ? p.shift[min(n0 + wq * 64 + ni * 32 + (lane & 31), p.N - 1)] : 0.f;
+    const int dbg = __builtin_amdgcn_readfirstlane(p.dbg);
+    if (dbg) {   // measurement modes: defined operands whatever is skipped
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { fa[ks][i] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; fb[ks][i] = bf16x8{8, 7, 6, 5, 4, 3, 2, 1}; }
+    }
+
+#define PP_READ_A(ST_, H_)                                                                                       \
+    if (!(dbg & 1)) {                                                                                            \
+        const unsigned char* sa_ = fa_base + (ST_) * STAGE + (H_) * (64 * 128);                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                         \
+            _Pragma("unroll") for (int m2 = 0; m2 < 2; ++m2)                                                     \
+                fa[ks][m2] = *reinterpret_cast<const bf16x8*>(sa_ + m2 * 4096 + foff[ks]);                       \
+    }
+#define PP_READ_W(ST_)                                                                                           \
+    if (!(dbg & 1)) {                                                                                            \
+        const unsigned char* sw_ = fb_base + (ST_) * STAGE;                                                      \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                         \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                    \
+                fb[ks][ni] = *reinterpret_cast<const bf16x8*>(sw_ + ni * 4096 + foff[ks]);                       \
+    }
+    // 16 MFMAs of row half H_
+#define PP_MUL(H_)                                                                                               \
+    if (!(dbg & 4)) {                                                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                                           \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                         \
+            _Pragma("unroll") for (int m2 = 0; m2 < 2; ++m2)                                                     \
+                _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                \
+                    acc[(H_) * 2 + m2][ni] = mfma16<F16>(fa[ks][m2], fb[ks][ni], acc[(H_) * 2 + m2][ni]);        \
+        __builtin_amdgcn_s_setprio(0);                                                                           \
+    }
+#define PP_BAR()                                  \
+    {                                             \
+        __builtin_amdgcn_sched_barrier(0);        \
+        __builtin_amdgcn_s_barrier();             \
+        __builtin_amdgcn_sched_barrier(0);        \
+    }
+    // end of a reading slot: this slot's refills (FIRST_: the group's first reading slot of the K tile - one A unit into K tile
+    // TA_; else one A unit and two W units into K tile TA_), the rows just read are free (lgkmcnt), all but the WAIT_ youngest
+    // requests of this wave have landed, barrier
+#define PP_END_READ(FIRST_, DO_, TA_, WAIT_)                                                                                  \
+    {                                                                                                                          \
+        if ((DO_) && !(dbg & 2)) {                                                                                             \
+            pp_dma2<TAG>(abase, ((FIRST_) ? da0 : da1) + ((TA_) & 1) * STAGE, (FIRST_) ? va00 : va10, (FIRST_) ? va01 : va11, (TA_) * (BK * 2)); \
+            if (!(FIRST_)) {                                                                                                   \
+                pp_dma2<TAG>(wbase, dw0 + ((TA_) & 1) * STAGE, vw00, vw01, (TA_) * (BK * 2));                                  \
+                pp_dma2<TAG>(wbase, dw1 + ((TA_) & 1) * STAGE, vw10, vw11, (TA_) * (BK * 2));                                  \
+            }                                                                                                                  \
+        }                                                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                     \
+        if (dbg & 2) wait_vmcnt<0>(); else wait_vmcnt<WAIT_>();                                                                \
+        PP_BAR()                                                                                                               \
+    }
+
+    // prologue: K tiles 0 and 1 requested by all eight waves (both stages are free), tile 0 waited for
+    {
+        int vpa[4], vpw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            vpa[j] = src_off((j * 8 + wave) * 8, p.M - 1 - m0, lda);
+            vpw[j] = src_off((j * 8 + wave) * 8, p.N - 1 - n0, ldw);
+        }
+        unsigned char* const dst = pp_smem + wave * 1024;
+        pp_dma4<TAG>(wbase, dst + WOFF, vpw, 0);
+        pp_dma4<TAG>(abase, dst, vpa, 0);
+        pp_dma4<TAG>(wbase, dst + STAGE + WOFF, vpw, BK * 2);
+        pp_dma4<TAG>(abase, dst + STAGE, vpa, BK * 2);
+    }
+    wait_vmcnt<8>();
+    PP_BAR()
+
+    // One K tile of a group's program (both groups pass the same four barriers).  D0_ / D2_ (D1_ / D3_): do the refills of the
+    // group's two reading slots exist for this kt (K tiles 0 and 1 come from the prologue; nothing lies beyond tile nk - 1);
+    // W0_ .. W3_: how many of the wave's youngest requests may still be in flight at the end of that slot.
+#define PP_TILE_G0(D0_, W0_, D2_, W2_)                                              \
+    {                                                                               \
+        const int cur = kt & 1;                                                     \
+        PP_READ_A(cur, 0) PP_READ_W(cur)                                            \
+        PP_END_READ(true, D0_, kt + 1, W0_)                                         \
+        PP_MUL(0)                                                                   \
+        PP_BAR()                                                                    \
+        PP_READ_A(cur, 1)                                                           \
+        PP_END_READ(false, D2_, kt + 2, W2_)                                        \
+        PP_MUL(1)                                                                   \
+        PP_BAR()                                                                    \
+    }
+#define PP_TILE_G1(FIRSTKT_, D1_, W1_, D3_, W3_)                                    \
+    {                                                                               \
+        const int cur = kt & 1;                                                     \
+        if (!(FIRSTKT_)) PP_MUL(1)                                                  \
+        PP_BAR()                                                                    \
+        PP_READ_A(cur, 0) PP_READ_W(cur)                                            \
+        PP_END_READ(true, D1_, kt + 2, W1_)                                         \
+        PP_MUL(0)                                                                   \
+        PP_BAR()                                                                    \
+        PP_READ_A(cur, 1)                                                           \
+        PP_END_READ(false, D3_, kt + 2, W3_)                                        \
+    }
+    if (g == 0) {
+        int kt = 0;
+        PP_TILE_G0(0, 0, 1, 6)                                   // the prologue's requests have all landed after slot 0
+        for (kt = 1; kt < nk - 2; ++kt) PP_TILE_G0(1, 8, 1, 8)
+        PP_TILE_G0(1, 8, 0, 2)                                   // kt = nk - 2: A-hi[64:128] of the last tile, nothing else
+        ++kt;
+        PP_TILE_G0(0, 0, 0, 0)                                   // kt = nk - 1
+    } else {
+        int kt = 0;
+        PP_TILE_G1(true, 1, 2, 1, 8)
+        for (kt = 1; kt < nk - 2; ++kt) PP_TILE_G1(false, 1, 8, 1, 8)
+        PP_TILE_G1(false, 0, 6, 0, 0)                            // kt = nk - 2
+        ++kt;
+        PP_TILE_G1(false, 0, 0, 0, 0)
+        PP_MUL(1)
+    }
+#undef PP_TILE_G0
+#undef PP_TILE_G1
+#undef PP_END_READ
+#undef PP_MUL
+#undef PP_READ_A
+#undef PP_READ_W
+#undef PP_BAR
+
+    if (dbg & 8) {   // no stores: keep the accumulators alive
+        float z = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z += acc[mi][ni][r];
+        if (z == 12345.678f) p.Y[0] = z;
+        return;
+    }
+    // epilogue straight from the C layout of the 32x32 MFMA (register r of block (mi, ni) = column lane & 31, row
+    // (r & 3) + 8 (r >> 2) + 4 (lane >> 5)): a store instruction writes two rows x 128 contiguous bytes (fp32).  Measured
+    // against two alternatives on the store-heavy shapes (c_attn / lm_head at 14 848 rows: 182 MB / 3 GB of fp32 output,
+    // `profiles/r05_gemm_big_*.log`): swapped MFMA operands (a lane = 4 consecutive columns, 16-byte stores of 32-byte row
+    // pieces) 142 / 3577 us, quad-transposed accumulators (16-byte stores, 8 rows x 128 B per instruction) 129 / 2377 us, this
+    // form 118 / 2232 us - the tile's 256 KiB leave through the HBM write path at ~3 TB/s whatever the instruction count
+    // (without the stores: 75 us), so the form with no extra VALU work in front of the first store wins.
+    const int ccol = lane & 31, crow4 = 4 * (lane >> 5);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = n0 + wq * 64 + ni * 32 + ccol;
+            const int colc = min(col, p.N - 1);
+            const int rbase = m0 + g * 128 + mi * 32 + crow4;
+            const float sh = esh[ni];
+            float rv[16], vv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            if (p.R) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+                    rv[r] = p.R[(size_t)row * p.ldy + colc];
+                }
+            }
+            if (p.G16) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+                    rv[r] = from16<F16>(p.G16[(size_t)row * p.ldy + colc]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vv[r] = (acc[mi][ni][r] + sh) * gelu_new_grad_fast(rv[r]);
+            } else {
+                if (p.Ypre16 && col < p.N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        if (rbase + dr < p.M)
+                            p.Ypre16[(size_t)rbase * p.ldy + col + (size_t)(dr * p.ldy)] = (u16)to16<F16>(acc[mi][ni][r] + sh + rv[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vv[r] = apply_act_fast(acc[mi][ni][r] + sh + rv[r], p.act);
+            }
+            if (col < p.N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (rbase + dr < p.M) {
+                        const size_t o = (size_t)rbase * p.ldy + col + (size_t)(dr * p.ldy);
+                        if (p.Y16) p.Y16[o] = (u16)to16<F16>(vv[r]);
+                        else if (p.N > 8192) __builtin_nontemporal_store(vv[r], &p.Y[o]);
+                        else p.Y[o] = vv[r];
+                    }
+                }
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, size_t n, int f16) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         dst[i] = (u16)to16_rt(src[i], f16);
@@ -681,19 +1029,35 @@ static int glds_attrs() {
     return glds_attr<BM, BN, 4>();
 }
 
+constexpr int PP_LDS = 2 * (256 + 256) * 128;   // two stages of the 256 x 256 ping-pong kernel
+
 int init_gemm_bf16_attrs() {
     static bool done = false;  // hipFuncSetAttribute is not capturable and not free: once per process
     if (done) return RGRG_OK;
     int rc;
     if ((rc = bf16_attr<128, 128, 512>()) || (rc = bf16_attr<64, 64, 256>())) return rc;
     if ((rc = glds_attrs<128, 128>()) || (rc = glds_attrs<64, 64>()) || (rc = glds_attrs<128, 64>()) || (rc = glds_attrs<64, 128>())) return rc;
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
+    RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
     done = true;
     return RGRG_OK;
 }
 
+// RGRG_GEMM_GM: row tiles per group of the tile order (GemmBf16Params::gm); unset = 8 when there are more than 16 row tiles,
+// -1 = column-major order always (the round-3/4 order; A/B runs of tools/gemm_bf16_bench.py)
+static int gemm_gm_override() {
+    static const int v = [] { const char* e = getenv("RGRG_GEMM_GM"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 template <int BM, int BN, int NST>
-static int launch_glds_cfg(const GemmBf16Params& p, hipStream_t st) {
+static int launch_glds_cfg(const GemmBf16Params& p0, hipStream_t st) {
+    GemmBf16Params p = p0;
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
+    if (p.gm == 0) {
+        const int o = gemm_gm_override();
+        p.gm = o < 0 ? 0 : o > 0 ? o : (mtiles > 16 ? 8 : 0);
+    }
 #define RGRG_G_LAUNCH(CONV_, F16_, LNF_) hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, NST, CONV_, F16_, LNF_>), dim3(mtiles * ntiles), dim3(256), NST * (BM + BN) * 128 + BM * 16, st, p, mtiles, ntiles)
     if (p.cCin) { if (p.f16) RGRG_G_LAUNCH(true, true, 0); else RGRG_G_LAUNCH(true, false, 0); }
     else if (p.Yb16) { if (p.f16) RGRG_G_LAUNCH(false, true, 1); else RGRG_G_LAUNCH(false, false, 1); }
@@ -710,7 +1074,31 @@ static int launch_glds_nst(const GemmBf16Params& p, int nst, hipStream_t st) {
     return launch_glds_cfg<BM, BN, 4>(p, st);
 }
 
-// tile = shape + 16 * stages; shape: 0 = heuristic, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128; stages: 0 (= 4), 2, 3, 4
+// 256 x 256 ping-pong kernel: plain GEMMs only (no LayerNorm fold, no convolution, no 16-bit residual), K tiles >= 4
+static bool pp_eligible(const GemmBf16Params& p) {
+    return !p.cCin && !p.Yb16 && !p.ln_colsum && !p.R16 && p.K >= 256 && p.K % 64 == 0;
+}
+static int launch_pp(const GemmBf16Params& p0, hipStream_t st) {
+    GemmBf16Params p = p0;
+    const int mtiles = (p.M + 255) / 256, ntiles = (p.N + 255) / 256;
+    if (p.gm == 0) {
+        const int o = gemm_gm_override();
+        p.gm = o < 0 ? 0 : o > 0 ? o : (mtiles > 8 ? 8 : 0);
+    }
+    { const char* e = getenv("RGRG_PP_DBG"); p.dbg = e ? atoi(e) : 0; }
+    if (p.f16) hipLaunchKernelGGL(gemm_bf16_pp_kernel<true>, dim3(mtiles * ntiles), dim3(512), PP_LDS, st, p, mtiles, ntiles);
+    else hipLaunchKernelGGL(gemm_bf16_pp_kernel<false>, dim3(mtiles * ntiles), dim3(512), PP_LDS, st, p, mtiles, ntiles);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+// RGRG_GEMM_PP=0: never pick the ping-pong kernel (A/B runs)
+static bool pp_enabled() {
+    static const bool v = [] { const char* e = getenv("RGRG_GEMM_PP"); return !e || atoi(e) != 0; }();
+    return v;
+}
+
+// tile = shape + 16 * stages; shape: 0 = heuristic, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 256x256 ping-pong;
+// stages: 0 (= 4), 2, 3, 4
 // (tools/gemm_bf16_bench.py measures them).  Heuristic from the COLD-weights table at M = 923
 // (profiles/r03_gemm_bf16_bench_v7_tiles_x_stages_cold.log: a decode step streams 0.7 GB of weights between two uses of a
 // matrix, so a GEMM never finds its W in a cache; a warm-cache bench flatters the short pipelines by 20-40 %).  What
@@ -722,10 +1110,22 @@ static int launch_glds_nst(const GemmBf16Params& p, int nst, hipStream_t st) {
 //   mlp_proj (N 1024, K 4096)       64 x 64,   4 stages (long K: depth pays)               20.7 us (2 stages: 47)
 static int launch_glds(const GemmBf16Params& p, int tile, hipStream_t st) {
     int shape = tile & 15, nst = tile >> 4;
+    if (shape == 5) {
+        if (!pp_eligible(p)) { set_error("bf16 GEMM: the 256 x 256 kernel does not take this variant"); return RGRG_EINVAL; }
+        return launch_pp(p, st);
+    }
+    if (shape == 0 && pp_enabled() && pp_eligible(p)) {
+        // at least ~3/4 of a round of one 256 x 256 workgroup per CU, and enough rows that the 128 x 128 kernel is the
+        // alternative (the M = 923 decode shapes keep their tuned tiles)
+        const long tiles_pp = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+        if (p.M >= 2048 && tiles_pp >= 192) return launch_pp(p, st);
+    }
     if (shape == 0) {
         const long tiles_big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
         if (p.N <= 64) { shape = 3; nst = 2; }            // a 64-channel conv: no point in a 128-wide column tile
-        else if (tiles_big >= 1024) { shape = 1; nst = 2; }
+        else if (tiles_big >= 512) { shape = 1; nst = 2; }   // >= one round of two workgroups per CU (round 5: was 1024 - the
+                                                              // M = 14 848 training GEMMs with N = 1024 ran on 64 x 64 tiles)
+        else if (p.K >= 8192 && tiles_big >= 192) { shape = 1; nst = 2; }   // fc6 at 8 images (6 650 x 1024 x 131 072): 2.1 ms, 64 x 64: 4.2
         else if (p.K > 1024) { shape = 2; nst = 4; }
         else if (tiles_big >= 256) { shape = 3; nst = 3; }
         else if (tiles_big >= 128) { shape = 2; nst = 3; }
@@ -750,7 +1150,11 @@ int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const 
     GemmBf16Params p{A, reinterpret_cast<const u16*>(A16), reinterpret_cast<const u16*>(Wb), shift, R, Y,
                      reinterpret_cast<u16*>(Y16), M, N, K, ldy, act};
     p.f16 = f16 ? 1 : 0;
-    if (ln) {   // LayerNorm folded around the GEMM (GemmBf16Params): LDS-DMA kernel only
+    if (ln && (ln->Ypre16 || ln->G16)) {   // training-pass epilogues (GemmBf16Params): LDS-DMA kernel, plain variant only
+        RGRG_CHECK_ARG(A16 && (size_t)128 * K * 2 < ((size_t)1 << 31) && !ln->Yb16 && !ln->ln_colsum);
+        RGRG_CHECK_ARG(!(ln->Ypre16 && ln->G16) && (!ln->G16 || (!R && act == RGRG_ACT_NONE)));
+        p.Ypre16 = reinterpret_cast<u16*>(ln->Ypre16); p.G16 = reinterpret_cast<const u16*>(ln->G16);
+    } else if (ln) {   // LayerNorm folded around the GEMM (GemmBf16Params): LDS-DMA kernel only
         RGRG_CHECK_ARG(A16 && (size_t)128 * K * 2 < ((size_t)1 << 31));
         RGRG_CHECK_ARG((ln->Yb16 != nullptr) != (ln->ln_colsum != nullptr));
         RGRG_CHECK_ARG(!ln->Yb16 || (Y && ln->stats_out && N == 1024));
@@ -821,6 +1225,21 @@ extern "C" int rgrg_debug_linear_bf16_tile(const uint16_t* A16, const uint16_t* 
     RGRG_CHECK_ARG((lda == 0 || lda >= K) && (ldw == 0 || ldw >= K));
     GemmBf16Params p{nullptr, A16, Wb, shift, R, Y, nullptr, M, N, K, ldy, act, lda, ldw};
     p.f16 = fp16 ? 1 : 0;
+    return launch_glds(p, tile, as_stream(stream));
+}
+
+// Test / measurement hook for the training-pass epilogues (GemmBf16Params::Ypre16 / G16) and the 16-bit output on a forced
+// tile (tile as in rgrg_debug_linear_bf16_tile; 5 = the 256 x 256 ping-pong kernel).
+extern "C" int rgrg_debug_linear_bf16_train(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
+                                            uint16_t* Y16, uint16_t* Ypre16, const uint16_t* G16, int M, int N, int K, int ldy,
+                                            int act, int tile, int fp16, void* stream) {
+    int rc = init_gemm_bf16_attrs();
+    if (rc) return rc;
+    RGRG_CHECK_ARG(A16 && Wb && ((Y != nullptr) != (Y16 != nullptr)) && M > 0 && N > 0 && K > 0 && K % 256 == 0 && ldy >= N);
+    RGRG_CHECK_ARG((size_t)128 * K * 2 < ((size_t)1 << 31) && !(Ypre16 && G16) && (!G16 || (!R && act == RGRG_ACT_NONE)));
+    GemmBf16Params p{nullptr, A16, Wb, shift, R, Y, Y16, M, N, K, ldy, act};
+    p.f16 = fp16 ? 1 : 0;
+    p.Ypre16 = Ypre16; p.G16 = G16;
     return launch_glds(p, tile, as_stream(stream));
 }
 

@@ -60,8 +60,10 @@ __global__ __launch_bounds__(256) void dropout_add_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, size_t n, const DropoutParams drop) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = dropout_mask(drop, i);
+// row_len > 0: the elements are rows of row_len whose index pitch is dropout_key_pitch(row_len) (attention-probability masks)
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, size_t n, const DropoutParams drop, int row_len) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = dropout_mask(drop, row_len > 0 ? (i / row_len) * dropout_key_pitch(row_len) + i % row_len : i);
 }
 
 // LayerNorm backward w.r.t. its input (weight / bias are frozen): one workgroup per row, D == 1024.
@@ -90,6 +92,143 @@ __global__ __launch_bounds__(256) void ln_backward_kernel(const float* __restric
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] += rstd * (t[e] - m1 - xh[e] * m2);
     reinterpret_cast<f32x4*>(out + (size_t)row * D)[tid] = o;
+}
+
+// ---------------------------------------------------------------- 16-bit activation flow of the training pass (round 5)
+// Under torch.autocast with more than 128 token rows every GEMM of the pass reads 16-bit A operands.  Rounds 1-4 kept all
+// activations fp32 and converted in front of every GEMM (272 conversion launches = 10 % of a configs[4] step); now every
+// producer writes the 16-bit copy its consumer GEMM reads, and the element-wise steps between two GEMMs are one kernel.
+__device__ __forceinline__ void store16x4(unsigned short* dst, const f32x4& v, int f16) {
+    const unsigned lo = to16_rt(v[0], f16) | (to16_rt(v[1], f16) << 16), hi = to16_rt(v[2], f16) | (to16_rt(v[3], f16) << 16);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+}
+
+// x = resid + dropout(y)  (resid_dropout / the embedding dropout when resid == nullptr; y may alias x), stored fp32 for the
+// backward pass, and xn16 = round16(LayerNorm(x) * g + b) for the GEMM behind the LayerNorm.  One wave per row of 1024,
+// reductions by DPP, two-pass variance like nn.LayerNorm (the arithmetic of ln_rows_kernel, decoder.hip).
+__global__ __launch_bounds__(256) void resid_dropout_ln16_kernel(const float* y, const float* __restrict__ resid, float* x,
+                                                                 const float* __restrict__ g, const float* __restrict__ b,
+                                                                 unsigned short* __restrict__ xn16, const DropoutParams drop, int f16,
+                                                                 int rows) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const size_t base = (size_t)row * 1024;
+    f32x4 v[4], rr[4], gg[4], bb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = reinterpret_cast<const f32x4*>(y + base)[j * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rr[j] = resid ? reinterpret_cast<const f32x4*>(resid + base)[j * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        gg[j] = reinterpret_cast<const f32x4*>(g)[j * 64 + lane];
+        bb[j] = reinterpret_cast<const f32x4*>(b)[j * 64 + lane];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float mk[4];
+        dropout_mask4(drop, (base >> 2) + j * 64 + lane, mk);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[j][e] = rr[j][e] + v[j][e] * mk[e];
+        reinterpret_cast<f32x4*>(x + base)[j * 64 + lane] = v[j];
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    }
+    const float mean = wave_sum_dpp(s) * (1.0f / 1024.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[j][e] -= mean; q += v[j][e] * v[j][e]; }
+    const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) * (1.0f / 1024.0f) + LN_EPS_T);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[j][e] * rstd * gg[j][e] + bb[j][e];
+        store16x4(xn16 + base + 4 * (j * 64 + lane), o, f16);
+    }
+}
+
+// LayerNorm backward w.r.t. its input (as ln_backward_kernel), one wave per row, plus the 16-bit copy the next dgrad GEMM
+// reads: out16 = round16(out * mask) - the dropout mask of the residual branch the gradient enters next (p = 0: plain copy).
+__global__ __launch_bounds__(256) void ln_backward16_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ g, float* out,
+                                                            unsigned short* __restrict__ out16, int accumulate,
+                                                            const DropoutParams drop, int f16, int rows) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const size_t base = (size_t)row * 1024;
+    f32x4 v[4], dd[4], gg[4], oo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = reinterpret_cast<const f32x4*>(x + base)[j * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dd[j] = reinterpret_cast<const f32x4*>(dy + base)[j * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gg[j] = reinterpret_cast<const f32x4*>(g)[j * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) oo[j] = accumulate ? reinterpret_cast<const f32x4*>(out + base)[j * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    const float mean = wave_sum_dpp(s) * (1.0f / 1024.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[j][e] -= mean; q += v[j][e] * v[j][e]; }
+    const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) * (1.0f / 1024.0f) + LN_EPS_T);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dd[j][e] *= gg[j][e];        // t
+            v[j][e] *= rstd;             // xhat
+            s1 += dd[j][e];
+            s2 += dd[j][e] * v[j][e];
+        }
+    const float m1 = wave_sum_dpp(s1) * (1.0f / 1024.0f), m2 = wave_sum_dpp(s2) * (1.0f / 1024.0f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 m;
+        float mk[4];
+        dropout_mask4(drop, (base >> 2) + j * 64 + lane, mk);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            oo[j][e] += rstd * (dd[j][e] - m1 - v[j][e] * m2);
+            m[e] = oo[j][e] * mk[e];
+        }
+        reinterpret_cast<f32x4*>(out + base)[j * 64 + lane] = oo[j];
+        if (out16) store16x4(out16 + base + 4 * (j * 64 + lane), m, f16);
+    }
+}
+
+// d logits as ce_backward_kernel, written as 16 bit to a separate [rows, ld] buffer (the A operand of the lm_head dgrad);
+// the K-padding columns [V, ld) of that buffer are zeroed once at allocation and never written.
+__global__ __launch_bounds__(256) void ce_backward16_kernel(const float* __restrict__ logits, size_t ld, int V, int row0,
+                                                            const long long* __restrict__ ids, const int* __restrict__ row_valid,
+                                                            const float* __restrict__ row_lse, const int* __restrict__ n_scored,
+                                                            float scale, const int* __restrict__ id_error,
+                                                            unsigned short* __restrict__ out16, int f16) {
+    const int r = row0 + blockIdx.x;
+    const float* x = logits + (size_t)blockIdx.x * ld;
+    unsigned short* o = out16 + (size_t)blockIdx.x * ld;
+    const int V4 = V & ~3;
+    if (!row_valid[r]) {
+        for (int i = threadIdx.x * 4; i < V4; i += 1024) *reinterpret_cast<uint2*>(o + i) = make_uint2(0u, 0u);
+        for (int i = V4 + threadIdx.x; i < V; i += 256) o[i] = 0;
+        return;
+    }
+    const float lse = row_lse[r], f = *id_error ? nanf("") : scale / (float)(*n_scored);
+    const int label = (int)ids[r + 1];
+    for (int i = threadIdx.x * 4; i < V4; i += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+        f32x4 gq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gq[e] = (expf(v[e] - lse) - (i + e == label ? 1.f : 0.f)) * f;
+        store16x4(o + i, gq, f16);
+    }
+    for (int i = V4 + threadIdx.x; i < V; i += 256) o[i] = (unsigned short)to16_rt((expf(x[i] - lse) - (i == label ? 1.f : 0.f)) * f, f16);
 }
 
 // d logits of CrossEntropyLoss(ignore_index=-100, mean) in place on a chunk of logits rows:
@@ -166,7 +305,8 @@ __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * 
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ ukv, int ld_ukv,
                                                           int kcol, const float* __restrict__ am, const float* __restrict__ d_att,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          float* __restrict__ d_qkv, int S, int H, int T, const DropoutParams drop) {
+                                                          float* __restrict__ d_qkv, int S, int H, int T, const DropoutParams drop,
+                                                          unsigned short* __restrict__ d_qkv16, int f16) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int QT = (T + 31) / 32;
     const int item = blockIdx.x * 4 + wave;
@@ -229,7 +369,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
                 const float addm = (c == 0 || !am) ? 0.f : (1.0f - am[(size_t)s * T + c - 1]) * -10000.0f;
                 const float pr = expf((allowed ? aS[r] / 8.0f : -1e4f) + addm - lse_q);
                 // attn_dropout: O = (P * mask) V  =>  dP = (dO . V) * mask ; delta = rowsum(dO . O) already includes it
-                const float mk = dropout_mask(drop, (((unsigned long long)s * H + hd) * T + iqc) * NK + c);
+                const float mk = dropout_mask(drop, (((unsigned long long)s * H + hd) * T + iqc) * dropout_key_pitch(NK) + c);
                 dsv = allowed ? pr * (aP[r] * mk - delta_q) / 8.0f : 0.f;
             }
             ds[r] = dsv;
@@ -241,11 +381,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
         }
     }
     if (iq < T) {
-        float* op = d_qkv + ((size_t)s * T + iq) * 3 * D + hd * 64;
+        const size_t off = ((size_t)s * T + iq) * 3 * D + hd * 64;
+        if (d_qkv16) {   // 16-bit training flow: the only reader is the c_attn dgrad GEMM (4 consecutive dims per store)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            op[mfma_row(r, half)] = o0[r];
-            op[32 + mfma_row(r, half)] = o1[r];
+            for (int q4 = 0; q4 < 4; ++q4) {
+                store16x4(d_qkv16 + off + 8 * q4 + 4 * half, f32x4{o0[4 * q4], o0[4 * q4 + 1], o0[4 * q4 + 2], o0[4 * q4 + 3]}, f16);
+                store16x4(d_qkv16 + off + 32 + 8 * q4 + 4 * half, f32x4{o1[4 * q4], o1[4 * q4 + 1], o1[4 * q4 + 2], o1[4 * q4 + 3]}, f16);
+            }
+        } else {
+            float* op = d_qkv + off;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                op[mfma_row(r, half)] = o0[r];
+                op[32 + mfma_row(r, half)] = o1[r];
+            }
         }
     }
 }
@@ -254,7 +403,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
                                                            int kcol, const float* __restrict__ am, const float* __restrict__ d_att,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            float* __restrict__ d_qkv, float* __restrict__ d_ukv, int S, int H, int T,
-                                                           const DropoutParams drop) {
+                                                           const DropoutParams drop, unsigned short* __restrict__ d_qkv16, int f16,
+                                                           float ukv_scale) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NK = T + 1, D = H * 64;
     const int KT = (NK + 31) / 32, QT = (T + 31) / 32;
@@ -307,7 +457,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
                 const float lse_i = lse[((size_t)s * T + i) * H + hd], delta_i = delta[((size_t)s * T + i) * H + hd];
                 const bool allowed = (c == 0) || (c - 1 <= i);
                 pr = expf((allowed ? aS[r] / 8.0f : -1e4f) + addm - lse_i);
-                const float mk = dropout_mask(drop, (((unsigned long long)s * H + hd) * T + i) * NK + c);
+                const float mk = dropout_mask(drop, (((unsigned long long)s * H + hd) * T + i) * dropout_key_pitch(NK) + c);
                 dsv = allowed ? pr * (aP[r] * mk - delta_i) / 8.0f : 0.f;
                 pr *= mk;  // dV^T = dO^T (P * mask)
             }
@@ -327,22 +477,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
         }
     }
     if (cvalid) {
-        float* kdst;
-        float* vdst;
-        if (c == 0) {
-            kdst = d_ukv + (size_t)s * ld_ukv + kcol + hd * 64;
-            vdst = kdst + D;
-        } else {
-            kdst = d_qkv + ((size_t)s * T + c - 1) * 3 * D + D + hd * 64;
-            vdst = kdst + D;
-        }
+        if (c != 0 && d_qkv16) {   // 16-bit training flow (see attn_bwd_dq_kernel)
+            unsigned short* kd = d_qkv16 + ((size_t)s * T + c - 1) * 3 * D + D + hd * 64;
+            unsigned short* vd = kd + D;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int dim = mfma_row(r, half);
-            kdst[dim] = dk0[r];
-            kdst[32 + dim] = dk1[r];
-            vdst[dim] = dv0[r];
-            vdst[32 + dim] = dv1[r];
+            for (int q4 = 0; q4 < 4; ++q4) {
+                store16x4(kd + 8 * q4 + 4 * half, f32x4{dk0[4 * q4], dk0[4 * q4 + 1], dk0[4 * q4 + 2], dk0[4 * q4 + 3]}, f16);
+                store16x4(kd + 32 + 8 * q4 + 4 * half, f32x4{dk1[4 * q4], dk1[4 * q4 + 1], dk1[4 * q4 + 2], dk1[4 * q4 + 3]}, f16);
+                store16x4(vd + 8 * q4 + 4 * half, f32x4{dv0[4 * q4], dv0[4 * q4 + 1], dv0[4 * q4 + 2], dv0[4 * q4 + 3]}, f16);
+                store16x4(vd + 32 + 8 * q4 + 4 * half, f32x4{dv1[4 * q4], dv1[4 * q4 + 1], dv1[4 * q4 + 2], dv1[4 * q4 + 3]}, f16);
+            }
+        } else {
+            float* kdst;
+            float* vdst;
+            float sc = 1.0f;
+            if (c == 0) {
+                kdst = d_ukv + (size_t)s * ld_ukv + kcol + hd * 64;
+                vdst = kdst + D;
+                sc = ukv_scale;   // undoes the internal loss scale of the fp16 flow (1 otherwise: exact)
+            } else {
+                kdst = d_qkv + ((size_t)s * T + c - 1) * 3 * D + D + hd * 64;
+                vdst = kdst + D;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dim = mfma_row(r, half);
+                kdst[dim] = dk0[r] * sc;
+                kdst[32 + dim] = dk1[r] * sc;
+                vdst[dim] = dv0[r] * sc;
+                vdst[32 + dim] = dv1[r] * sc;
+            }
         }
     }
 }
@@ -427,6 +591,28 @@ int launch_ce_backward(float* logits, size_t ld, int V, int row0, int rows, cons
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
+int launch_resid_dropout_ln16(const float* y, const float* resid, float* x, const float* g, const float* b, unsigned short* xn16,
+                              DropoutParams drop, int f16, int rows, int D, hipStream_t st) {
+    RGRG_CHECK_ARG(D == 1024 && rows > 0 && y && x && xn16);
+    hipLaunchKernelGGL(resid_dropout_ln16_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, y, resid, x, g, b, xn16, drop, f16, rows);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+int launch_ln_backward16(const float* dy, const float* x, const float* g, float* out, unsigned short* out16, int rows, int D,
+                         int accumulate, DropoutParams drop, int f16, hipStream_t st) {
+    RGRG_CHECK_ARG(D == 1024 && rows > 0);
+    hipLaunchKernelGGL(ln_backward16_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, dy, x, g, out, out16, accumulate, drop, f16, rows);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+int launch_ce_backward16(const float* logits, size_t ld, int V, int row0, int rows, const long long* ids, const int* row_valid,
+                         const float* row_lse, const int* n_scored, float scale, const int* id_error, unsigned short* out16, int f16,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(ce_backward16_kernel, dim3(rows), dim3(256), 0, st, logits, ld, V, row0, ids, row_valid, row_lse, n_scored, scale,
+                       id_error, out16, f16);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
 int launch_transpose_pad(const float* src, float* dst, int R, int Cc, int Rp, hipStream_t st) {
     RGRG_CHECK_ARG(R > 0 && Cc > 0 && Rp >= R);
     hipLaunchKernelGGL(transpose_pad_kernel, dim3((Cc + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, src, dst, R, Cc, Rp);
@@ -440,17 +626,17 @@ int launch_colsum(const float* src, float* out, int R, int Cc, hipStream_t st) {
 }
 int launch_attn_backward(const float* qkv, const float* ukv, int ld_ukv, int kcol, const float* am, const float* d_att,
                          const float* att, const float* lse, float* delta, float* d_qkv, float* d_ukv, int S, int H, int T,
-                         DropoutParams drop, hipStream_t st) {
+                         DropoutParams drop, hipStream_t st, unsigned short* d_qkv16, int f16, float ukv_scale) {
     RGRG_CHECK_ARG(T >= 1 && att && lse && delta);
     const int NK = T + 1, D = H * 64, M = S * T;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(M), dim3(256), 0, st, d_att, att, delta, D, H);
     RGRG_LAUNCH_CHECK();
     const int qitems = S * H * ((T + 31) / 32), kitems = S * H * ((NK + 31) / 32);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((qitems + 3) / 4), dim3(256), 0, st, qkv, ukv, ld_ukv, kcol, am, d_att, lse, delta,
-                       d_qkv, S, H, T, drop);
+                       d_qkv, S, H, T, drop, d_qkv16, f16);
     RGRG_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((kitems + 3) / 4), dim3(256), 0, st, qkv, ukv, ld_ukv, kcol, am, d_att, lse, delta,
-                       d_qkv, d_ukv, S, H, T, drop);
+                       d_qkv, d_ukv, S, H, T, drop, d_qkv16, f16, ukv_scale);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
@@ -484,10 +670,10 @@ extern "C" int rgrg_bce_with_logits_masked_backward_f32(const float* logits, con
     return RGRG_OK;
 }
 
-extern "C" int rgrg_dropout_mask_f32(uint64_t seed, uint32_t stream_id, float p, int64_t n, float* out, void* stream) {
-    RGRG_CHECK_ARG(out && n > 0 && p >= 0.f && p < 1.f);
+extern "C" int rgrg_dropout_mask_f32(uint64_t seed, uint32_t stream_id, float p, int64_t n, int row_len, float* out, void* stream) {
+    RGRG_CHECK_ARG(out && n > 0 && p >= 0.f && p < 1.f && row_len >= 0);
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks_for((size_t)n)), dim3(256), 0, as_stream(stream), out, (size_t)n,
-                       DropoutParams{seed, stream_id, p});
+                       DropoutParams{seed, stream_id, p}, row_len);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }

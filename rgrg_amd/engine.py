@@ -816,8 +816,9 @@ class HipEngine:
         """The training pass's dropout mask of one site (0 or 1/(1-p)); sites: 0 embedding, 1 attention probabilities
         [S,16,T,T+1], 2 attn c_proj output, 3 mlp c_proj output ([S*T,1024])."""
         out = torch.empty(shape, dtype=torch.float32, device=self.device)
-        _hip.check(self.lib.rgrg_dropout_mask_f32(int(seed) & (2 ** 64 - 1), layer * 4 + site, float(p), out.numel(), _hip.ptr(out),
-                                                  self._s()), "rgrg_dropout_mask_f32")
+        row_len = int(shape[-1]) if site == 1 else 0   # attention masks: the key pitch of the index is a multiple of 4
+        _hip.check(self.lib.rgrg_dropout_mask_f32(int(seed) & (2 ** 64 - 1), layer * 4 + site, float(p), out.numel(), row_len,
+                                                  _hip.ptr(out), self._s()), "rgrg_dropout_mask_f32")
         return out
 
     def sync_trainable(self, state_dict: Dict[str, Tensor]) -> None:

@@ -1,0 +1,212 @@
+"""Round 5: the 16-bit activation flow of the training pass (BASELINE configs[4]; the reference wraps its training step in
+torch.autocast, src/full_model/train_full_model.py:172-237) and the kernels under it - the 256 x 256 ping-pong GEMM with the
+training epilogues, the fused residual / dropout / LayerNorm and LayerNorm-backward kernels, the 16-bit cross-entropy
+gradient.  The fp32 pass (pinned against the real reference's autograd by tests/golden/lm_grads*.pt) is the yardstick of the
+16-bit passes; tolerances are the 16-bit noise levels written next to each check."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import gpu_model, synth_sd
+from oracle import language_model as o_lm
+from rgrg_amd import _hip
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T16 = {0: torch.bfloat16, 1: torch.float16}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _gelu_new_grad(x):
+    k = math.sqrt(2.0 / math.pi)
+    u = k * (x + 0.044715 * x ** 3)
+    th = torch.tanh(u)
+    return 0.5 * (1 + th) + 0.5 * x * (1 - th * th) * k * (1 + 3 * 0.044715 * x * x)
+
+
+@pytest.mark.parametrize("fp16", [0, 1])
+@pytest.mark.parametrize("tile", [5, 1 + 16 * 2])
+@pytest.mark.parametrize("M,N,K,mode", [(2085, 1024, 1024, "res"), (4100, 768, 256, "plain"), (300, 700, 512, "gelu16"),
+                                        (2300, 1280, 1024, "pre16"), (2300, 1024, 768, "gbwd"), (513, 257, 2048, "out16")])
+def test_pingpong_gemm_and_training_epilogues(M, N, K, mode, tile, fp16):
+    """gemm_bf16_pp_kernel (tile 5: 8 waves, 256 x 256, two wave groups alternating between the matrix core and the LDS side)
+    and the 128 x 128 LDS-DMA kernel (grouped tile order: 18+ row tiles) against a float64 product of the same 16-bit
+    operands: ragged row / column tiles, the shortest K (4 tiles), K = 2048; residual, fused gelu with 16-bit output, the
+    pre-activation copy (Ypre16) next to the activated output, the gelu' multiplier (G16)."""
+    if K % 256:
+        pytest.skip("K must be a multiple of 256")
+    lib = _hip.load()
+    t16 = T16[fp16]
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    A = torch.randn((M, K), generator=g).to(t16)
+    W = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(t16)
+    b = torch.randn((N,), generator=g)
+    R = torch.randn((M, N), generator=g) if mode == "res" else None
+    G = torch.randn((M, N), generator=g).to(t16) if mode == "gbwd" else None
+    pre = A.double() @ W.double().t() + b.double()
+    if R is not None:
+        pre = pre + R.double()
+    act = 2 if mode in ("gelu16", "pre16") else 0
+    ref = F.gelu(pre, approximate="tanh") if act == 2 else pre
+    if G is not None:
+        ref = pre * _gelu_new_grad(G.double())
+    A16, Wb = A.view(torch.int16).to(DEV), W.view(torch.int16).to(DEV)
+    out16 = mode in ("gelu16", "pre16", "gbwd", "out16")
+    y = torch.full((M, N), float("nan"), device=DEV)
+    y16 = torch.zeros((M, N), dtype=torch.int16, device=DEV)
+    p16 = torch.zeros((M, N), dtype=torch.int16, device=DEV)
+    Gd = G.view(torch.int16).to(DEV) if G is not None else None
+    Rd = R.to(DEV) if R is not None else None
+    _hip.check(lib.rgrg_debug_linear_bf16_train(A16.data_ptr(), Wb.data_ptr(), b.to(DEV).data_ptr(), Rd.data_ptr() if R is not None else None,
+                                                None if out16 else y.data_ptr(), y16.data_ptr() if out16 else None,
+                                                p16.data_ptr() if mode == "pre16" else None, Gd.data_ptr() if G is not None else None,
+                                                M, N, K, N, act, tile, fp16, _stream()))
+    scale = ref.abs().max().item()
+    if out16:
+        got = y16.cpu().view(t16).double()
+        assert (got - ref).abs().max().item() <= 2 ** -7 * scale          # one 16-bit rounding of an fp32-accurate value
+    else:
+        err = (y.cpu().double() - ref).abs()
+        assert bool((err <= 2e-6 * scale + 2e-5 * ref.abs()).all()), err.max().item()   # fp32 accumulation of exact 16-bit products
+    if mode == "pre16":
+        gotp = p16.cpu().view(t16).double()
+        assert (gotp - pre).abs().max().item() <= 2 ** -7 * pre.abs().max().item()
+
+
+def _lm_train_model():
+    import rgrg_amd
+    m = rgrg_amd.ReportGenerationModel(pretrain_without_lm_model=False)
+    m.load_state_dict(synth_sd("ragged"))
+    m.to(torch.device("cuda", 0))
+    m.language_model.dropout_p = 0.0
+    return m
+
+
+def _batch(S, T, seed, min_len=2):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(0, 50257, (S, T), generator=g)
+    lens = torch.randint(min_len, T + 1, (S,), generator=g)
+    lens[0] = T
+    am = (torch.arange(T)[None, :] < lens[:, None]).to(torch.int64)
+    feats = torch.randn((S, 1024), generator=g)
+    return ids, am, feats
+
+
+def _grads(m, ids, am, feats, autocast=None, seed=None):
+    lm = m.language_model
+    for p in m.parameters():
+        p.grad = None
+    if seed is not None:
+        lm.dropout_seed = seed
+    if autocast is None:
+        loss = lm(ids.clone().to(DEV), am.to(DEV), feats.to(DEV), return_loss=True)
+    else:
+        with torch.autocast("cuda", dtype=autocast):
+            loss = lm(ids.clone().to(DEV), am.to(DEV), feats.to(DEV), return_loss=True)
+    loss.backward()
+    return loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+
+def _compare(got, ref, cos_min, norm_tol, big_only=True):
+    worst = (1.0, 0.0, "")
+    for k, r in ref.items():
+        if big_only and r.numel() < 1024 * 1024:
+            continue
+        a, b = got[k].reshape(-1).double(), r.reshape(-1).double()
+        cos = (torch.dot(a, b) / (a.norm() * b.norm())).item()
+        nr = abs(a.norm().item() / b.norm().item() - 1)
+        assert cos >= cos_min and nr <= norm_tol, (k, cos, nr)
+        if cos < worst[0]:
+            worst = (cos, nr, k)
+    return worst
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_train16_with_dropout_follows_the_fp32_pass_with_the_same_masks(dtype):
+    """240 token rows (> 128: the 16-bit flow) with dropout 0.25 at all four sites and the SAME seed as an fp32 pass: the
+    masks are pure functions of (seed, site, element), recomputed by the fused residual / dropout / LayerNorm kernel, by the
+    LayerNorm-backward kernel (the mask of the branch the gradient enters next) and by both attention-backward kernels.  A
+    wrong mask anywhere decorrelates the gradients (cosine ~0.75 at p = 0.25); 16-bit noise alone keeps cosine >= 0.99."""
+    m = _lm_train_model()
+    lm = m.language_model
+    lm.train()
+    lm.dropout_p = 0.25
+    ids, am, feats = _batch(10, 24, 5)
+    l32, g32 = _grads(m, ids, am, feats, None, seed=1000)
+    l16, g16 = _grads(m, ids, am, feats, dtype, seed=1000)
+    lother, gother = _grads(m, ids, am, feats, None, seed=2000)
+    assert abs(l16 - l32) <= 3e-2 and l16 != l32
+    cos, nr, k = _compare(g16, g32, 0.99, 0.03)
+    # the same comparison against OTHER masks fails clearly: the test can see a wrong mask
+    a, b = gother[k].reshape(-1).double(), g32[k].reshape(-1).double()
+    assert (torch.dot(a, b) / (a.norm() * b.norm())).item() < 0.97
+    m.invalidate_engine()
+
+
+@pytest.mark.parametrize("S,T", [(2, 150), (3, 127), (5, 33), (4, 96)])
+def test_train16_attention_paths(S, T):
+    """T + 1 <= 128 keys: the 16-bit attention kernels (attn_train16.hip) - 127 tokens = the full 4 key tiles, 33 tokens = 34 keys
+    (two keys in the second tile), 96 tokens = a key tile holding only the last key; 150 tokens: the fp32 attention kernels
+    with 16-bit outputs.  Dropout 0.2 with the seed of an fp32 pass: the attention-probability masks are recomputed in the
+    forward kernel and in both halves of the fused backward kernel.  16-bit noise: cosine >= 0.99, norms within 3 %."""
+    m = _lm_train_model()
+    lm = m.language_model
+    lm.train()
+    lm.dropout_p = 0.2
+    ids, am, feats = _batch(S, T, 100 + T)
+    l32, g32 = _grads(m, ids, am, feats, None, seed=77)
+    l16, g16 = _grads(m, ids, am, feats, torch.bfloat16, seed=77)
+    assert abs(l16 - l32) <= 3e-2
+    _compare(g16, g32, 0.99, 0.03)
+    m.invalidate_engine()
+
+
+def test_fp16_training_gradients_keep_their_small_values():
+    """under torch.autocast(float16) d(logits) = (softmax - onehot) / n_scored is 1e-4 .. 1e-9 - fp16's
+    subnormal / flush-to-zero range - and GradScaler's scale only arrives after the pass.  The 16-bit flow therefore carries
+    an internal power-of-two scale (2^15) from d(logits) to d(uk / uv), removed exactly where the gradients leave 16-bit
+    storage.  2320 token rows (n_scored ~ 1700): every large gradient tensor within 3 % in norm and cosine >= 0.99 of the fp32
+    pass, bias gradients (sums over few elements: the first to lose small addends) within 5 %."""
+    m = _lm_train_model()
+    m.language_model.train()
+    ids, am, feats = _batch(58, 40, 11, min_len=20)
+    l32, g32 = _grads(m, ids, am, feats, None)
+    l16, g16 = _grads(m, ids, am, feats, torch.float16)
+    assert abs(l16 - l32) <= 3e-2
+    _compare(g16, g32, 0.99, 0.03)
+    for k, r in g32.items():
+        if r.dim() == 1 and r.numel() >= 1024:
+            assert abs(g16[k].norm().item() / r.norm().item() - 1) <= 0.05, k
+    m.invalidate_engine()
+
+
+def test_configs4_shape_partition_property_and_oracle_subset():
+    """BASELINE configs[4] at its real per-GPU shape: 8 images = 232 sentences x 64 tokens = 14 848 token rows in ONE lm_head /
+    cross-entropy chunk, bf16 autocast, dropout off.  The loss is a mean over the scored tokens, so for a partition of the
+    sentences into A (4 sentences) and B (228)   n G(full) = n_A G(A) + n_B G(B)   and the same for the loss - three passes of
+    the 16-bit flow at 256 / 14 592 / 14 848 rows must agree (cosine >= 0.995, norms within 2 %: each pass has its own 16-bit
+    noise), and pass A (256 rows) is checked against torch autograd through the CPU oracle (cosine >= 0.99, norms 3 %)."""
+    m = _lm_train_model()
+    m.language_model.train()
+    S, T, NA = 232, 64, 4
+    ids, am, feats = _batch(S, T, 64, min_len=T // 2)
+
+    def scored(a):
+        return int(a[:, 1:].sum().item())
+    n, nA, nB = scored(am), scored(am[:NA]), scored(am[NA:])
+    assert n == nA + nB
+    lF, gF = _grads(m, ids, am, feats, torch.bfloat16)
+    lA, gA = _grads(m, ids[:NA], am[:NA], feats[:NA], torch.bfloat16)
+    lB, gB = _grads(m, ids[NA:], am[NA:], feats[NA:], torch.bfloat16)
+    assert abs(lF * n - (lA * nA + lB * nB)) <= 2e-3 * lF * n
+    combo = {k: (gA[k] * nA + gB[k] * nB) / n for k in gF}
+    _compare(gF, combo, 0.995, 0.02)
+    o_loss, o_grads = o_lm.lm_loss_and_grads(synth_sd("ragged"), ids[:NA], am[:NA], feats[:NA])
+    assert abs(lA - o_loss.item()) <= 3e-2
+    _compare({k: v.cpu() for k, v in gA.items()}, o_grads, 0.99, 0.03)
+    m.invalidate_engine()

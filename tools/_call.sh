@@ -1,10 +1,13 @@
 #!/bin/bash
-# Scratch script for `gpurun -- 'bash tools/_call.sh'` calls: edit per call.  This version is the round-end check -
-# smoke, the full GPU suite, the default bench line.
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_test_suite.log 2>&1
-echo "tests rc=$?"; tail -2 gpurun_out/gpu_test_suite.log
-timeout 900 python bench.py > gpurun_out/bench_b1.json 2> gpurun_out/bench_b1.err
-echo "bench rc=$?"; cut -c1-200 gpurun_out/bench_b1.json
+ROOT=$GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout 300 python -c "import __graft_entry__ as g; g.build(); print('build ok')" 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_gpu_train16.py -x -q 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_gpu_generate.py -x -q -k "dropout or bf16_autocast_close or gradscaler or training_pass_gradients" 2>&1 | tail -5
+timeout 300 python tools/train_bench.py 8 64 3 bf16 2>&1 | tail -1
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_train -- python $ROOT/tools/train_bench.py 8 64 3 bf16 > $ROOT/gpurun_out/r05_train_b8_v3.log 2>&1
+python $ROOT/tools/prof_summary.py /tmp/kt_train $ROOT/gpurun_out/r05_kernel_trace_summary_train_b8_v3.md > /dev/null
+head -20 $ROOT/gpurun_out/r05_kernel_trace_summary_train_b8_v3.md

@@ -1,6 +1,6 @@
 """One training step at the shape of BASELINE configs[4] (8 images per GPU, object detector frozen): forward() in
 train mode (detector inference + both classifier losses + teacher-forced LM loss), backward on the HIP kernels, HIP AdamW
-over the 53.66 M trainable values.  Usage: python tools/train_bench.py [B] [T] [steps]"""
+over the 53.66 M trainable values.  Usage: python tools/train_bench.py [B] [T] [steps] [fp32|bf16|both]"""
 import os
 import sys
 import time
@@ -14,6 +14,7 @@ from rgrg_amd import optim, synth  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+MODES = sys.argv[4] if len(sys.argv) > 4 else "both"
 dev = torch.device("cuda", 0)
 m = rgrg_amd.ReportGenerationModel(pretrain_without_lm_model=False)
 m.load_state_dict(synth.make_state_dict(0, "bench"))
@@ -44,6 +45,8 @@ def step(low):
 
 
 for name, low in (("fp32", False), ("bf16 autocast", True)):
+    if MODES != "both" and MODES != name.split()[0]:
+        continue
     losses = step(low)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
