@@ -361,13 +361,33 @@ def config4_line(model, synth, world=1, use_dist=False, dev=None, steps=3, T=64)
         step()
         dt, out = _bracketed(step, steps, use_dist, dev)
         n_values = sum(p.numel() for p in params)
+        # roofline of the step's dominant kernel family (the frozen-weight GEMMs of forward + activation gradients: 46 % of
+        # the GPU time of a step): timed live with HIP events on the decoder's stream, launched back to back with the step's
+        # own operands and epilogues; `step_frac` = the same flops over the WHOLE step (attention, row kernels, detector,
+        # optimizer included)
+        roof = None
+        try:
+            eng = model.engine()
+            S_run, T_run = eng.last_train_shape   # the sentences the step really fed (a region that is not detected is dropped)
+            t = eng.time_train_gemms(S_run, T_run, 3)
+            tf = t["gemm_flops"] / (t["ms_gemm"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel (256 x 256 ping-pong, all GEMMs of the step at 14 848 rows)",
+                    "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None,
+                    "launches_per_step": t["gemm_launches"], "avg_launch_us": 1e3 * t["ms_gemm"] / t["gemm_launches"],
+                    "algorithmic_flops_per_launch": t["gemm_flops"] / t["gemm_launches"], "ms_gemm_per_step": t["ms_gemm"],
+                    "step_frac": t["gemm_flops"] / (dt / steps) / 1e12 / 2500.0,
+                    "token_rows": S_run * T_run,
+                    "note": "achieved = 2 M N K of the frozen-weight GEMMs of one step (forward + activation gradients of 24 blocks, lm_head "
+                            "forward + dgrad; M = token_rows) / their duration between two HIP events on the decoder stream"}
+        except Exception as e:  # noqa: BLE001
+            roof = {"error": str(e)}
         return {"workload": f"end-to-end training step, detector frozen, LM + binary-classifier heads, per-GPU batch=8 (232 sentences x {T} tokens), "
                             f"bf16 autocast, gradient all-reduce over {world} rank(s) on {n_buckets} flat buckets, HIP AdamW (BASELINE configs[4]"
                             + ("" if world == 8 else ": the 8-GPU shape at this N") + ")",
                 "metric": "images/sec end-to-end training step", "value": B * world * steps / dt, "unit": "images/sec", "n_gpus": world,
                 "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": 1, "dtype": "bf16", "scaling": "weak", "global_batch": B * world,
                 "trainable_values": n_values, "allreduce_bytes_per_step": 4 * n_values if world > 1 else 0,
-                "losses_last_step": [float(o.detach()) for o in out[1:4]]}
+                "losses_last_step": [float(o.detach()) for o in out[1:4]], "roofline": roof}
     finally:
         for p in model.trainable_parameters():
             p.grad = None
@@ -457,7 +477,7 @@ def main():
                    "data": "synthetic", "config": {"workload": res4["workload"], "global_batch": res4["global_batch"],
                                                    "parallelism": f"dp{world} (replicas, bucketed gradient all-reduce)" if use_dist else "single GPU",
                                                    "weights": "seeded random init (rgrg_amd.synth, profile bench)"},
-                   "training": res4}
+                   "roofline": res4.get("roofline"), "training": res4}
             print(json.dumps(res), flush=True)
         if use_dist:
             torch.distributed.destroy_process_group()

@@ -235,6 +235,12 @@ int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, const int64_t
                               int S, int T, float loss_scale, float dropout_p, uint64_t dropout_seed, float* loss_out,
                               float* grad_ukv_w, float* grad_ukv_b, float* grad_fst0_w, float* grad_fst0_b, float* grad_fst2_w,
                               float* grad_fst2_b, void* stream);
+/* Measurement hook of bench.py's BASELINE configs[4] leg: the frozen-weight GEMMs of ONE training step of the 16-bit
+ * (torch.autocast) flow - forward and activation-gradient GEMMs of the 24 blocks, lm_head forward / dgrad - launched back to
+ * back on the decoder's stream between two HIP events, on the work space of the last rgrg_decoder_lm_loss_grad call of this
+ * shape (overwritten: timing only).  flops_per_step = 2 M N K of those launches. */
+int rgrg_decoder_time_train_gemms(rgrg_decoder* d, int S, int T, int iters, float* ms_per_step, double* flops_per_step,
+                                  int* launches_per_step);
 /* The dropout mask of one site as the training pass computes it: out[i] = 0 (dropped, probability p) or 1/(1-p), for the
  * flat element index i of the site's tensor ([S*T,1024] for sites 0/2/3, [S,16,T,T+1] for the attention probabilities);
  * stream_id = layer*4 + site; row_len = T + 1 for the attention probabilities (their generator index pads a row of keys to
@@ -282,6 +288,11 @@ int rgrg_bce_with_logits_masked_backward_f32(const float* logits, const uint8_t*
  * with g = grad * grad_scale (1/AMP-scale, 1/accumulation steps).  All arrays f32 [n]; step t >= 1. */
 int rgrg_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                         float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* The same update for n_items tensors in ceil(n_items / 64) launches (hyper-parameters and step shared): `items` = a HOST array
+ * of records of five 64-bit words {param, grad, exp_avg, exp_avg_sq (device pointers to f32), element count}; the records
+ * travel in the kernel arguments. */
+int rgrg_adamw_multi_step_f32(const void* items, int n_items, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int step, float grad_scale, void* stream);
 /* The 16-bit entry points below (names say bf16 for history) take `fp16`: 0 = bfloat16, 1 = IEEE float16 - the dtype of the
  * caller's torch.autocast (the reference's scripts use float16: generate_reports_for_images.py:108, train_full_model.py:172).
  * Storage is uint16_t bits either way; the matrix core runs v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x16_f16 (same rate),

@@ -70,6 +70,7 @@ SIGNATURES = {
     "rgrg_relu_backward_f32": (_i, [_p, _p, C.c_int64, _p]),
     "rgrg_bce_with_logits_masked_backward_f32": (_i, [_p, _p, _p, C.c_float, _i, C.c_float, _p, _i, _p]),
     "rgrg_adamw_step_f32": (_i, [_p, _p, _p, _p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _p]),
+    "rgrg_adamw_multi_step_f32": (_i, [_p, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _p]),
     "rgrg_f32_to_bf16": (_i, [_p, _p, C.c_int64, _i, _p]),
     "rgrg_bf16_to_f32": (_i, [_p, _p, C.c_int64, _i, _p]),
     "rgrg_conv2d_nhwc_bf16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -88,6 +89,7 @@ SIGNATURES = {
     "rgrg_fastrcnn_loss_f32": (_i, [_p, _i, _i, _p, _p, _i, _p, _p]),
     "rgrg_decoder_time_step_parts": (_i, [_p, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
+    "rgrg_decoder_time_train_gemms": (_i, [_p, _i, _i, _i, C.POINTER(_f), C.POINTER(C.c_double), C.POINTER(_i)]),
     "rgrg_debug_chain": (_i, [_i, _i, _i, C.POINTER(_f)]),
     "rgrg_debug_grid_barrier": (_i, [_i, _i, _i, C.POINTER(_f), C.POINTER(C.c_uint)]),
     "rgrg_debug_xcc_map": (_i, [_i, _i, C.POINTER(_i)]),

@@ -76,10 +76,13 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const u16* __restrict__
                                                          const float* __restrict__ am, u16* __restrict__ out16, float* __restrict__ lse,
                                                          int S, int H, int T, const DropoutParams drop) {
     __shared__ __attribute__((aligned(16))) u16 VT[64 * A16_TP];
+    __shared__ float addm_s[A16_MAXK];   // additive padding mask of every key (0 for the image key)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hd = blockIdx.x % H, s = blockIdx.x / H;
     const int NK = T + 1, D = H * 64, NKP = (NK + 31) & ~31, QT = (T + 31) / 32;
     stage_transposed(VT, NKP, NK, [&](int c) { return kv_row(qkv16, ukv16, ld_ukv, kcol, s, T, D, hd, c, 2); });
+    for (int c = threadIdx.x; c < A16_MAXK; c += blockDim.x)
+        addm_s[c] = (c == 0 || c >= NK || !am) ? 0.f : (1.0f - am[(size_t)s * T + c - 1]) * -10000.0f;
     __syncthreads();
     if (wave >= QT) return;
     const int qt = wave, col = lane & 31, half = lane >> 5;
@@ -116,8 +119,7 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const u16* __restrict__
             float w = -INFINITY;                                                                                          \
             if (c < NK) {                                                                                                 \
                 const bool allowed = (c == 0) || (c - 1 <= iq);                                                           \
-                const float addm = (c == 0 || !am) ? 0.f : (1.0f - am[(size_t)s * T + c - 1]) * -10000.0f;                \
-                w = (allowed ? SC_[r] * 0.125f : -1e4f) + addm;                                                             \
+                w = (allowed ? SC_[r] * 0.125f : -1e4f) + addm_s[c];                                                      \
             }                                                                                                             \
             SC_[r] = w;                                                                                                   \
             m = fmaxf(m, w);                                                                                              \
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const u16* __restrict__
 #define A16_EXP(KT_, SC_)                                                                                                 \
     if ((KT_) < need) {                                                                                                   \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                  \
-            const float pe = expf(SC_[r] - m);                                                                            \
+            const float pe = __expf(SC_[r] - m);                                                                          \
             SC_[r] = pe;                                                                                                  \
             sum += pe;                                                                                                    \
         }                                                                                                                 \
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const u16* __restrict__
 // 16 bit receives dq | dk | dv of the token rows, d_ukv (fp32 [S, ld_ukv], columns kcol .. kcol + 2D of this layer) the
 // gradient of the image key / value times ukv_scale (the inverse of the fp16 flow's internal loss scale).
 template <bool F16>
-__global__ __launch_bounds__(256) void attn16_bwd_kernel(const u16* __restrict__ qkv16, const u16* __restrict__ ukv16, int ld_ukv, int kcol,
+__global__ __launch_bounds__(256, 3) void attn16_bwd_kernel(const u16* __restrict__ qkv16, const u16* __restrict__ ukv16, int ld_ukv, int kcol,
                                                          const float* __restrict__ am, const u16* __restrict__ d_att16,
                                                          const u16* __restrict__ att16, const float* __restrict__ lse,
                                                          u16* __restrict__ d_qkv16, float* __restrict__ d_ukv, int S, int H, int T,
@@ -192,6 +194,8 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const u16* __restrict__
     __shared__ __attribute__((aligned(16))) u16 GT_[64 * A16_TP];    // dO^T  [dim][permuted query]
     __shared__ __attribute__((aligned(16))) u16 KT_[64 * A16_TP];    // K^T   [dim][permuted key]
     __shared__ float delta_s[A16_MAXK];                              // rowsum(dO . O) per query
+    __shared__ float lse_s[A16_MAXK];                                // log-sum-exp of every query's scores (forward pass)
+    __shared__ float addm_s[A16_MAXK];                               // additive padding mask of every key
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hd = blockIdx.x % H, s = blockIdx.x / H;
     const int NK = T + 1, D = H * 64, NKP = (NK + 31) & ~31, QTN = (T + 31) / 32, KTN = NKP / 32, TP32 = QTN * 32;
@@ -201,6 +205,10 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const u16* __restrict__
     stage_transposed(QT_, TP32, T, qrow);
     stage_transposed(GT_, TP32, T, grow);
     stage_transposed(KT_, NKP, NK, [&](int c) { return kv_row(qkv16, ukv16, ld_ukv, kcol, s, T, D, hd, c, 1); });
+    for (int c = threadIdx.x; c < A16_MAXK; c += blockDim.x) {
+        addm_s[c] = (c == 0 || c >= NK || !am) ? 0.f : (1.0f - am[(size_t)s * T + c - 1]) * -10000.0f;
+        lse_s[c] = lse[((size_t)s * T + min(c, T - 1)) * H + hd];
+    }
     // delta of query i: lanes (i, half 0 / 1) take 32 dims each
     for (int i0 = wave * 32; i0 < TP32; i0 += 128) {
         const int i = min(i0 + col, T - 1);
@@ -218,9 +226,12 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const u16* __restrict__
     }
     __syncthreads();
 
-    // ---- dQ of query tile `wave`: transposed tiles (a lane = one query)
-    if (wave < QTN) {
-        const int qt = wave, iq = qt * 32 + col, iqc = min(iq, T - 1);
+    // Roles: the QTN dQ tiles and the KTN dK / dV tiles are dealt out over the four waves round robin in the order
+    // dQ_0 .. dQ_{QTN-1}, dKV_0 .. dKV_{KTN-1} (role r -> wave r % 4); 64 tokens: dQ_0, dQ_1, dKV_0, dKV_1 on waves 0-3, dKV_2
+    // (the last key alone) on wave 0 again.
+    // ---- dQ of a query tile: transposed tiles (a lane = one query)
+    for (int qt = wave; qt < QTN; qt += 4) {
+        const int iq = qt * 32 + col, iqc = min(iq, T - 1);
         const int need = min(NK - 1, qt * 32 + 32) / 32 + 1;
         h16x8 qf[4], gf[4];
 #pragma unroll
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const u16* __restrict__
             qf[ks] = *reinterpret_cast<const h16x8*>(qrow(iqc) + half * 8 + ks * 16);
             gf[ks] = *reinterpret_cast<const h16x8*>(grow(iqc) + half * 8 + ks * 16);
         }
-        const float lse_q = lse[((size_t)s * T + iqc) * H + hd], delta_q = delta_s[qt * 32 + col];
+        const float lse_q = lse_s[iqc], delta_q = delta_s[qt * 32 + col];
         const unsigned long long mrow4 = (((unsigned long long)s * H + hd) * T + iqc) * (dropout_key_pitch(NK) >> 2);
         f32x16 dq[2];
 #pragma unroll
@@ -263,8 +274,7 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const u16* __restrict__
                         float x = 0.f;
                         if (c < NK) {
                             const bool allowed = (c == 0) || (c - 1 <= iq);
-                            const float addm = (c == 0 || !am) ? 0.f : (1.0f - am[(size_t)s * T + c - 1]) * -10000.0f;
-                            const float pr = expf((allowed ? aS[r] * 0.125f : -1e4f) + addm - lse_q);
+                            const float pr = __expf((allowed ? aS[r] * 0.125f : -1e4f) + addm_s[c] - lse_q);
                             x = allowed ? pr * (aP[r] * mk4[e4] - delta_q) * 0.125f : 0.f;
                         }
                         dsv[e] = x;
@@ -291,21 +301,13 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const u16* __restrict__
         }
     }
 
-    // ---- dK, dV of key tile `wave`: untransposed tiles (a lane = one key)
-    if (wave < KTN) {
-        const int kt = wave, c = kt * 32 + col, cc = min(c, NK - 1);
+    // ---- dK, dV of a key tile: untransposed tiles (a lane = one key)
+    for (int kt = ((wave - QTN) % 4 + 4) % 4; kt < KTN; kt += 4) {
+        const int c = kt * 32 + col, cc = min(c, NK - 1);
         const bool cvalid = c < NK;
-        h16x8 kf[4], vf[4];
-        {
-            const u16* kp = kv_row(qkv16, ukv16, ld_ukv, kcol, s, T, D, hd, cc, 1) + half * 8;
-            const u16* vp = kv_row(qkv16, ukv16, ld_ukv, kcol, s, T, D, hd, cc, 2) + half * 8;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                kf[ks] = *reinterpret_cast<const h16x8*>(kp + ks * 16);
-                vf[ks] = *reinterpret_cast<const h16x8*>(vp + ks * 16);
-            }
-        }
-        const float addm = (cc == 0 || !am) ? 0.f : (1.0f - am[(size_t)s * T + cc - 1]) * -10000.0f;
+        const u16* kp = kv_row(qkv16, ukv16, ld_ukv, kcol, s, T, D, hd, cc, 1) + half * 8;
+        const u16* vp = kv_row(qkv16, ukv16, ld_ukv, kcol, s, T, D, hd, cc, 2) + half * 8;
+        const float addm = addm_s[cc];
         const int kpitch = dropout_key_pitch(NK);
         f32x16 dk[2], dv[2];
 #pragma unroll
@@ -313,19 +315,30 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const u16* __restrict__
         const int qt0 = kt == 0 ? 0 : kt - 1;   // first query tile with a query i >= (first key of the tile) - 1
         for (int qt = qt0; qt < QTN; ++qt) {
             const int ia = min(qt * 32 + col, T - 1);
-            h16x8 qf[4], gf[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                qf[ks] = *reinterpret_cast<const h16x8*>(qrow(ia) + half * 8 + ks * 16);
-                gf[ks] = *reinterpret_cast<const h16x8*>(grow(ia) + half * 8 + ks * 16);
-            }
+            // (the K / V fragments of this lane's key are re-read per query tile - L2 hits - instead of living in 32 registers
+            // across the loop: 184 -> <= 168 registers = three waves per SIMD, what the LDS footprint admits anyway)
             f32x16 aS, aP;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { aS[r] = 0.f; aP[r] = 0.f; }
+            {
+                h16x8 qf[4], kf[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                aS = mfma_h<F16>(qf[ks], kf[ks], aS);
-                aP = mfma_h<F16>(gf[ks], vf[ks], aP);
+                for (int ks = 0; ks < 4; ++ks) {
+                    qf[ks] = *reinterpret_cast<const h16x8*>(qrow(ia) + half * 8 + ks * 16);
+                    kf[ks] = *reinterpret_cast<const h16x8*>(kp + ks * 16);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) aS = mfma_h<F16>(qf[ks], kf[ks], aS);
+            }
+            {
+                h16x8 gf[4], vf[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    gf[ks] = *reinterpret_cast<const h16x8*>(grow(ia) + half * 8 + ks * 16);
+                    vf[ks] = *reinterpret_cast<const h16x8*>(vp + ks * 16);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) aP = mfma_h<F16>(gf[ks], vf[ks], aP);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -344,9 +357,9 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const u16* __restrict__
                         const int e = 4 * q + e4, r = 8 * u + e, i = i0 + e4;
                         float pr = 0.f, x = 0.f;
                         if (i < T && cvalid) {
-                            const float lse_i = lse[((size_t)s * T + i) * H + hd], delta_i = delta_s[i];
+                            const float lse_i = lse_s[i], delta_i = delta_s[i];
                             const bool allowed = (c == 0) || (c - 1 <= i);
-                            pr = expf((allowed ? aS[r] * 0.125f : -1e4f) + addm - lse_i);
+                            pr = __expf((allowed ? aS[r] * 0.125f : -1e4f) + addm - lse_i);
                             x = allowed ? pr * (aP[r] * mk4[e4] - delta_i) * 0.125f : 0.f;
                             pr *= mk4[e4];
                         }
@@ -397,8 +410,10 @@ bool attn16_supported(int T) { return T >= 1 && T + 1 <= A16_MAXK; }
 int launch_attn16_forward(const unsigned short* qkv16, const unsigned short* ukv16, int ld_ukv, int kcol, const float* am,
                           unsigned short* out16, float* lse, int S, int H, int T, DropoutParams drop, int f16, hipStream_t st) {
     RGRG_CHECK_ARG(attn16_supported(T) && qkv16 && ukv16 && out16 && lse);
-    if (f16) hipLaunchKernelGGL(attn16_fwd_kernel<true>, dim3(S * H), dim3(256), 0, st, qkv16, ukv16, ld_ukv, kcol, am, out16, lse, S, H, T, drop);
-    else hipLaunchKernelGGL(attn16_fwd_kernel<false>, dim3(S * H), dim3(256), 0, st, qkv16, ukv16, ld_ukv, kcol, am, out16, lse, S, H, T, drop);
+    // a wave per 32-query tile: <= 64 tokens need two waves (a 256-thread workgroup would keep two idle waves resident)
+    const dim3 block(T <= 64 ? 128 : 256);
+    if (f16) hipLaunchKernelGGL(attn16_fwd_kernel<true>, dim3(S * H), block, 0, st, qkv16, ukv16, ld_ukv, kcol, am, out16, lse, S, H, T, drop);
+    else hipLaunchKernelGGL(attn16_fwd_kernel<false>, dim3(S * H), block, 0, st, qkv16, ukv16, ld_ukv, kcol, am, out16, lse, S, H, T, drop);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }

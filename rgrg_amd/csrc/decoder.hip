@@ -2560,10 +2560,10 @@ int launch_attn16_forward(const unsigned short* qkv16, const unsigned short* ukv
 int launch_attn16_backward(const unsigned short* qkv16, const unsigned short* ukv16, int ld_ukv, int kcol, const float* am,
                            const unsigned short* d_att16, const unsigned short* att16, const float* lse, unsigned short* d_qkv16,
                            float* d_ukv, int S, int H, int T, DropoutParams drop, float ukv_scale, int f16, hipStream_t st);
-int launch_resid_dropout_ln16(const float* y, const float* resid, float* x, const float* g, const float* b, unsigned short* xn16,
-                              DropoutParams drop, int f16, int rows, int D, hipStream_t st);
-int launch_ln_backward16(const float* dy, const float* x, const float* g, float* out, unsigned short* out16, int rows, int D,
-                         int accumulate, DropoutParams drop, int f16, hipStream_t st);
+int launch_resid_dropout_ln16(const float* y, const unsigned short* y16, const float* resid, float* x, const float* g, const float* b,
+                              unsigned short* xn16, DropoutParams drop, int f16, int rows, int D, hipStream_t st);
+int launch_ln_backward16(const float* dy, const unsigned short* dy16, const float* x, const float* g, float* out, unsigned short* out16,
+                         int rows, int D, int accumulate, DropoutParams drop, int f16, hipStream_t st);
 int launch_ce_backward16(const float* logits, size_t ld, int V, int row0, int rows, const long long* ids, const int* row_valid,
                          const float* row_lse, const int* n_scored, float scale, const int* id_error, unsigned short* out16, int f16,
                          hipStream_t st);
@@ -2715,7 +2715,12 @@ static int tr_body16(rgrg_decoder* d, const long long* ids, const float* attenti
     auto dp = [&](int l, int site) { return DropoutParams{dropout_seed, (unsigned)(l * 4 + site), dropout_p}; };
     const DropoutParams none{0ull, 0u, 0.f};
     const float s_int = f16 ? 32768.0f : 1.0f;
-    float* y = d->tr_dbig;   // [M, D] scratch for a projection's output in front of the residual / dropout / LayerNorm kernel
+    // [M, D] 16-bit scratch for a projection's output in front of the residual / dropout / LayerNorm kernel (forward: the
+    // buffer of the masked gradient, unused until the backward) and for d(LayerNorm output) in front of the LayerNorm-backward
+    // kernel (backward: the buffer of the LayerNorm outputs, unused after the forward).  16 bit like every GEMM output of the
+    // reference under autocast: half the store tail of the K = 1024 GEMMs, whose 256 KiB tiles leave through the HBM write path.
+    unsigned short* y16 = d->tr_dx16;
+    unsigned short* dy16 = d->tr_xn16;
     const bool a16 = d->tr_a16;
     if (a16 && (rc = convert_f32_to_bf16(d->ukv_out, d->tr_ukv16, (size_t)S * LD, st, f16))) return rc;
 
@@ -2723,7 +2728,7 @@ static int tr_body16(rgrg_decoder* d, const long long* ids, const float* attenti
                        xs(0), d->tf_xn, D, d->V, d->id_error);
     RGRG_LAUNCH_CHECK();
     // self.drop on the embeddings (language_model.py:311) and ln_1 of layer 0 as 16 bit
-    if ((rc = launch_resid_dropout_ln16(xs(0), nullptr, xs(0), d->layers[0].ln1_g, d->layers[0].ln1_b, d->tr_xn16, dp(0, 0), f16, M, D, st)))
+    if ((rc = launch_resid_dropout_ln16(xs(0), nullptr, nullptr, xs(0), d->layers[0].ln1_g, d->layers[0].ln1_b, d->tr_xn16, dp(0, 0), f16, M, D, st)))
         return rc;
     for (int l = 0; l < L; ++l) {
         const LayerW& w = d->layers[l];
@@ -2739,19 +2744,19 @@ static int tr_body16(rgrg_decoder* d, const long long* ids, const float* attenti
             if ((rc = tr_lin16(d, w.c_attn, false, d->tr_xn16, nullptr, nullptr, qkv16, M, 3 * D))) return rc;
             if ((rc = launch_attn16_forward(qkv16, d->tr_ukv16, LD, l * 2 * D, attention_mask, att16, lse, S, d->H, T, dp(l, 1), f16, st)))
                 return rc;
-            if ((rc = tr_lin16(d, w.attn_proj, false, att16, nullptr, y, nullptr, M, D))) return rc;
+            if ((rc = tr_lin16(d, w.attn_proj, false, att16, nullptr, nullptr, y16, M, D))) return rc;
         } else {
             if ((rc = tr_lin16(d, w.c_attn, false, d->tr_xn16, nullptr, qkv, nullptr, M, 3 * D))) return rc;
             if ((rc = launch_attn_prefill(qkv, d->ukv_out, LD, l * 2 * D, attention_mask, att, S, d->H, T, lse, dp(l, 1), st, d->tr_att16, f16)))
                 return rc;
-            if ((rc = tr_lin16(d, w.attn_proj, false, d->tr_att16, nullptr, y, nullptr, M, D))) return rc;
+            if ((rc = tr_lin16(d, w.attn_proj, false, d->tr_att16, nullptr, nullptr, y16, M, D))) return rc;
         }
-        if ((rc = launch_resid_dropout_ln16(y, xs(2 * l), xs(2 * l + 1), w.ln2_g, w.ln2_b, d->tr_xn16, dp(l, 2), f16, M, D, st))) return rc;
+        if ((rc = launch_resid_dropout_ln16(nullptr, y16, xs(2 * l), xs(2 * l + 1), w.ln2_g, w.ln2_b, d->tr_xn16, dp(l, 2), f16, M, D, st))) return rc;
         GemmLnFold pre{};
         pre.Ypre16 = ffpre16;
         if ((rc = tr_lin16(d, w.c_fc, false, d->tr_xn16, nullptr, nullptr, d->tr_ff16, M, 4 * D, RGRG_ACT_GELU_NEW, &pre))) return rc;
-        if ((rc = tr_lin16(d, w.mlp_proj, false, d->tr_ff16, nullptr, y, nullptr, M, D))) return rc;
-        if ((rc = launch_resid_dropout_ln16(y, xs(2 * l + 1), xs(2 * l + 2), ng, nb, d->tr_xn16, dp(l, 3), f16, M, D, st))) return rc;
+        if ((rc = tr_lin16(d, w.mlp_proj, false, d->tr_ff16, nullptr, nullptr, y16, M, D))) return rc;
+        if ((rc = launch_resid_dropout_ln16(nullptr, y16, xs(2 * l + 1), xs(2 * l + 2), ng, nb, d->tr_xn16, dp(l, 3), f16, M, D, st))) return rc;
     }
     // lm_head + loss + d(logits) + d(ln_f output), chunk by chunk
     hipLaunchKernelGGL(ce_valid_kernel, dim3((M + 255) / 256), dim3(256), 0, st, attention_mask, T, M, d->tf_row_loss, d->tf_row_valid);
@@ -2768,6 +2773,7 @@ static int tr_body16(rgrg_decoder* d, const long long* ids, const float* attenti
         if ((rc = launch_ce_backward16(d->tr_logits, (size_t)VP, V, r0, rows, ids, d->tf_row_valid, d->tr_row_lse, d->tr_count,
                                        loss_scale * s_int, d->id_error, d->tr_dl16, f16, st)))
             return rc;
+        // (fp32: the 16-bit scratch still holds the ln_f rows the lm_head of later chunks reads)
         if ((rc = tr_lin16(d, d->lm_head, true, d->tr_dl16, nullptr, d->tr_dxn + (size_t)r0 * D, nullptr, rows, D))) return rc;
     }
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, d->tf_row_loss, d->tf_row_valid, M, loss_out, (int*)nullptr,
@@ -2775,15 +2781,15 @@ static int tr_body16(rgrg_decoder* d, const long long* ids, const float* attenti
     RGRG_LAUNCH_CHECK();
     if ((rc = id_error_end(d))) return rc;
     // backward through ln_f and the 24 frozen blocks; dx16 always carries the mask of the branch the gradient enters next
-    if ((rc = launch_ln_backward16(d->tr_dxn, xs(2 * L), d->lnf_g, d->tr_dx, d->tr_dx16, M, D, 0, dp(L - 1, 3), f16, st))) return rc;
+    if ((rc = launch_ln_backward16(d->tr_dxn, nullptr, xs(2 * L), d->lnf_g, d->tr_dx, d->tr_dx16, M, D, 0, dp(L - 1, 3), f16, st))) return rc;
     for (int l = L - 1; l >= 0; --l) {
         const LayerW& w = d->layers[l];
         float* qkv = a16 ? nullptr : d->tr_qkv + (size_t)l * M * 3 * D;
         GemmLnFold gb{};
         gb.G16 = d->tr_ffpre16 + (size_t)l * M * 4 * D;
         if ((rc = tr_lin16(d, w.mlp_proj, true, d->tr_dx16, nullptr, nullptr, d->tr_dff16, M, 4 * D, RGRG_ACT_NONE, &gb))) return rc;
-        if ((rc = tr_lin16(d, w.c_fc, true, d->tr_dff16, nullptr, d->tr_dxn, nullptr, M, D))) return rc;
-        if ((rc = launch_ln_backward16(d->tr_dxn, xs(2 * l + 1), w.ln2_g, d->tr_dx, d->tr_dx16, M, D, 1, dp(l, 2), f16, st))) return rc;
+        if ((rc = tr_lin16(d, w.c_fc, true, d->tr_dff16, nullptr, nullptr, dy16, M, D))) return rc;
+        if ((rc = launch_ln_backward16(nullptr, dy16, xs(2 * l + 1), w.ln2_g, d->tr_dx, d->tr_dx16, M, D, 1, dp(l, 2), f16, st))) return rc;
         if (a16) {
             if ((rc = tr_lin16(d, w.attn_proj, true, d->tr_dx16, nullptr, nullptr, d->tr_datt16, M, D))) return rc;
             if ((rc = launch_attn16_backward(d->tr_qkv16 + (size_t)l * M * 3 * D, d->tr_ukv16, LD, l * 2 * D, attention_mask, d->tr_datt16,
@@ -2797,9 +2803,9 @@ static int tr_body16(rgrg_decoder* d, const long long* ids, const float* attenti
                                            d->tr_dqkv16, f16, 1.0f / s_int)))
                 return rc;
         }
-        if ((rc = tr_lin16(d, w.c_attn, true, d->tr_dqkv16, nullptr, d->tr_dxn, nullptr, M, D))) return rc;
+        if ((rc = tr_lin16(d, w.c_attn, true, d->tr_dqkv16, nullptr, nullptr, dy16, M, D))) return rc;
         // the gradient enters layer l - 1 through its mlp branch (site 3); below layer 0 nothing reads the 16-bit copy
-        if ((rc = launch_ln_backward16(d->tr_dxn, xs(2 * l), w.ln1_g, d->tr_dx, l > 0 ? d->tr_dx16 : nullptr, M, D, 1,
+        if ((rc = launch_ln_backward16(nullptr, dy16, xs(2 * l), w.ln1_g, d->tr_dx, l > 0 ? d->tr_dx16 : nullptr, M, D, 1,
                                        l > 0 ? dp(l - 1, 3) : none, f16, st)))
             return rc;
     }
@@ -2949,6 +2955,72 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
     return RGRG_OK;
 }
 
+// Roofline support for BASELINE configs[4] (bench.py): the frozen-weight GEMMs of ONE training step of the 16-bit flow - per
+// layer c_attn, attn_proj, c_fc, mlp_proj forward and their four activation-gradient GEMMs, lm_head forward and dgrad per
+// chunk - launched back to back on the decoder's stream with the operands and epilogues of tr_body16, timed between two HIP
+// events (one untimed pass in front).  The work space of the last rgrg_decoder_lm_loss_grad call at this shape is reused (its
+// contents are overwritten with garbage: timing only).  flops = 2 M N K of those launches.
+extern "C" int rgrg_decoder_time_train_gemms(rgrg_decoder* d, int S, int T, int iters, float* ms_per_step, double* flops_per_step,
+                                             int* launches_per_step) {
+    RGRG_CHECK_ARG(d && S > 0 && T >= 2 && iters > 0 && ms_per_step && flops_per_step && launches_per_step);
+    const int D = d->D, M = S * T, L = d->n_layer, VP = pad256(d->V);
+    if (!d->tr_h16 || (size_t)M > d->tr_rows || !d->bf16_gemms) {
+        set_error("time_train_gemms: run a 16-bit training pass of this shape first (16-bit work space %d, rows %zu of %d, mode %d)",
+                  (int)d->tr_h16, d->tr_rows, M, d->bf16_gemms);
+        return RGRG_EINVAL;
+    }
+    const bool a16 = d->tr_a16;
+    const size_t MD = (size_t)M * D;
+    hipEvent_t e0, e1;
+    RGRG_HIP(hipEventCreate(&e0));
+    RGRG_HIP(hipEventCreate(&e1));
+    int rc = RGRG_OK, launches = 0;
+    double flops = 0.0;
+    auto cnt = [&](const Lin& l) { flops += 2.0 * M * (double)l.N * l.K; ++launches; };
+    for (int it = -1; it < iters && !rc; ++it) {
+        if (it == 0) RGRG_HIP(hipEventRecord(e0, d->stream));
+        const bool c = it == -1;
+        for (int l = 0; l < L && !rc; ++l) {
+            const LayerW& w = d->layers[l];
+            unsigned short* att16 = a16 ? d->tr_att16 + (size_t)l * MD : d->tr_att16;
+            GemmLnFold pre{}, gb{};
+            pre.Ypre16 = d->tr_ffpre16 + (size_t)l * M * 4 * D;
+            gb.G16 = d->tr_ffpre16 + (size_t)l * M * 4 * D;
+            if (a16) rc = tr_lin16(d, w.c_attn, false, d->tr_xn16, nullptr, nullptr, d->tr_qkv16 + (size_t)l * M * 3 * D, M, 3 * D);
+            else rc = tr_lin16(d, w.c_attn, false, d->tr_xn16, nullptr, d->tr_qkv + (size_t)l * M * 3 * D, nullptr, M, 3 * D);
+            if (rc || (rc = tr_lin16(d, w.attn_proj, false, att16, nullptr, nullptr, d->tr_dx16, M, D))) break;
+            if ((rc = tr_lin16(d, w.c_fc, false, d->tr_xn16, nullptr, nullptr, d->tr_ff16, M, 4 * D, RGRG_ACT_GELU_NEW, &pre))) break;
+            if ((rc = tr_lin16(d, w.mlp_proj, false, d->tr_ff16, nullptr, nullptr, d->tr_dx16, M, D))) break;
+            if ((rc = tr_lin16(d, w.mlp_proj, true, d->tr_dx16, nullptr, nullptr, d->tr_dff16, M, 4 * D, RGRG_ACT_NONE, &gb))) break;
+            if ((rc = tr_lin16(d, w.c_fc, true, d->tr_dff16, nullptr, nullptr, d->tr_xn16, M, D))) break;
+            if (a16) rc = tr_lin16(d, w.attn_proj, true, d->tr_dx16, nullptr, nullptr, d->tr_datt16, M, D);
+            else rc = tr_lin16(d, w.attn_proj, true, d->tr_dx16, nullptr, d->tr_dxn, nullptr, M, D);
+            if (rc || (rc = tr_lin16(d, w.c_attn, true, d->tr_dqkv16, nullptr, nullptr, d->tr_xn16, M, D))) break;
+            if (c) { cnt(w.c_attn); cnt(w.attn_proj); cnt(w.c_fc); cnt(w.mlp_proj); cnt(w.mlp_proj); cnt(w.c_fc); cnt(w.attn_proj); cnt(w.c_attn); }
+        }
+        const int chunk = (int)d->tr_chunk;
+        for (int r0 = 0; r0 < M && !rc; r0 += chunk) {
+            const int rows = (M - r0 < chunk) ? M - r0 : chunk;
+            if ((rc = tr_lin16(d, d->lm_head, false, d->tr_xn16 + (size_t)r0 * D, nullptr, d->tr_logits, nullptr, rows, VP))) break;
+            if ((rc = tr_lin16(d, d->lm_head, true, d->tr_dl16, nullptr, d->tr_dxn + (size_t)r0 * D, nullptr, rows, D))) break;
+            if (c) { flops += 2.0 * 2.0 * rows * (double)d->lm_head.N * d->lm_head.K; launches += 2; }
+        }
+    }
+    float ms = 0.f;
+    if (!rc) {
+        RGRG_HIP(hipEventRecord(e1, d->stream));
+        RGRG_HIP(hipEventSynchronize(e1));
+        RGRG_HIP(hipEventElapsedTime(&ms, e0, e1));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    *ms_per_step = ms / iters;
+    *flops_per_step = flops;
+    *launches_per_step = launches;
+    return RGRG_OK;
+}
+
 // LanguageModel.forward(input_ids, ..., past_key_values, use_cache=True) (language_model.py:258-366, :396-399): the
 // incremental form the reference's own generate loop is built on, over THIS decoder's K/V cache.  past_len == 0: the image
 // key / value is computed from feats and stored in slot 0 (past_key_values=None, :135-157); then the T tokens of every row
@@ -2957,13 +3029,15 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
 extern "C" int rgrg_decoder_forward_cached(rgrg_decoder* d, const float* feats, const int64_t* input_ids, const int64_t* position_ids,
                                            int S, int T, int past_len, float* logits_out, void* stream) {
     RGRG_CHECK_ARG(d && input_ids && logits_out && S > 0 && S <= d->max_seqs && T >= 1 && past_len >= 0);
-    RGRG_CHECK_ARG((past_len == 0) == (feats != nullptr));
+    // feats == NULL with past_len == 0: the caller put a past that holds ONLY the image slot into the cache (a foreign
+    // past_key_values of shape [.., 1, 64], language_model.py:162-166 uses the supplied past and ignores the image then)
+    RGRG_CHECK_ARG(past_len == 0 || feats == nullptr);
     RGRG_CHECK_ARG(past_len + T <= d->max_len);   // slot of the last token = past_len + T <= T_cache - 1
     hipStream_t caller = as_stream(stream), st = d->stream;
     RGRG_HIP(hipEventRecord(d->ev_in, caller));
     RGRG_HIP(hipStreamWaitEvent(st, d->ev_in, 0));
     int rc;
-    if (past_len == 0 && (rc = enqueue_prefill(d, feats, S))) return rc;   // also resets the step counter to 0
+    if (past_len == 0 && feats && (rc = enqueue_prefill(d, feats, S))) return rc;   // also resets the step counter to 0
     for (int j = 0; j < T; ++j) {
         hipLaunchKernelGGL(forward_cached_tokens_kernel, dim3((S + 255) / 256), dim3(256), 0, st,
                            reinterpret_cast<const long long*>(input_ids), reinterpret_cast<const long long*>(position_ids), T, j, S, d->V,
@@ -3037,9 +3111,27 @@ extern "C" int rgrg_debug_ln_fold16(const float* w, const float* gain, const flo
     return RGRG_OK;
 }
 
+static int set_precision_impl(rgrg_decoder* d, int mode);
 extern "C" int rgrg_decoder_set_precision(rgrg_decoder* d, int mode) {
     RGRG_CHECK_ARG(d && mode >= 0 && mode <= 2);
     if (mode == d->bf16_gemms) return RGRG_OK;
+    const int prev = d->bf16_gemms;
+    const int rc = set_precision_impl(d, mode);
+    if (rc) {
+        // a copy or an allocation failed half way: the decoder goes back to the mode it was in - whose copies may
+        // have been re-typed already, so every 16-bit copy is marked stale (the next successful switch redoes them all) and the
+        // mode falls back to fp32 unless it already was - and graphs captured for either type are dropped
+        auto stale = [](Lin& l) { l.wb_f16 = -1; l.wb_ln_f16 = -1; l.wTb_f16 = -1; };
+        stale(d->lm_head); stale(d->ukv); stale(d->fst2);
+        for (auto& w : d->layers) { stale(w.c_attn); stale(w.attn_proj); stale(w.c_fc); stale(w.mlp_proj); }
+        d->bf16_gemms = 0;
+        (void)prev;
+        for (auto& g : d->graphs) (void)hipGraphExecDestroy(g.exec);
+        d->graphs.clear();
+    }
+    return rc;
+}
+static int set_precision_impl(rgrg_decoder* d, int mode) {
     const int prev = d->bf16_gemms;
     d->bf16_gemms = mode;   // d->f16() below is the NEW type
     if (mode) {

@@ -106,7 +106,14 @@ __device__ __forceinline__ void store16x4(unsigned short* dst, const f32x4& v, i
 // x = resid + dropout(y)  (resid_dropout / the embedding dropout when resid == nullptr; y may alias x), stored fp32 for the
 // backward pass, and xn16 = round16(LayerNorm(x) * g + b) for the GEMM behind the LayerNorm.  One wave per row of 1024,
 // reductions by DPP, two-pass variance like nn.LayerNorm (the arithmetic of ln_rows_kernel, decoder.hip).
-__global__ __launch_bounds__(256) void resid_dropout_ln16_kernel(const float* y, const float* __restrict__ resid, float* x,
+__device__ __forceinline__ f32x4 load16x4(const unsigned short* src, int f16) {
+    const uint2 r = *reinterpret_cast<const uint2*>(src);
+    return f32x4{from16_rt(r.x & 0xffffu, f16), from16_rt(r.x >> 16, f16), from16_rt(r.y & 0xffffu, f16), from16_rt(r.y >> 16, f16)};
+}
+// y comes as fp32 (y) or as 16 bit (y16: the projection GEMMs of the 16-bit flow write their result in the autocast type, as
+// the reference's do under torch.autocast) - exactly one of the two is non-null
+__global__ __launch_bounds__(256) void resid_dropout_ln16_kernel(const float* y, const unsigned short* __restrict__ y16,
+                                                                 const float* __restrict__ resid, float* x,
                                                                  const float* __restrict__ g, const float* __restrict__ b,
                                                                  unsigned short* __restrict__ xn16, const DropoutParams drop, int f16,
                                                                  int rows) {
@@ -115,7 +122,8 @@ __global__ __launch_bounds__(256) void resid_dropout_ln16_kernel(const float* y,
     const size_t base = (size_t)row * 1024;
     f32x4 v[4], rr[4], gg[4], bb[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = reinterpret_cast<const f32x4*>(y + base)[j * 64 + lane];
+    for (int j = 0; j < 4; ++j)
+        v[j] = y16 ? load16x4(y16 + base + 4 * (j * 64 + lane), f16) : reinterpret_cast<const f32x4*>(y + base)[j * 64 + lane];
 #pragma unroll
     for (int j = 0; j < 4; ++j) rr[j] = resid ? reinterpret_cast<const f32x4*>(resid + base)[j * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -151,8 +159,8 @@ __global__ __launch_bounds__(256) void resid_dropout_ln16_kernel(const float* y,
 
 // LayerNorm backward w.r.t. its input (as ln_backward_kernel), one wave per row, plus the 16-bit copy the next dgrad GEMM
 // reads: out16 = round16(out * mask) - the dropout mask of the residual branch the gradient enters next (p = 0: plain copy).
-__global__ __launch_bounds__(256) void ln_backward16_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                            const float* __restrict__ g, float* out,
+__global__ __launch_bounds__(256) void ln_backward16_kernel(const float* __restrict__ dy, const unsigned short* __restrict__ dy16,
+                                                            const float* __restrict__ x, const float* __restrict__ g, float* out,
                                                             unsigned short* __restrict__ out16, int accumulate,
                                                             const DropoutParams drop, int f16, int rows) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -162,7 +170,8 @@ __global__ __launch_bounds__(256) void ln_backward16_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = reinterpret_cast<const f32x4*>(x + base)[j * 64 + lane];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dd[j] = reinterpret_cast<const f32x4*>(dy + base)[j * 64 + lane];
+    for (int j = 0; j < 4; ++j)
+        dd[j] = dy16 ? load16x4(dy16 + base + 4 * (j * 64 + lane), f16) : reinterpret_cast<const f32x4*>(dy + base)[j * 64 + lane];
 #pragma unroll
     for (int j = 0; j < 4; ++j) gg[j] = reinterpret_cast<const f32x4*>(g)[j * 64 + lane];
 #pragma unroll
@@ -555,6 +564,26 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// The same update for MANY tensors in one launch (round 5: a configs[4] step updated its 112 trainable tensors with 112
+// launches of ~6 us): blockIdx.y = tensor, blockIdx.x strides over its elements; hyper-parameters and step are shared.
+struct AdamItem { float* p; const float* g; float* m; float* v; long long n; };
+constexpr int ADAM_BATCH = 64;                       // records per launch: they travel in the kernel arguments (2.5 KiB of the 4 KiB)
+struct AdamBatch { AdamItem it[ADAM_BATCH]; };
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamBatch batch, float lr, float b1, float b2, float eps,
+                                                          float wd, float bc1, float bc2_sqrt, float grad_scale) {
+    const AdamItem it = batch.it[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)it.n; i += (size_t)gridDim.x * 256) {
+        const float gi = it.g[i] * grad_scale;
+        float pi = it.p[i] * (1.0f - lr * wd);
+        const float mi = b1 * it.m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * it.v[i] + (1.0f - b2) * gi * gi;
+        it.m[i] = mi;
+        it.v[i] = vi;
+        pi -= (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        it.p[i] = pi;
+    }
+}
+
 // ------------------------------------------------------------------ launchers (decoder.hip)
 static int blocks_for(size_t n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
 
@@ -591,17 +620,17 @@ int launch_ce_backward(float* logits, size_t ld, int V, int row0, int rows, cons
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
-int launch_resid_dropout_ln16(const float* y, const float* resid, float* x, const float* g, const float* b, unsigned short* xn16,
-                              DropoutParams drop, int f16, int rows, int D, hipStream_t st) {
-    RGRG_CHECK_ARG(D == 1024 && rows > 0 && y && x && xn16);
-    hipLaunchKernelGGL(resid_dropout_ln16_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, y, resid, x, g, b, xn16, drop, f16, rows);
+int launch_resid_dropout_ln16(const float* y, const unsigned short* y16, const float* resid, float* x, const float* g, const float* b,
+                              unsigned short* xn16, DropoutParams drop, int f16, int rows, int D, hipStream_t st) {
+    RGRG_CHECK_ARG(D == 1024 && rows > 0 && ((y != nullptr) != (y16 != nullptr)) && x && xn16);
+    hipLaunchKernelGGL(resid_dropout_ln16_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, y, y16, resid, x, g, b, xn16, drop, f16, rows);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
-int launch_ln_backward16(const float* dy, const float* x, const float* g, float* out, unsigned short* out16, int rows, int D,
-                         int accumulate, DropoutParams drop, int f16, hipStream_t st) {
-    RGRG_CHECK_ARG(D == 1024 && rows > 0);
-    hipLaunchKernelGGL(ln_backward16_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, dy, x, g, out, out16, accumulate, drop, f16, rows);
+int launch_ln_backward16(const float* dy, const unsigned short* dy16, const float* x, const float* g, float* out, unsigned short* out16,
+                         int rows, int D, int accumulate, DropoutParams drop, int f16, hipStream_t st) {
+    RGRG_CHECK_ARG(D == 1024 && rows > 0 && ((dy != nullptr) != (dy16 != nullptr)));
+    hipLaunchKernelGGL(ln_backward16_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, dy, dy16, x, g, out, out16, accumulate, drop, f16, rows);
     RGRG_LAUNCH_CHECK();
     return RGRG_OK;
 }
@@ -687,5 +716,32 @@ extern "C" int rgrg_adamw_step_f32(float* param, const float* grad, float* exp_a
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks_for((size_t)n)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq,
                        (size_t)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
     RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
+// items: HOST array of n_items records {param, grad, exp_avg, exp_avg_sq (device pointers to f32), element count (int64)} - five
+// 64-bit words each.  The records ride in the kernel arguments (64 per launch): no device-side table to keep in sync with
+// gradients that are re-allocated every step (zero_grad(set_to_none=True)), no host-to-device copy, nothing to wait for.
+extern "C" int rgrg_adamw_multi_step_f32(const void* items, int n_items, float lr, float beta1, float beta2, float eps,
+                                         float weight_decay, int step, float grad_scale, void* stream) {
+    RGRG_CHECK_ARG(items && n_items > 0 && step >= 1 && lr >= 0.f);
+    static_assert(sizeof(AdamItem) == 40, "five 64-bit words per record");
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    const AdamItem* src = reinterpret_cast<const AdamItem*>(items);
+    for (int i0 = 0; i0 < n_items; i0 += ADAM_BATCH) {
+        const int n = n_items - i0 < ADAM_BATCH ? n_items - i0 : ADAM_BATCH;
+        AdamBatch b{};
+        long long max_n = 1;
+        for (int i = 0; i < n; ++i) {
+            b.it[i] = src[i0 + i];
+            RGRG_CHECK_ARG(b.it[i].p && b.it[i].g && b.it[i].m && b.it[i].v && b.it[i].n > 0);
+            if (b.it[i].n > max_n) max_n = b.it[i].n;
+        }
+        const int gx = (int)(((size_t)max_n + 255) / 256 < 1024 ? ((size_t)max_n + 255) / 256 : 1024);
+        hipLaunchKernelGGL(adamw_multi_kernel, dim3(gx, n), dim3(256), 0, as_stream(stream), b, lr, beta1, beta2, eps, weight_decay, bc1,
+                           bc2_sqrt, grad_scale);
+        RGRG_LAUNCH_CHECK();
+    }
     return RGRG_OK;
 }

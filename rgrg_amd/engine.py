@@ -243,6 +243,12 @@ class HipEngine:
             self._decoder = None
             self._kv = None
             self._cached = None
+            # the decoder's own work space is raw hipMalloc memory: hand torch's now unused cache blocks (up to tens of GB) back to
+            # the device so that the next decoder can allocate
+            try:
+                torch.cuda.empty_cache()
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
 
     def __del__(self):
         try:
@@ -805,6 +811,7 @@ class HipEngine:
              "fst0_w": torch.empty((1024, 1024), dtype=torch.float32, device=dev), "fst0_b": torch.empty((1024,), dtype=torch.float32, device=dev),
              "fst2_w": torch.empty((1024, 1024), dtype=torch.float32, device=dev), "fst2_b": torch.empty((1024,), dtype=torch.float32, device=dev)}
         loss = torch.empty((), dtype=torch.float32, device=dev)
+        self.last_train_shape = (int(S), int(T))   # (sentences, tokens) of the last training pass: bench.py times its GEMMs at this shape
         self._check_ids(self.lib.rgrg_decoder_lm_loss_grad(dec, _hip.ptr(feats), _hip.ptr(ids), None if am is None else _hip.ptr(am), S, T,
                                                            float(loss_scale), float(dropout_p), int(dropout_seed) & (2 ** 64 - 1), _hip.ptr(loss),
                                                            _hip.ptr(g["ukv_w"]), _hip.ptr(g["ukv_b"]),
@@ -847,7 +854,11 @@ class HipEngine:
         rows = max(32, ((S + 31) // 32) * 32)
         per_slot = self.n_layer * 2 * rows * 16 * 64 * 4
         free, _total = torch.cuda.mem_get_info(self.device)
+        # blocks torch's caching allocator holds but does not use (e.g. a replaced cache) can serve the new cache tensor
+        free += max(0, torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device))
         fit = int(free * budget_fraction) // per_slot - 1
+        if fit < 2:
+            raise _hip.RgrgHipError(f"a K/V cache for {S} rows does not fit: {free / 2 ** 30:.1f} GiB free, {per_slot / 2 ** 20:.0f} MiB per token slot")
         return max(2, min(int(want), fit))
 
     def forward_cached(self, feats: Optional[Tensor], input_ids: Tensor, past_len: int, cache_len: int = 1024,
@@ -875,9 +886,16 @@ class HipEngine:
                 raise IndexError(f"index out of range in self: a position id is outside [0, {self.vocab})")
             pos = pos.expand(S, T).contiguous()
         if past_len == 0 or adopt_past is not None:
-            if past_len == 0 and (feats is None or feats.shape[0] != S):
+            # an adopted past that holds only the image slot (shape [.., 1, 64]): the supplied key / value of slot 0 is used and the
+            # image is ignored, like the reference does with any past_key_values (language_model.py:162-166)
+            if past_len == 0 and adopt_past is None and (feats is None or feats.shape[0] != S):
                 raise ValueError("image_hidden_states [S,1024] is needed when past_key_values is None")
-            _require_gpu(feats.device if feats is not None else adopt_past[0][0].device)
+            if adopt_past is not None:
+                feats = None
+                for k, v in adopt_past:
+                    if not (torch.is_tensor(k) and torch.is_tensor(v) and k.is_floating_point() and v.is_floating_point()):
+                        raise TypeError("past_key_values must hold floating-point tensors")
+            _require_gpu(feats.device if feats is not None else self.device)
             want = max(self.cache_tokens_that_fit(S, cache_len), past_len + T)
             if self._decoder is not None and S <= self._decoder_caps[0]:
                 want = min(want, max(self._decoder_caps[1], past_len + T))   # an existing decoder is reused as is; it grows only when it must
@@ -914,7 +932,7 @@ class HipEngine:
             self._cached = {"S": S, "tokens": past_len}
         _hip.check(self.lib.rgrg_decoder_set_precision(dec, 0), "rgrg_decoder_set_precision")
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
-        f = None if past_len else feats.to(torch.float32).contiguous()
+        f = None if (past_len or feats is None) else feats.to(torch.float32).contiguous()
         logits = torch.empty((S, T, self.vocab), dtype=torch.float32, device=self.device)
         _hip.check(self.lib.rgrg_decoder_forward_cached(dec, _hip.ptr(f), _hip.ptr(ids), _hip.ptr(pos), S, T, int(past_len), _hip.ptr(logits),
                                                         self._s()), "rgrg_decoder_forward_cached")
@@ -952,6 +970,15 @@ class HipEngine:
         dst = torch.empty((S, self.vocab), dtype=torch.float32, device=self.device)
         _hip.check(self.lib.rgrg_decoder_copy_last_logits(self._decoder, _hip.ptr(dst), S, self._s()), "copy_last_logits")
         return dst
+
+    def time_train_gemms(self, S: int, T: int, iters: int = 3) -> Dict[str, float]:
+        """The frozen-weight GEMMs of one 16-bit training step (forward + activation gradients + lm_head), launched back to
+        back between two HIP events on the decoder's stream, on the work space of the last training pass of this shape
+        (bench.py: roofline of BASELINE configs[4])."""
+        ms, fl, n = C.c_float(0), C.c_double(0), C.c_int(0)
+        _hip.check(self.lib.rgrg_decoder_time_train_gemms(self._decoder, S, T, iters, C.byref(ms), C.byref(fl), C.byref(n)),
+                   "rgrg_decoder_time_train_gemms")
+        return {"ms_gemm": ms.value, "gemm_flops": fl.value, "gemm_launches": n.value}
 
     def time_step_parts(self, S: int, nkeys: int, iters: int = 3) -> Dict[str, float]:
         """Per decode step, measured with HIP events on the decoder's stream (bench.py roofline): ms spent in the

@@ -195,7 +195,8 @@ class LanguageModel(EngineOwner):
         if position_ids is None and past_key_values is not None:
             # the reference's default counts the image key: arange(past_length, past_length + T), past_length = keys in the cache
             position_ids = torch.arange(past + 1, past + 1 + T).view(1, T)
-        return eng.forward_cached(image_hidden_states if past == 0 else None, ids2, past, position_ids=position_ids, adopt_past=adopt)
+        return eng.forward_cached(image_hidden_states if (past == 0 and adopt is None) else None, ids2, past, position_ids=position_ids,
+                                  adopt_past=adopt)
 
     def trainable_parameters(self):
         """uk/uv of every layer, then feature_space_transformation_nn: the language-model tensors the reference

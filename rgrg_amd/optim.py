@@ -26,6 +26,8 @@ class AdamW(torch.optim.Optimizer):
                 loss = closure()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            if self._multi_step(group, b1, b2, grad_scale):
+                continue
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -50,3 +52,37 @@ class AdamW(torch.optim.Optimizer):
                 # layouts (LanguageModel.sync_trainable_if_stale) and autograd's checks notice
                 torch._C._increment_version(p)
         return loss
+
+    def _multi_step(self, group, b1, b2, grad_scale) -> bool:
+        """All tensors of the group in ceil(n / 64) launches (rgrg_adamw_multi_step_f32) when they share device and step count - the
+        normal case; the per-tensor loop above remains for anything else."""
+        ps = [p for p in group["params"] if p.grad is not None]
+        if len(ps) < 2:
+            return False
+        dev = ps[0].device
+        for p in ps:
+            if not (p.is_cuda and p.device == dev and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
+                    and p.grad.dtype == torch.float32):
+                return False
+        for p in ps:
+            st = self.state[p]
+            if not st:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        steps = {int(self.state[p]["step"]) for p in ps}
+        if len(steps) != 1:
+            return False
+        if self._lib is None:
+            self._lib = _hip.load()
+        rows = torch.tensor([(p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
+                              p.numel()) for p in ps], dtype=torch.int64)   # host table: the records travel in the kernel arguments
+        step = steps.pop() + 1
+        with torch.cuda.device(dev):
+            _hip.check(self._lib.rgrg_adamw_multi_step_f32(rows.data_ptr(), len(ps), float(group["lr"]), float(b1), float(b2),
+                                                           float(group["eps"]), float(group["weight_decay"]), step, float(grad_scale),
+                                                           torch.cuda.current_stream(dev).cuda_stream), "rgrg_adamw_multi_step_f32")
+        for p in ps:
+            self.state[p]["step"] = step
+            torch._C._increment_version(p)
+        return True

@@ -234,3 +234,71 @@ def test_bench_self_spawns_n_ranks_when_no_launcher_is_present():
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak"
     assert r["config"]["global_batch"] == 6 and r["config"]["regions_generated"] == 6 * 29
     assert r["value"] > 0 and abs(r["value"] - 6 * 2 / (r["ms_per_step"] * 2e-3)) < 1e-6 * r["value"]
+
+
+# ------------------------------------------------------------------------- world 8 at the shape of BASELINE configs[3] (gloo)
+class _FakeModel8(_FakeModel):
+    """Rank 5 selects nothing (its generate() is never called: the reference returns -1 there, generate_sharded must still
+    take part in the gather); every rank stops at its own length."""
+
+    def __init__(self, rank):
+        super().__init__(300 + rank, 9 + 2 * rank)
+        self.none = rank == 5
+
+    def object_detector(self, images):
+        self.ids, self.sel, det, cd = _fake_generate(images.shape[0], self.seed, none_selected=self.none, length=self.length)
+        return {}, det, torch.zeros((images.shape[0], 29, 1024)), cd
+
+
+def _world8_worker(rank, world, port, ret):
+    from rgrg_amd.dist import generate_sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_bounds(256, rank, world)
+        assert hi - lo == 32
+        out = generate_sharded(_FakeModel8(rank), torch.zeros((hi - lo, 1, 8, 8)), MAXLEN)
+        if rank == 0:
+            ret["out"] = (out[0], out[1], out[2]["top_scores"], out[2]["top_region_boxes"], out[3])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_generate_sharded_world8_at_the_configs3_shape():
+    """configs[3] (256 images over 8 ranks, 32 per rank, ONE gather of token ids) has no hardware run; the
+    code path runs here at its real world size and batch on gloo with stub stages: rank-order concatenation of 8 shards, a rank
+    without any selected region, eight different early-exit lengths (global L' = the longest), per-image records of every rank."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_world8_worker, args=(8, port, ret), nprocs=8, join=True)
+    ids, sel, scores, boxes, cd = ret["out"]
+    parts = [_fake_generate(32, 300 + r, none_selected=(r == 5), length=9 + 2 * r) for r in range(8)]
+    assert sel.shape == (256, 29) and torch.equal(sel, torch.cat([p[1] for p in parts]))
+    assert torch.equal(cd, torch.cat([p[3] for p in parts]))
+    assert torch.equal(scores, torch.cat([p[2]["top_scores"] for p in parts]))
+    assert torch.equal(boxes, torch.cat([p[2]["top_region_boxes"] for p in parts]))
+    L = 9 + 2 * 7
+    want = torch.cat([torch.nn.functional.pad(p[0], (0, L - p[0].shape[1]), value=50256) for p in parts if p[0] is not None])
+    assert int(sel[5 * 32:6 * 32].sum()) == 0 and ids.shape == (int(sel.sum()), L) and torch.equal(ids, want)
+
+
+def test_bench_launcher_with_eight_ranks_on_the_stub():
+    """`python bench.py --gpus 8` as the driver's scaling run would start it (self-spawned here), 32 images per rank: one JSON
+    line from rank 0 with the whole-job aggregate and the configs[3] leg (256 images, one gather) in it."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                          "--batch", "32", "--stub-cpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["scaling"] == "weak" and r["config"]["global_batch"] == 256
+    assert r["config"]["regions_generated"] == 256 * 29
+    assert r["value"] > 0 and abs(r["value"] - 256 * 2 / (r["ms_per_step"] * 2e-3)) < 1e-6 * r["value"]

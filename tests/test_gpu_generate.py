@@ -908,6 +908,15 @@ def test_incremental_forward_with_use_cache_reproduces_the_oracles_cached_steps(
     assert (l_def.cpu() - o_def).abs().max().item() <= 2e-3
     with pytest.raises(IndexError, match="position id"):
         lm(nxt[1].to(DEV), am.to(DEV), feats.to(DEV), past_key_values=clones, position_ids=torch.full((3, 1), 50257), use_cache=True)
+    # a foreign past that holds ONLY the image slot (cloned presents[..., :1, :]): the supplied slot 0 is used as is
+    # and image_hidden_states is ignored, like the reference does with any past_key_values (:162-166) - feeding the prompt on
+    # top of it reproduces the first call's logits even when a DIFFERENT image is passed along
+    img_only = tuple((k[:, :, :1].clone(), v[:, :, :1].clone()) for k, v in clones)
+    l_img, p_img = lm(prompt.to(DEV), torch.ones((3, 4), device=DEV), torch.randn((3, 1024), generator=g).to(DEV), return_loss=False,
+                      past_key_values=img_only, position_ids=torch.arange(3)[None, :], use_cache=True)
+    o_first, _ = o_lm.lm_forward(sd, prompt, torch.ones((3, 3), dtype=torch.int64), feats, None, torch.arange(3)[None, :])
+    assert p_img[0][0].shape == (3, 16, 4, 64) and torch.equal(p_img[7][1][:, :, :1], img_only[7][1])
+    assert (l_img.cpu() - o_first).abs().max().item() <= 2e-3
     # greedy loop written against forward(), as the reference's greedy_search does (:609-652)
     f5 = _lm_feats().to(DEV)
     ref = lm.generate(f5, max_length=10)

@@ -227,3 +227,72 @@ def test_fastrcnn_and_rpn_loss_hand_values():
     # anchor 0 positive (IoU 1), anchor 1 between (0.4: ignored), anchor 2 negative; exact match -> zero box loss
     want = 0.5 * (math.log1p(math.exp(-2.0)) + math.log1p(math.exp(-1.0)))
     assert abs(float(lo) - want) < 1e-6 and float(lb) == 0.0
+
+
+DOWN_GEOMS = [(3056, 2544), (2544, 3056), (1024, 1024), (1536, 1536), (768, 512), (700, 513)]
+UP_GEOMS = [(300, 200), (200, 300), (256, 256), (511, 3), (37, 41)]
+
+
+def _test_image(h, w, seed):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img[: h // 3] = (np.arange(w) % 256).astype(np.uint8)
+    return img
+
+
+def test_preprocess_resize_against_independent_references():
+    """pins for the pre-processing oracle that ARE possible without OpenCV (the reference's
+    generate_reports_for_images.py:129-147 delegates to albumentations / cv2.INTER_AREA, absent from the image).
+      (a) the six DOWN-scaling geometries of the GPU parity test against an independent float64 evaluation of the exact area
+          integral (dense overlap-length matrices Wy^T img Wx - no coverage tables, no float32): the oracle's 8-bit pixel is
+          within 0.5 LSB of the exact box average everywhere, i.e. it IS the correctly rounded area average (ties aside);
+      (b) integer factors against Pillow's Image.reduce() (an independent box filter): factor 2 bit-identical (both compute
+          (a + b + c + d + 2) >> 2), factors 3 and 4 within 1 LSB (Pillow's fixed-point reciprocal rounds a few % of the pixels
+          the other way);
+      (c) the five ENLARGING geometries (OpenCV emulates INTER_AREA with its fixed-point bilinear path there) against a
+          float64 evaluation of the same coordinate rule: within 1 LSB (11-bit weights, two truncating shifts)."""
+    import numpy as np
+    from PIL import Image
+    from oracle import preprocess as P
+
+    def overlap(s, d):   # [s, d] overlap length of source pixel and destination cell, / cell size
+        sc = s / d
+        S, D = np.arange(s, dtype=np.float64)[:, None], np.arange(d, dtype=np.float64)[None, :]
+        return np.clip(np.minimum(S + 1, (D + 1) * sc) - np.maximum(S, D * sc), 0, None) / sc
+
+    for h, w in DOWN_GEOMS:
+        img = _test_image(h, w, h * 31 + w)
+        sc = 512 / max(h, w)
+        nh, nw = max(P.py3round(h * sc), 1), max(P.py3round(w * sc), 1)
+        got = P.resize_area_u8(img, nh, nw).astype(np.float64)
+        exact = overlap(h, nh).T @ img.astype(np.float64) @ overlap(w, nw)
+        assert np.abs(got - exact).max() <= 0.5 + 1e-6, (h, w, np.abs(got - exact).max())
+    for h, w, f, tol in [(1024, 1024, 2, 0), (2048, 1024, 2, 0), (1536, 1536, 3, 1), (1536, 768, 3, 1), (2048, 2048, 4, 1)]:
+        img = _test_image(h, w, h + w + f)
+        got = P.resize_area_u8(img, h // f, w // f).astype(np.int64)
+        pil = np.asarray(Image.fromarray(img).reduce(f)).astype(np.int64)
+        assert np.abs(got - pil).max() <= tol, (h, w, f)
+
+    def coords(ssize, dsize):
+        scale, inv = ssize / dsize, dsize / ssize
+        d = np.arange(dsize, dtype=np.float64)
+        s = np.floor(d * scale)
+        fr = (d + 1.0) - (s + 1.0) * inv
+        fr = np.where(fr <= 0, 0.0, fr - np.floor(fr))
+        s = s.astype(np.int64)
+        fr = np.where(s >= ssize - 1, 0.0, fr)
+        s0 = np.minimum(s, ssize - 1)
+        return s0, np.minimum(s0 + 1, ssize - 1), fr
+    for h, w in UP_GEOMS:
+        img = _test_image(h, w, h * 7 + w)
+        sc = 512 / max(h, w)
+        nh, nw = max(P.py3round(h * sc), 1), max(P.py3round(w * sc), 1)
+        got = P.resize_area_u8(img, nh, nw).astype(np.float64)
+        y0, y1, fy = coords(h, nh)
+        x0, x1, fx = coords(w, nw)
+        src = img.astype(np.float64)
+        top = src[y0][:, x0] * (1 - fx) + src[y0][:, x1] * fx
+        bot = src[y1][:, x0] * (1 - fx) + src[y1][:, x1] * fx
+        ref = top * (1 - fy)[:, None] + bot * fy[:, None]
+        assert np.abs(got - ref).max() <= 1.0, (h, w, np.abs(got - ref).max())
