@@ -223,7 +223,7 @@ int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, const int64_t* 
  *   loss_scale    d(total_loss)/d(language_model_loss), e.g. the loss weight (and an AMP scale)
  *   dropout_p     0 = deterministic pass.  > 0: GPT-2's four dropout sites of train mode (embedding `drop` :311,
  *                 attn_dropout on the probabilities :116, resid_dropout :178, the MLP's dropout) with a counter-based
- *                 generator: mask = f(dropout_seed, layer*4 + site, element index) (Philox4x32-10: counter = index / 4,
+ *                 generator: mask = f(dropout_seed, layer*4 + site, element index) (Philox4x32-7: counter = index / 4,
  *                 word index % 4), recomputed by the backward pass; torch's generator stream cannot be reproduced, so
  *                 the masks differ from the reference's (rgrg_dropout_mask_f32 exports them for checks).
  *   dropout_seed  a fresh value per call

@@ -16,7 +16,7 @@ c_float_p = C.c_void_p  # device pointers travel as void*
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p
 
 ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
-ABI_VERSION = 15  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
+ABI_VERSION = 16  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
 
 
 class RgrgHipError(RuntimeError):

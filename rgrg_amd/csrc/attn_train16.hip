@@ -48,6 +48,10 @@ __device__ __forceinline__ const u16* kv_row(const u16* qkv16, const u16* ukv16,
                     : qkv16 + ((size_t)s * T + tok - 1) * 3 * D + which * D + hd * 64;
 }
 
+// Element (dim, position) of a transposed image: the 16-byte chunk of the position is XORed with dim / 8 - the eight lanes
+// that transpose one source row write dims 8 ch + j, ch = 0..7, at the SAME position: without the swizzle all eight hit one
+// bank (the row pitch is a multiple of 16 bytes), 74 % of the LDS cycles of the first version were bank conflicts.
+__device__ __forceinline__ int timg(int dim, int pos) { return dim * A16_TP + ((((pos >> 3) ^ (dim >> 3)) << 3) | (pos & 7)); }
 // dst[dim][perm16(idx)] = row[dim] for the 64 dims of `rows` rows (zero beyond nrows): 8 dims per thread step
 template <typename RowFn>
 __device__ __forceinline__ void stage_transposed(u16* dst, int rows_padded, int nrows, RowFn row_ptr) {
@@ -57,7 +61,7 @@ __device__ __forceinline__ void stage_transposed(u16* dst, int rows_padded, int 
         if (idx < nrows) v = *reinterpret_cast<const h16x8*>(row_ptr(idx) + ch * 8);
         const int pos = perm16(idx);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[(ch * 8 + j) * A16_TP + pos] = (u16)v[j];
+        for (int j = 0; j < 8; ++j) dst[timg(ch * 8 + j, pos)] = (u16)v[j];
     }
 }
 
@@ -155,9 +159,8 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const u16* __restrict__
             _Pragma("unroll") for (int e = 0; e < 4; ++e) pv[4 * q + e] = SC_[8 * (U_) + 4 * q + e] * mk[e];              \
         }                                                                                                                 \
         const h16x8 pb = pack8<F16>(pv);                                                                                  \
-        const u16* vt = &VT[col * A16_TP + (KT_) * 32 + (U_) * 16 + half * 8];                                            \
-        o0 = mfma_h<F16>(*reinterpret_cast<const h16x8*>(vt), pb, o0);                                                    \
-        o1 = mfma_h<F16>(*reinterpret_cast<const h16x8*>(vt + 32 * A16_TP), pb, o1);                                      \
+        o0 = mfma_h<F16>(*reinterpret_cast<const h16x8*>(&VT[timg(col, (KT_) * 32 + (U_) * 16 + half * 8)]), pb, o0);      \
+        o1 = mfma_h<F16>(*reinterpret_cast<const h16x8*>(&VT[timg(32 + col, (KT_) * 32 + (U_) * 16 + half * 8)]), pb, o1); \
     }
 #define A16_PV(KT_, SC_)                                                                                                  \
     if ((KT_) < need) { A16_PV_STEP(KT_, SC_, 0) A16_PV_STEP(KT_, SC_, 1) }
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256, 3) void attn16_bwd_kernel(const u16* __restric
                 const h16x8 db8 = pack8<F16>(dsv);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const h16x8 ka = *reinterpret_cast<const h16x8*>(&KT_[(db * 32 + col) * A16_TP + kt * 32 + u * 16 + half * 8]);
+                    const h16x8 ka = *reinterpret_cast<const h16x8*>(&KT_[timg(db * 32 + col, kt * 32 + u * 16 + half * 8)]);
                     dq[db] = mfma_h<F16>(ka, db8, dq[db]);
                 }
             }
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256, 3) void attn16_bwd_kernel(const u16* __restric
                 const h16x8 pb = pack8<F16>(pm), sb = pack8<F16>(dsv);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const int off = (db * 32 + col) * A16_TP + qt * 32 + u * 16 + half * 8;
+                    const int off = timg(db * 32 + col, qt * 32 + u * 16 + half * 8);
                     dv[db] = mfma_h<F16>(*reinterpret_cast<const h16x8*>(&GT_[off]), pb, dv[db]);
                     dk[db] = mfma_h<F16>(*reinterpret_cast<const h16x8*>(&QT_[off]), sb, dk[db]);
                 }

@@ -72,9 +72,9 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // train_full_model.py:172).  Both round to nearest even; fp16 saturates to inf beyond 65504 as torch's does.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned f32_to_bf16_bits(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+    // the hardware conversion (v_cvt_pk_bf16_f32, round to nearest even): one instruction instead of the four of the integer
+    // form (add 0x7fff + lsb, shift) - the 16-bit GEMM epilogues convert 128-256 values per lane
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f);
 }
 __device__ __forceinline__ unsigned f32_to_f16_bits(float f) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)f); }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned h) { return __uint_as_float(h << 16); }
@@ -106,7 +106,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 
-// Counter-based dropout (training pass): Philox4x32-10 keyed by the call's seed, counter = (element index / 4, stream id),
+// Counter-based dropout (training pass): Philox4x32-7 keyed by the call's seed, counter = (element index / 4, stream id),
 // element i takes word i % 4 of its call - a kernel that owns 4 consecutive elements pays ONE generator call for them (round 5:
 // one call per element made the row kernels and the attention kernels generator-bound: ~440 cycles of quarter-rate integer
 // multiplies per wave call).  Every element's mask is a pure function of (seed, stream, index), so the backward pass
@@ -117,11 +117,13 @@ struct DropoutParams {
     float p;          // 0: no dropout (every helper short-circuits)
 };
 struct Philox4 { unsigned w[4]; };
-__host__ __device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsigned stream, unsigned long long ctr) {
+constexpr int DROPOUT_PHILOX_ROUNDS = 7;   // Philox4x32-7: the fewest rounds Random123 reports as passing BigCrush (the sampler
+                                           // keys of det_train.hip, which are pinned against published vectors, keep 10)
+__host__ __device__ __forceinline__ Philox4 philox4x32(unsigned long long seed, unsigned stream, unsigned long long ctr) {
     unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = stream, c3 = 0u;
     unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < DROPOUT_PHILOX_ROUNDS; ++r) {
         const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
         const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
         const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
@@ -137,13 +139,13 @@ __host__ __device__ __forceinline__ float dropout_word_mask(const DropoutParams&
 // masks of the elements 4 * idx4 .. 4 * idx4 + 3
 __host__ __device__ __forceinline__ void dropout_mask4(const DropoutParams& d, unsigned long long idx4, float (&m)[4]) {
     if (d.p <= 0.f) { m[0] = m[1] = m[2] = m[3] = 1.f; return; }
-    const Philox4 w = philox4x32_10(d.seed, d.stream, idx4);
+    const Philox4 w = philox4x32(d.seed, d.stream, idx4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) m[e] = dropout_word_mask(d, w.w[e]);
 }
 __host__ __device__ __forceinline__ float dropout_mask(const DropoutParams& d, unsigned long long idx) {
     if (d.p <= 0.f) return 1.f;
-    const Philox4 w = philox4x32_10(d.seed, d.stream, idx >> 2);
+    const Philox4 w = philox4x32(d.seed, d.stream, idx >> 2);
     const unsigned e = (unsigned)idx & 3u;
     return dropout_word_mask(d, e == 0 ? w.w[0] : e == 1 ? w.w[1] : e == 2 ? w.w[2] : w.w[3]);
 }

@@ -43,6 +43,9 @@ struct GemmLnFold {   // LayerNorm folded around the 16-bit GEMMs (gemm_bf16.hip
     const float* ln_colsum = nullptr;   // consumer: column sums of the gain-scaled rounded weights
     void* Ypre16 = nullptr;             // training pass: 16-bit pre-activation copy next to the activated Y16 (c_fc)
     const void* G16 = nullptr;          // training pass: saved 16-bit pre-activations, result *= gelu_new'(G16) (mlp_proj dgrad)
+    int ksplit = 0;                     // split-K over `ksplit` workgroups per tile with a last-arriver reduce (work space, tickets)
+    float* sk_ws = nullptr;
+    unsigned* sk_cnt = nullptr;
 };
 int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const float* shift, const float* R, float* Y, void* Y16,
                          int M, int N, int K, int ldy, int act, hipStream_t st, int f16, const GemmLnFold* ln = nullptr);
@@ -1509,6 +1512,9 @@ struct rgrg_decoder {
     int bf16_gemms = 0;  // 1 (bf16) / 2 (fp16): 16-bit-weight MFMA GEMMs on the many-sequence path (not bit-exact; opt-in)
     int f16() const { return bf16_gemms == 2 ? 1 : 0; }   // the 16-bit type of that mode
     unsigned short *xn16 = nullptr, *att16 = nullptr, *ff16 = nullptr;  // bf16 activations of that path (GEMM inputs)
+    float* sk_ws = nullptr;     // split-K work space of the N = 1024 projections of the many-sequence decode step (gemm_bf16.hip)
+    unsigned* sk_cnt = nullptr;
+    int sk_attn = 0, sk_mlp = 0; // K slices of attn_proj / mlp_proj there (RGRG_SK_ATTN / RGRG_SK_MLP; 0 or 1 = off)
     float* ln_stat = nullptr;   // [rows][16][2]: per-row (sum, sum of squares) slots (one per 64 columns) of the residual stream (folded LayerNorm)
     bool ln_fold = true;        // 16-bit path: LayerNorms folded into the GEMMs around them; RGRG_LN_FOLD=0: ln_rows launches (A/B)
     int gemm_launches_per_step = 0;
@@ -1650,6 +1656,15 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
             GemmLnFold f = *ln;
             f.ln_colsum = l.cs16;
             return launch_gemm_bf16w_ex(nullptr, X16, l.wb_ln, l.c2_16, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream, d->f16(), &f);
+        }
+        if (ln && ln->Yb16 && d->sk_ws && M <= d->rows) {
+            // a producer of the many-sequence decode step (attn_proj / mlp_proj, N = 1024): split-K with a last-arriver reduce
+            const int ks = l.K >= 2048 ? d->sk_mlp : d->sk_attn;
+            if (ks > 1) {
+                GemmLnFold f = *ln;
+                f.ksplit = ks; f.sk_ws = d->sk_ws; f.sk_cnt = d->sk_cnt;
+                return launch_gemm_bf16w_ex(nullptr, X16, l.wb, l.b, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream, d->f16(), &f);
+            }
         }
         return launch_gemm_bf16w_ex(X16 ? nullptr : X, X16, l.wb, l.b, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream, d->f16(), ln);
     }
@@ -3175,6 +3190,19 @@ static int set_precision_impl(rgrg_decoder* d, int mode) {
                 return RGRG_OK;
             };
             if (!d->ln_stat && (rc2 = dmalloc(d, (void**)&d->ln_stat, (size_t)d->rows * 32 * sizeof(float), true))) return rc2;
+            if (!d->sk_ws) {   // split-K of the two N = 1024 projections: up to 4 slabs of 64 x 64 fp32 per tile + a ticket per tile
+                const size_t tiles = (size_t)((d->rows + 63) / 64) * (d->D / 64);
+                if ((rc2 = dmalloc(d, (void**)&d->sk_ws, tiles * 4 * 4096 * sizeof(float), false)) ||
+                    (rc2 = dmalloc(d, (void**)&d->sk_cnt, tiles * sizeof(unsigned), true)))
+                    return rc2;
+                const char* e1 = getenv("RGRG_SK_MLP");
+                const char* e2 = getenv("RGRG_SK_ATTN");
+                // measured (profiles/r05_splitk_decode_ab.log): the hand-off costs what the shorter K loop saves - off unless asked for
+                d->sk_mlp = e1 ? atoi(e1) : 1;
+                d->sk_attn = e2 ? atoi(e2) : 1;
+                if (d->sk_mlp > 4) d->sk_mlp = 4;
+                if (d->sk_attn > 4) d->sk_attn = 4;
+            }
             for (auto& w : d->layers) {
                 if ((rc2 = mkln(w.c_attn, w.ln1_g, w.ln1_b)) || (rc2 = mkln(w.c_fc, w.ln2_g, w.ln2_b))) return rc2;
             }

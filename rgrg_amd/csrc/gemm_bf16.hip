@@ -26,6 +26,9 @@ struct GemmLnFold {
     const float* ln_colsum = nullptr;
     void* Ypre16 = nullptr;       // training pass: GemmBf16Params::Ypre16 / G16
     const void* G16 = nullptr;
+    int ksplit = 0;               // split-K (GemmBf16Params::ksplit / sk_ws / sk_cnt)
+    float* sk_ws = nullptr;
+    unsigned* sk_cnt = nullptr;
 };
 
 struct GemmBf16Params {
@@ -63,6 +66,14 @@ struct GemmBf16Params {
     // rows fastest inside a column), so the ~64 workgroups an XCD runs at a time form a gm x (64 / gm) block of the tile grid
     // and its L2 serves gm + 64 / gm operand panels instead of 65.  gm >= mtiles (or 0) = one group = column-major order.
     int gm = 0;
+    // split-K (round 5, LDS-DMA kernel, not CONV): ksplit > 1 workgroups share an output tile, each multiplies K / ksplit;
+    // every slice writes its fp32 accumulators to sk_ws [tile][slice][BM x BN], draws a ticket from sk_cnt [tile], and the LAST
+    // arriver adds the slabs in slice order (its own from registers), runs the epilogue and resets the ticket - nobody waits.
+    // For the N = 1024 projections of the many-sequence decode step (240 tiles of 64 x 64 on 256 CUs, a serial K loop of 16-64
+    // tiles at the ~50 GB/s a CU delivers to ONE workgroup): two to four workgroups per CU overlap their K loops.
+    int ksplit = 0;
+    float* sk_ws = nullptr;
+    unsigned* sk_cnt = nullptr;
     int dbg = 0;   // ping-pong kernel, measurements only (RGRG_PP_DBG): 1 no fragment reads, 2 no refill DMAs, 4 no MFMAs, 8 no stores
 };
 
@@ -386,11 +397,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    const int ks = (!CONV && p.ksplit > 1) ? p.ksplit : 1;   // K slices per output tile (consecutive workgroup ids: one XCD)
     int t = blockIdx.x;
     {
-        const int total = mtiles * ntiles, q = total >> 3, r = total & 7, x = t & 7, i = t >> 3;
+        const int total = mtiles * ntiles * ks, q = total >> 3, r = total & 7, x = t & 7, i = t >> 3;
         t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
+    const int slice = t % ks, tile = t / ks;
+    t = tile;
     int tn, tm;
     if (p.gm <= 0 || p.gm >= mtiles) {
         tn = t / mtiles; tm = t - tn * mtiles;
@@ -400,11 +414,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
         tn = r / rows; tm = g * p.gm + (r - tn * rows);
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int nk = p.K / BK;
+    const int nk = p.K / BK / ks;          // K tiles of this slice (the launcher checks divisibility and nk >= NST - 1)
     const int lda = p.lda ? p.lda : p.K, ldw = p.ldw ? p.ldw : p.K;
-    // buffer descriptors are rebased to the tile; CONV: to the zero line in front of the image (offsets are absolute)
-    const u16* abase = CONV ? p.A16 - 128 : p.A16 + (size_t)m0 * lda;
-    const u16* wbase = p.Wb + (size_t)n0 * ldw;
+    // buffer descriptors are rebased to the tile (and to the K slice); CONV: to the zero line in front of the image (offsets are absolute)
+    const u16* abase = CONV ? p.A16 - 128 : p.A16 + (size_t)m0 * lda + (size_t)slice * nk * BK;
+    const u16* wbase = p.Wb + (size_t)n0 * ldw + (size_t)slice * nk * BK;
     // per-lane source offsets (bytes) of this wave's LDS-DMA instructions: lane -> (row = lane / 8, LDS chunk = lane % 8)
     const int lrow = lane >> 3, lch = lane & 7;
     int va[LA], vb[LB];
@@ -535,6 +549,51 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
 #undef RGRG_GLDS_TAIL
 #undef RGRG_GLDS_ISSUE
 #undef RGRG_GLDS_COMPUTE
+
+    if constexpr (!CONV) {
+        if (ks > 1) {
+            // split-K: publish this slice's accumulators with WRITE-THROUGH 16-byte stores (sc1: no release fence - a
+            // `buffer_wbl2` writes back the whole XCD's L2, and 480 workgroups doing that cost more than the K loops they save:
+            // measured +15 us per GEMM), every wave drains, barrier, ONE relaxed agent-scope ticket; all but the last arriver
+            // leave; the last arriver reads the other slabs with sc1 loads (they bypass its L1; the producers stored sc1, so no
+            // acquire fence either - MI355X_MICROARCH.md "valid forms")
+            const __amdgpu_buffer_rsrc_t rs = bf16_rsrc(p.sk_ws + (size_t)tile * ks * (BM * BN));
+            const int soff = slice * (BM * BN * 4);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            __builtin_bit_cast(u32x4, f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]}),
+                            rs, (((mi * NI + ni) * 4 + q) * 256 + tid) * 16, soff, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned* flag = reinterpret_cast<unsigned*>(glds_smem + NST * STAGE + BM * 8);   // behind row_stat, inside the one LDS array
+            if (tid == 0) *flag = __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (*flag != (unsigned)(ks - 1)) return;
+            if (tid == 0) __hip_atomic_store(p.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch (graph replay)
+            // the sum in slice order, this workgroup's own slice from its registers: independent of who arrives last
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+                        for (int sl = 0; sl < ks; ++sl) {
+                            f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (((mi * NI + ni) * 4 + q) * 256 + tid) * 16,
+                                                                                                         sl * (BM * BN * 4), 16));
+                            if (sl == slice) v = f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                            tot += v;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[mi][ni][4 * q + e] = tot[e];
+                    }
+        }
+    }
 
     // folded LayerNorm: (mean, rstd) of the tile's rows -> LDS behind the stages (the last stage may still be read by slower
     // waves), from where the epilogue fetches the 16 rows of its C layout
@@ -1058,7 +1117,9 @@ static int launch_glds_cfg(const GemmBf16Params& p0, hipStream_t st) {
         const int o = gemm_gm_override();
         p.gm = o < 0 ? 0 : o > 0 ? o : (mtiles > 16 ? 8 : 0);
     }
-#define RGRG_G_LAUNCH(CONV_, F16_, LNF_) hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, NST, CONV_, F16_, LNF_>), dim3(mtiles * ntiles), dim3(256), NST * (BM + BN) * 128 + BM * 16, st, p, mtiles, ntiles)
+    const int ks = (!p.cCin && p.ksplit > 1 && p.sk_ws && p.sk_cnt && (p.K / 64) % p.ksplit == 0 && p.K / 64 / p.ksplit >= NST - 1) ? p.ksplit : 1;
+    p.ksplit = ks;
+#define RGRG_G_LAUNCH(CONV_, F16_, LNF_) hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, NST, CONV_, F16_, LNF_>), dim3(mtiles * ntiles * ks), dim3(256), NST * (BM + BN) * 128 + BM * 16, st, p, mtiles, ntiles)
     if (p.cCin) { if (p.f16) RGRG_G_LAUNCH(true, true, 0); else RGRG_G_LAUNCH(true, false, 0); }
     else if (p.Yb16) { if (p.f16) RGRG_G_LAUNCH(false, true, 1); else RGRG_G_LAUNCH(false, false, 1); }
     else if (p.ln_colsum) { if (p.f16) RGRG_G_LAUNCH(false, true, 2); else RGRG_G_LAUNCH(false, false, 2); }
@@ -1097,6 +1158,11 @@ static bool pp_enabled() {
     return v;
 }
 
+static bool pp_lm_head() {   // RGRG_GEMM_PP_LMHEAD=0: keep the decode lm_head on the 128 x 128 kernel (A/B)
+    static const bool v = [] { const char* e = getenv("RGRG_GEMM_PP_LMHEAD"); return !e || atoi(e) != 0; }();
+    return v;
+}
+
 // tile = shape + 16 * stages; shape: 0 = heuristic, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 256x256 ping-pong;
 // stages: 0 (= 4), 2, 3, 4
 // (tools/gemm_bf16_bench.py measures them).  Heuristic from the COLD-weights table at M = 923
@@ -1119,6 +1185,9 @@ static int launch_glds(const GemmBf16Params& p, int tile, hipStream_t st) {
         // alternative (the M = 923 decode shapes keep their tuned tiles)
         const long tiles_pp = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         if (p.M >= 2048 && tiles_pp >= 192) return launch_pp(p, st);
+        // the vocabulary-sized lm_head of a many-sequence decode step (923 rows x 50 257 columns: 4 x 197 tiles): 160 us against
+        // 173 us on 128 x 128 tiles (profiles/r05_gemm_big_fc6_v1.log)
+        if (p.M >= 512 && p.N >= 32768 && tiles_pp >= 512 && pp_lm_head()) return launch_pp(p, st);
     }
     if (shape == 0) {
         const long tiles_big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
@@ -1154,7 +1223,7 @@ int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const 
         RGRG_CHECK_ARG(A16 && (size_t)128 * K * 2 < ((size_t)1 << 31) && !ln->Yb16 && !ln->ln_colsum);
         RGRG_CHECK_ARG(!(ln->Ypre16 && ln->G16) && (!ln->G16 || (!R && act == RGRG_ACT_NONE)));
         p.Ypre16 = reinterpret_cast<u16*>(ln->Ypre16); p.G16 = reinterpret_cast<const u16*>(ln->G16);
-    } else if (ln) {   // LayerNorm folded around the GEMM (GemmBf16Params): LDS-DMA kernel only
+    } else if (ln && (ln->Yb16 || ln->ln_colsum)) {   // LayerNorm folded around the GEMM (GemmBf16Params): LDS-DMA kernel only
         RGRG_CHECK_ARG(A16 && (size_t)128 * K * 2 < ((size_t)1 << 31));
         RGRG_CHECK_ARG((ln->Yb16 != nullptr) != (ln->ln_colsum != nullptr));
         RGRG_CHECK_ARG(!ln->Yb16 || (Y && ln->stats_out && N == 1024));
@@ -1162,6 +1231,7 @@ int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const 
         p.Yb16 = reinterpret_cast<u16*>(ln->Yb16); p.stats_out = ln->stats_out;
         p.ln_stats = ln->ln_stats; p.ln_colsum = ln->ln_colsum;
     }
+    if (ln && ln->ksplit > 1) { p.ksplit = ln->ksplit; p.sk_ws = ln->sk_ws; p.sk_cnt = ln->sk_cnt; }   // split-K (LDS-DMA kernel)
     if (A16 && (size_t)128 * K * 2 < ((size_t)1 << 31)) return launch_glds(p, 0, st);  // both operands bf16: LDS-DMA kernel
     // fp32 activations (rounded to bf16 while they are staged through registers)
     const long tiles_big = (long)((M + 127) / 128) * ((N + 127) / 128);

@@ -192,3 +192,40 @@ def test_configs2_full_size_properties_batch32_bf16():
     L = max(ids.shape[1], ids_p.shape[1])
     pad = lambda t: torch.nn.functional.pad(t, (0, L - t.shape[1]), value=50256)  # noqa: E731
     assert torch.equal(pad(ids)[rows], pad(ids_p))
+
+
+def test_opt_in_split_k_of_the_decode_projections_matches_the_default_path():
+    """VERDICT r04 item 1a was built and measured slower (profiles/r05_splitk_decode_ab.log), so it is opt-in: RGRG_SK_MLP /
+    RGRG_SK_ATTN = K slices per tile of mlp_proj / attn_proj in the many-sequence 16-bit decode step (write-through slabs, one
+    ticket per tile, the last arriver adds the slabs in slice order and runs the LayerNorm-producer epilogue).  Read once per
+    process -> child processes: 200 sequences x 10 tokens under bf16 autocast, 2 / 4 slices against the unsplit kernels - the
+    sums are re-associated, which a 16-bit evaluation amplifies to its quantisation-noise level within a few layers:
+    last-step logits within 2e-2 of their range, >= 90 % identical token ids - the bounds of the 16-bit parity tests."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import gpu_model\n"
+        "m = gpu_model('ragged'); g = torch.Generator().manual_seed(9)\n"
+        "feats = torch.randn((200, 1024), generator=g).cuda()\n"
+        "eng = m.engine()\n"
+        "ids = eng.greedy_decode(feats, 10, bf16=1)\n"
+        "lg = eng.last_logits(200)\n"
+        "torch.save((ids.cpu(), lg.cpu()), sys.argv[1])\n" % (repo, os.path.join(repo, "tests")))
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, env_add in (("off", {}), ("mlp2", {"RGRG_SK_MLP": "2", "RGRG_SK_ATTN": "2"}), ("mlp4", {"RGRG_SK_MLP": "4"})):
+            path = os.path.join(tmp, name + ".pt")
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env_add), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[name] = torch.load(path)
+    ids0, lg0 = res["off"]
+    span = lg0.abs().max().item()
+    for name in ("mlp2", "mlp4"):
+        ids1, lg1 = res[name]
+        assert ids1.shape == ids0.shape
+        assert (lg1 - lg0).abs().max().item() <= 2e-2 * span, name
+        assert (ids1 == ids0).float().mean().item() >= 0.90, name
