@@ -43,7 +43,7 @@ def pmc_traffic(family, S_dec, dtype):
     detector finds on the synthetic batch moves by one or two between builds).  -> (bytes per launch, "file:key") or
     (None, None) when there is none: the quoted number always names the profile it comes from."""
     import re
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # newest committed measurement that has the key
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # newest committed measurement that has the key
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 table = json.load(f)

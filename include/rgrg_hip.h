@@ -332,6 +332,11 @@ int rgrg_debug_linear_bf16_tile(const uint16_t* A16, const uint16_t* Wb, const f
 int rgrg_debug_linear_bf16_train(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
                                  uint16_t* Y16, uint16_t* Ypre16, const uint16_t* G16, int M, int N, int K, int ldy, int act,
                                  int tile, int fp16, void* stream);
+/* Test hook for the greedy lm_head of the many-sequence 16-bit decode step (src/language_model/language_model.py:420-428:
+ * next_token_logits.argmax(-1)): the 256 x 256 GEMM leaves, per row and 256-column tile, the maximum of A16 Wb^T + shift and
+ * its column (first maximum wins, like torch.argmax) in cand_val / cand_idx [M][ceil(N / 256)] instead of the logits. */
+int rgrg_debug_linear_bf16_argmax(const uint16_t* A16, const uint16_t* Wb, const float* shift, int M, int N, int K,
+                                  float* cand_val, int* cand_idx, int fp16, void* stream);
 /* Test hooks for the LayerNorm folded around the 16-bit decode GEMMs (transformers GPT2Block: ln_1 -> c_attn, ln_2 -> c_fc;
  * src/language_model/language_model.py:338-366 runs them as separate modules).  rgrg_debug_ln_fold16: wb[n][k] =
  * round16(gain[k] w[n][k]), colsum[n] = sum_k wb[n][k] (of the ROUNDED values), shift[n] = bias[n] + sum_k beta[k] w[n][k].

@@ -16,7 +16,7 @@ c_float_p = C.c_void_p  # device pointers travel as void*
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p
 
 ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
-ABI_VERSION = 16  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
+ABI_VERSION = 17  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
 
 
 class RgrgHipError(RuntimeError):
@@ -78,6 +78,7 @@ SIGNATURES = {
     "rgrg_linear_bf16_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "rgrg_debug_linear_bf16_tile": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rgrg_debug_linear_bf16_train": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "rgrg_debug_linear_bf16_argmax": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i, _p]),
     "rgrg_debug_ln_fold16": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "rgrg_debug_linear_bf16_ln": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "rgrg_decoder_copy_last_logits": (_i, [_p, _p, _i, _p]),

@@ -46,7 +46,10 @@ struct GemmLnFold {   // LayerNorm folded around the 16-bit GEMMs (gemm_bf16.hip
     int ksplit = 0;                     // split-K over `ksplit` workgroups per tile with a last-arriver reduce (work space, tickets)
     float* sk_ws = nullptr;
     unsigned* sk_cnt = nullptr;
+    float* cand_val = nullptr;          // 256 x 256 kernel: per-row (maximum, column) of every column tile instead of Y (greedy lm_head)
+    int* cand_idx = nullptr;
 };
+bool gemm_bf16_cand_epilogue_ok(int M, int N, int K);   // would launch_gemm_bf16w_ex pick the 256 x 256 kernel for this lm_head?
 int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const float* shift, const float* R, float* Y, void* Y16,
                          int M, int N, int K, int ldy, int act, hipStream_t st, int f16, const GemmLnFold* ln = nullptr);
 int launch_gemm_bf16w(const float* A, const void* Wb, const float* shift, const float* R, float* Y, int M, int N, int K,
@@ -500,9 +503,12 @@ template <bool HAS_SRC, int ATT_NI>  // HAS_SRC (beam search): per-slot ancestor
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                           float* __restrict__ kc, float* __restrict__ vc,
                                                           const int* __restrict__ step, float* __restrict__ out,
-                                                          int S, int H, int T, const int* __restrict__ src, int frag_out) {
+                                                          int S, int H, int T, const int* __restrict__ src, int frag_out,
+                                                          unsigned long long* __restrict__ stamps) {   // stamps: -DRGRG_SKINNY_STAMPS builds, else null
     __shared__ float pm[16], pl[16];
     __shared__ __attribute__((aligned(16))) float pacc[16][64];
+    SKS_DECL;
+    SKS(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = blockIdx.x / H, hd = blockIdx.x - s * H;
     const int t = *step, nkeys = t + 2, slot = t + 1;
@@ -537,6 +543,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
         for (int base = 0; base < nkeys; base += ATT_CHUNK) ATT_CHUNK_CALL(ATT_NI, base);
     }
 #undef ATT_CHUNK_CALL
+    SKS(1);   // stamp 1 (after a read of the running sums: the chunk's loads have landed and its arithmetic is issued)
     if (wave == 0 && g == 0) {
         *reinterpret_cast<f32x4*>(kc + (((size_t)s * H + hd) * T + slot) * 64 + d4 * 4) = k4;
         *reinterpret_cast<f32x4*>(vc + (((size_t)s * H + hd) * T + slot) * 64 + d4 * 4) = v4;
@@ -544,7 +551,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     const int grp = wave * 4 + g;
     if (d4 == 0) { pm[grp] = m; pl[grp] = l; }
     *reinterpret_cast<f32x4*>(&pacc[grp][d4 * 4]) = acc;
+    SKS(3);   // stamp 3: wave 0's partial sums written to LDS (depends on every key of the wave)
     __syncthreads();
+    SKS(4);
     if (threadIdx.x < 64) {
         float M = pm[0];
 #pragma unroll
@@ -559,6 +568,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
         // fused plan: the attention output is attn_proj's A operand -> fragment-major (skinny_direct.inc)
         out[frag_out ? frag_off(s, hd * 64 + threadIdx.x, D) : (size_t)s * D + hd * 64 + threadIdx.x] = o / L;
     }
+    SKS(5);
+    SKS_FLUSH(stamps, blockIdx.x);
 }
 
 // bf16 helpers for the opt-in bf16 K/V cache (torch.autocast(bf16) in the reference makes c_attn's output,
@@ -1529,6 +1540,14 @@ struct rgrg_decoder {
     std::vector<PkLayer> pk_layers;   // per-layer pointer table (copied into the kernel arguments)
     unsigned* pk_bar = nullptr;     // barrier state (persistent.inc), zeroed at creation
     unsigned long long* pk_dbg = nullptr;   // RGRG_PK_TRACE=<file>: cycle stamps of the last persistent launch, dumped at destruction
+    // -DRGRG_SKINNY_STAMPS builds + RGRG_SKINNY_TRACE=<file> (tools/skinny_stamps.py): phase stamps of every launch of the last
+    // fused decode step, [launch slot][workgroup][8]; null in the product build
+    // > 0: the last greedy generate ran the lm_head with the arg-max epilogue for this many rows - d->logits was not written;
+    // rgrg_decoder_copy_last_logits recomputes it from the retained ln_f output (xn16) before copying
+    int logits_stale_rows = 0;
+    unsigned long long* sk_stamps = nullptr;
+    int sk_stamp_next = 0;
+    std::vector<std::pair<const char*, int>> sk_stamp_meta;   // (kernel, workgroups) per slot
 };
 
 namespace rgrg {
@@ -1623,6 +1642,15 @@ static int init_skinny_attrs() {
 // number of token rows of the decode steps (sequences x beams), the same for every launch of one generate call.
 static bool kv_is_bf16(const rgrg_decoder* d, int rows) { return d->bf16_gemms && rows > skinny_max_rows(); }
 
+// Measurement builds: the stamp block of the next launch of the fused decode step (null in the product build / without
+// RGRG_SKINNY_TRACE).  The pointers are baked into the captured graph, so a dump holds the LAST replayed step.
+constexpr int SK_STAMP_SLOTS = 128, SK_STAMP_WGS = 512;
+static unsigned long long* stamp_slot(rgrg_decoder* d, const char* kernel, int wgs) {
+    if (!d->sk_stamps || d->sk_stamp_next >= SK_STAMP_SLOTS || wgs > SK_STAMP_WGS) return nullptr;
+    d->sk_stamp_meta.emplace_back(kernel, wgs);
+    return d->sk_stamps + (size_t)(d->sk_stamp_next++) * SK_STAMP_WGS * 8;
+}
+
 // Y[:M] = act(X W^T + b + R).  Prefill GEMMs (packed, <= 128 rows): LDS-staged weight-streaming kernel (+ a small
 // reduce kernel when the layer splits K over workgroups); everything else: tiled MFMA GEMM (fp32, or the bf16-weight
 // kernel in the opt-in bf16 mode, optionally with bf16 activations in / out).
@@ -1673,6 +1701,12 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
 }
 
 
+// Greedy many-sequence step in 16-bit mode: the lm_head leaves per-tile arg-max candidates instead of logits (gemm_bf16.hip)
+static bool lm_head_cand_path(const rgrg_decoder* d, int S) {
+    return S > skinny_max_rows() && kv_is_bf16(d, S) && d->xn16 && d->lm_head.wb && d->lm_head.K % 256 == 0 &&
+           gemm_bf16_cand_epilogue_ok(S, d->lm_head.N, d->lm_head.K);
+}
+
 static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsigned short* att16, int frag_out = 0) {
     hipStream_t st = d->stream;
     const int D = d->D;
@@ -1695,7 +1729,8 @@ static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsig
 #undef KV16_LAUNCH
     } else {
         const dim3 grid(S * d->H), blk(256);
-#define ATT_LAUNCH(SRC_, NI_) hipLaunchKernelGGL((attn_decode_kernel<SRC_, NI_>), grid, blk, 0, st, d->qkv, 3 * D, kc, vc, d->step, d->att, S, d->H, d->T, src, frag_out)
+#define ATT_LAUNCH(SRC_, NI_) hipLaunchKernelGGL((attn_decode_kernel<SRC_, NI_>), grid, blk, 0, st, d->qkv, 3 * D, kc, vc, d->step, d->att, S, d->H, d->T, src, frag_out, \
+                                                 stamp_slot(d, "attention", S * d->H))
         if (S * d->H <= 4096) { if (src) ATT_LAUNCH(true, 9); else ATT_LAUNCH(false, 9); }
         else { if (src) ATT_LAUNCH(true, 2); else ATT_LAUNCH(false, 2); }
 #undef ATT_LAUNCH
@@ -1716,11 +1751,14 @@ static int direct_linear(rgrg_decoder* d, const Lin& l, DirectArgs a, int mode, 
     const dim3 grid(l.NT, l.KS), blk(64 * SK_WAVES);
     hipStream_t st = d->stream;
     if (l.lnf && mode == DX_COMBINE4 && l.NT > 512 && mt == 1 && l.K == DK_SLICE) {  // lm_head, one row tile: a wave per column tile
+        a.stamps = stamp_slot(d, "lm_head'", 256);
         hipLaunchKernelGGL((rgrg_lm_head_wave_f32<DX_COMBINE4>), dim3(256), blk, LMH_LDS, st, a);
     } else if (!l.lnf && mode == DX_PLAIN && l.KS == 1 && mt == 1 && l.NT <= 64 && M > 16 && !cand) {
         // attn_proj': few column tiles, MFMA bound -> one row half per workgroup (2 x NT workgroups)
+        a.stamps = stamp_slot(d, "attn_proj'", l.NT * 2);
         hipLaunchKernelGGL(rgrg_skinny_direct_half_f32, dim3(l.NT, 2), blk, 0, st, a);
     } else {
+        a.stamps = stamp_slot(d, l.N == 3 * d->D ? "c_attn'" : l.KS > 1 ? "mlp_proj" : l.N == 4 * d->D ? "c_fc'" : "skinny_direct", l.NT * l.KS);
 #define DX_LAUNCH(MT_, MODE_, LNF_) hipLaunchKernelGGL((rgrg_skinny_direct_f32<MT_, MODE_, LNF_>), grid, blk, 0, st, a)
 #define DX_MODES(MT_)                                                                        \
     do {                                                                                     \
@@ -1819,6 +1857,7 @@ static void pk_count(rgrg_decoder* d, int S, const Lin& l) {   // bookkeeping of
 // The residual stream ping-pongs between d->x and d->x2; x, att, ff and the partial sums are fragment-major.
 static int enqueue_step_fused(rgrg_decoder* d, int S, bool count, const int* tok_override, const int* src, bool beam) {
     if (count) { d->gemm_bytes_per_step = 0; d->gemm_flops_per_step = 0.0; d->gemm_launches_per_step = 0; }
+    d->sk_stamp_next = 0; d->sk_stamp_meta.clear();
     hipStream_t st = d->stream;
     int rc;
     float* cur = d->x;
@@ -1930,6 +1969,16 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
             hipLaunchKernelGGL(ln_rows_kernel, dim3((S + 3) / 4), dim3(256), 0, st, d->x, ng, nb, d->xn, D, xn16, d->f16(), S);
             RGRG_LAUNCH_CHECK();
         }
+    }
+    if (!beam && xn16 && lm_head_cand_path(d, S)) {
+        // greedy: the 256 x 256 lm_head leaves one (maximum, column) pair per row and column tile; no logits, no candidates pass
+        GemmLnFold ce{};
+        ce.cand_val = d->cand_val; ce.cand_idx = d->cand_idx;
+        if ((rc = linear(d, d->lm_head, d->xn, nullptr, nullptr, S, d->ld_logits, RGRG_ACT_NONE, count, xn16, nullptr, &ce))) return rc;
+        hipLaunchKernelGGL(argmax_update_kernel, dim3(S), dim3(256), 0, st, d->cand_val, d->cand_idx, (d->lm_head.N + 255) / 256, d->ids,
+                           d->max_len, d->finished, d->step, d->done_len, d->sync, S);
+        RGRG_LAUNCH_CHECK();
+        return RGRG_OK;
     }
     if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, xn16))) return rc;
     if (beam) return RGRG_OK;  // the caller ranks the logits (beam_row_topk / beam_merge)
@@ -2094,6 +2143,10 @@ extern "C" int rgrg_decoder_create_with_cache(const rgrg_decoder_weights* w, int
         d->pk_mode = 0;
         if (const char* e = getenv("RGRG_PERSISTENT")) d->pk_mode = atoi(e);
         if (getenv("RGRG_PK_TRACE")) TRY(dmalloc(d, (void**)&d->pk_dbg, (size_t)PK_WGS * 64 * sizeof(unsigned long long), true));
+#ifdef RGRG_SKINNY_STAMPS
+        if (getenv("RGRG_SKINNY_TRACE"))
+            TRY(dmalloc(d, (void**)&d->sk_stamps, (size_t)SK_STAMP_SLOTS * SK_STAMP_WGS * 8 * sizeof(unsigned long long), true));
+#endif
         // one workgroup per CU, all resident: needs the 256 CUs of an MI355X and a D = 1024 / 16-head model
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < PK_WGS ||
             d->D != DK_SLICE || d->H != 16)
@@ -2129,6 +2182,23 @@ extern "C" void rgrg_decoder_destroy(rgrg_decoder* d) {
             if (hipDeviceSynchronize() == hipSuccess &&
                 hipMemcpy(h.data(), d->pk_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
                 if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+            }
+        }
+    }
+    if (d->sk_stamps) {   // measurement builds (tools/skinny_stamps.py): text dump, one line per workgroup of every launch slot
+        const char* path = getenv("RGRG_SKINNY_TRACE");
+        std::vector<unsigned long long> h((size_t)SK_STAMP_SLOTS * SK_STAMP_WGS * 8);
+        if (path && hipDeviceSynchronize() == hipSuccess &&
+            hipMemcpy(h.data(), d->sk_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE* f = fopen(path, "w")) {
+                for (size_t sl = 0; sl < d->sk_stamp_meta.size(); ++sl) {
+                    fprintf(f, "slot %zu %s %d\n", sl, d->sk_stamp_meta[sl].first, d->sk_stamp_meta[sl].second);
+                    for (int w = 0; w < d->sk_stamp_meta[sl].second; ++w) {
+                        const unsigned long long* r = h.data() + (sl * SK_STAMP_WGS + w) * 8;
+                        fprintf(f, "%llu %llu %llu %llu %llu %llu %llu %llu\n", r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+                    }
+                }
+                fclose(f);
             }
         }
     }
@@ -2215,6 +2285,7 @@ extern "C" int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S,
     }
     done = *d->h_done;
     *out_len = (done > 0 && done < limit) ? done : limit;
+    d->logits_stale_rows = lm_head_cand_path(d, S) ? S : 0;
     return RGRG_OK;
 }
 
@@ -2280,6 +2351,7 @@ extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int
     int cur_len = 1;
     std::vector<float> nscore(R);
     std::vector<int> ntok(R), nidx(R);
+    d->logits_stale_rows = 0;   // beam steps write d->logits
     while (true) {
         RGRG_HIP(hipMemcpyAsync(d->beam_tok, beam_tok.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
         RGRG_HIP(hipMemcpyAsync(d->beam_scores, beam_scores.data(), R * sizeof(float), hipMemcpyHostToDevice, st));
@@ -3052,6 +3124,7 @@ extern "C" int rgrg_decoder_forward_cached(rgrg_decoder* d, const float* feats, 
     RGRG_HIP(hipEventRecord(d->ev_in, caller));
     RGRG_HIP(hipStreamWaitEvent(st, d->ev_in, 0));
     int rc;
+    d->logits_stale_rows = 0;   // every step below writes d->logits
     if (past_len == 0 && feats && (rc = enqueue_prefill(d, feats, S))) return rc;   // also resets the step counter to 0
     for (int j = 0; j < T; ++j) {
         hipLaunchKernelGGL(forward_cached_tokens_kernel, dim3((S + 255) / 256), dim3(256), 0, st,
@@ -3217,6 +3290,14 @@ static int set_precision_impl(rgrg_decoder* d, int mode) {
 
 extern "C" int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S, void* stream) {
     RGRG_CHECK_ARG(d && dst && S > 0 && S <= d->max_seqs);
+    if (d->logits_stale_rows > 0) {   // the greedy step kept only arg-max candidates: the logits of its last step from the retained ln_f rows
+        const int rows = d->logits_stale_rows;
+        RGRG_CHECK_ARG(S <= rows);
+        int rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, rows, d->ld_logits, RGRG_ACT_NONE, false, d->xn16);
+        if (rc) return rc;
+        RGRG_HIP(hipStreamSynchronize(d->stream));
+        d->logits_stale_rows = 0;
+    }
     RGRG_HIP(hipMemcpy2DAsync(dst, (size_t)d->V * 4, d->logits, (size_t)d->ld_logits * 4, (size_t)d->V * 4, S,
                               hipMemcpyDeviceToDevice, as_stream(stream)));
     RGRG_HIP(hipStreamSynchronize(as_stream(stream)));
@@ -3275,7 +3356,13 @@ extern "C" int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, i
             h.Xf = d->x; h.part = d->part; h.Y = d->logits; h.ldy = d->ld_logits; h.act = RGRG_ACT_NONE;
             rc = direct_linear(d, d->lm_head, h, DX_COMBINE4, S, c, true);
         } else if (!rc) {
-            rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, c, xn16);
+            if (xn16 && lm_head_cand_path(d, S)) {   // as the greedy step launches it: arg-max epilogue, no logits
+                GemmLnFold ce{};
+                ce.cand_val = d->cand_val; ce.cand_idx = d->cand_idx;
+                rc = linear(d, d->lm_head, d->xn, nullptr, nullptr, S, d->ld_logits, RGRG_ACT_NONE, c, xn16, nullptr, &ce);
+            } else {
+                rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, c, xn16);
+            }
         }
     }
     if (!rc) {

@@ -29,6 +29,8 @@ struct GemmLnFold {
     int ksplit = 0;               // split-K (GemmBf16Params::ksplit / sk_ws / sk_cnt)
     float* sk_ws = nullptr;
     unsigned* sk_cnt = nullptr;
+    float* cand_val = nullptr;    // arg-max candidates instead of Y (GemmBf16Params::cand_val / cand_idx)
+    int* cand_idx = nullptr;
 };
 
 struct GemmBf16Params {
@@ -74,6 +76,12 @@ struct GemmBf16Params {
     int ksplit = 0;
     float* sk_ws = nullptr;
     unsigned* sk_cnt = nullptr;
+    // ping-pong kernel, greedy decoding (lm_head of the many-sequence step): instead of storing the 256 x 256 block of logits a
+    // workgroup leaves ONE (maximum, column) pair per row - first maximum wins, like torch.argmax - in cand_val / cand_idx
+    // [M][ntiles]; argmax_update_kernel picks the row's token from the ceil(N / 256) candidates.  The 186 MB of fp32 logits per
+    // step (923 x 50 257) are neither written nor re-read.  Y may be null.
+    float* cand_val = nullptr;
+    int* cand_idx = nullptr;
     int dbg = 0;   // ping-pong kernel, measurements only (RGRG_PP_DBG): 1 no fragment reads, 2 no refill DMAs, 4 no MFMAs, 8 no stores
 };
 
@@ -981,6 +989,72 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmBf16Params 
         if (z == 12345.678f) p.Y[0] = z;
         return;
     }
+    if (p.cand_val) {
+        // Row arg-max of the block.  A lane holds, per 32-row block mi, 16 rows x 2 columns (ni): combine the two columns, then a
+        // butterfly over the 32 lanes of its half that HALVES the rows a lane carries at every step (lane ^ 16: rows 0-7 stay in
+        // the lower lane, 8-15 in the upper one, ...): 8 + 4 + 2 + 1 + 1 exchanges per block instead of 16 x 5.  Ties keep the
+        // lower column (explicit index compare), columns >= N are -inf.  The four column quarters (waves) of a row meet in LDS.
+        __syncthreads();   // every wave is done with the operand stages: the LDS is reused below
+        float* cv = reinterpret_cast<float*>(pp_smem);            // [2 groups][4 quarters][128 rows]
+        int* ci = reinterpret_cast<int*>(pp_smem + 4096);
+        const int ccol = lane & 31;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float bv[16];
+            int bi[16];
+            const int c0 = n0 + wq * 64 + ccol, c1 = c0 + 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v0 = c0 < p.N ? acc[mi][0][r] + esh[0] : -INFINITY;
+                const float v1 = c1 < p.N ? acc[mi][1][r] + esh[1] : -INFINITY;
+                const bool hi = v1 > v0;
+                bv[r] = hi ? v1 : v0;
+                bi[r] = hi ? c1 : c0;
+            }
+#define PP_CAND_STEP(CNT_, XOR_)                                                                   \
+    {                                                                                              \
+        const bool up = (lane & (XOR_)) != 0;                                                      \
+        _Pragma("unroll") for (int j = 0; j < (CNT_); ++j) {                                       \
+            const float keep_v = up ? bv[j + (CNT_)] : bv[j], send_v = up ? bv[j] : bv[j + (CNT_)]; \
+            const int keep_i = up ? bi[j + (CNT_)] : bi[j], send_i = up ? bi[j] : bi[j + (CNT_)];   \
+            const float ov = __shfl_xor(send_v, (XOR_), 64);                                       \
+            const int oi = __shfl_xor(send_i, (XOR_), 64);                                         \
+            const bool take = ov > keep_v || (ov == keep_v && oi < keep_i);                        \
+            bv[j] = take ? ov : keep_v;                                                            \
+            bi[j] = take ? oi : keep_i;                                                            \
+        }                                                                                          \
+    }
+            PP_CAND_STEP(8, 16) PP_CAND_STEP(4, 8) PP_CAND_STEP(2, 4) PP_CAND_STEP(1, 2)
+#undef PP_CAND_STEP
+            {
+                const float ov = __shfl_xor(bv[0], 1, 64);
+                const int oi = __shfl_xor(bi[0], 1, 64);
+                if (ov > bv[0] || (ov == bv[0] && oi < bi[0])) { bv[0] = ov; bi[0] = oi; }
+            }
+            if ((lane & 1) == 0) {   // the register this lane ended up with: r = bit4 * 8 + bit3 * 4 + bit2 * 2 + bit1 of its lane id
+                const int r = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+                const int lrow_t = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);   // row inside the group's 128
+                cv[(g * 4 + wq) * 128 + lrow_t] = bv[0];
+                ci[(g * 4 + wq) * 128 + lrow_t] = bi[0];
+            }
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int gg = tid >> 7, lr = tid & 127, row = m0 + tid;
+            float best = cv[(gg * 4) * 128 + lr];
+            int idx = ci[(gg * 4) * 128 + lr];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {   // ascending columns: a strict compare keeps the first maximum
+                const float v = cv[(gg * 4 + q) * 128 + lr];
+                if (v > best) { best = v; idx = ci[(gg * 4 + q) * 128 + lr]; }
+            }
+            if (row < p.M) {
+                p.cand_val[(size_t)row * ntiles + tn] = best;
+                p.cand_idx[(size_t)row * ntiles + tn] = idx;
+            }
+        }
+        return;
+    }
     // epilogue straight from the C layout of the 32x32 MFMA (register r of block (mi, ni) = column lane & 31, row
     // (r & 3) + 8 (r >> 2) + 4 (lane >> 5)): a store instruction writes two rows x 128 contiguous bytes (fp32).  Measured
     // against two alternatives on the store-heavy shapes (c_attn / lm_head at 14 848 rows: 182 MB / 3 GB of fp32 output,
@@ -1212,10 +1286,18 @@ static int launch_glds(const GemmBf16Params& p, int tile, hipStream_t st) {
     return RGRG_EINVAL;
 }
 
+// The greedy lm_head of the many-sequence decode step: is this the shape launch_glds sends to the 256 x 256 kernel (whose
+// epilogue can leave arg-max candidates instead of logits)?  RGRG_LMHEAD_CAND=0: keep the logits + candidates pass (A/B runs).
+bool gemm_bf16_cand_epilogue_ok(int M, int N, int K) {
+    static const bool on = [] { const char* e = getenv("RGRG_LMHEAD_CAND"); return !e || atoi(e) != 0; }();
+    const long tiles_pp = (long)((M + 255) / 256) * ((N + 255) / 256);
+    return on && pp_enabled() && pp_lm_head() && M >= 512 && N >= 32768 && tiles_pp >= 512 && K >= 256 && K % 64 == 0;
+}
+
 // A16 / Y16 (either may be null): bf16 activations in / out, see GemmBf16Params
 int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const float* shift, const float* R, float* Y, void* Y16,
                          int M, int N, int K, int ldy, int act, hipStream_t st, int f16, const GemmLnFold* ln) {
-    RGRG_CHECK_ARG((A || A16) && Wb && (Y || Y16) && M > 0 && N > 0 && K > 0 && K % (4 * BK16) == 0 && ldy >= N);  // 4 = depth NS
+    RGRG_CHECK_ARG((A || A16) && Wb && (Y || Y16 || (ln && ln->cand_val)) && M > 0 && N > 0 && K > 0 && K % (4 * BK16) == 0 && ldy >= N);  // 4 = depth NS
     GemmBf16Params p{A, reinterpret_cast<const u16*>(A16), reinterpret_cast<const u16*>(Wb), shift, R, Y,
                      reinterpret_cast<u16*>(Y16), M, N, K, ldy, act};
     p.f16 = f16 ? 1 : 0;
@@ -1232,6 +1314,11 @@ int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const 
         p.ln_stats = ln->ln_stats; p.ln_colsum = ln->ln_colsum;
     }
     if (ln && ln->ksplit > 1) { p.ksplit = ln->ksplit; p.sk_ws = ln->sk_ws; p.sk_cnt = ln->sk_cnt; }   // split-K (LDS-DMA kernel)
+    if (ln && ln->cand_val) {   // arg-max candidates instead of logits: 256 x 256 ping-pong kernel only
+        RGRG_CHECK_ARG(A16 && ln->cand_idx && !R && act == RGRG_ACT_NONE && !Y16 && !ln->Yb16 && !ln->ln_colsum && !ln->Ypre16 && !ln->G16);
+        p.cand_val = ln->cand_val; p.cand_idx = ln->cand_idx;
+        return launch_glds(p, 5, st);
+    }
     if (A16 && (size_t)128 * K * 2 < ((size_t)1 << 31)) return launch_glds(p, 0, st);  // both operands bf16: LDS-DMA kernel
     // fp32 activations (rounded to bf16 while they are staged through registers)
     const long tiles_big = (long)((M + 127) / 128) * ((N + 127) / 128);
@@ -1311,6 +1398,18 @@ extern "C" int rgrg_debug_linear_bf16_train(const uint16_t* A16, const uint16_t*
     p.f16 = fp16 ? 1 : 0;
     p.Ypre16 = Ypre16; p.G16 = G16;
     return launch_glds(p, tile, as_stream(stream));
+}
+
+// Test hook for the arg-max epilogue of the 256 x 256 kernel (the greedy lm_head of the many-sequence decode step):
+// cand_val / cand_idx [M][ceil(N / 256)] = per row and 256-column tile the maximum of A16 Wb^T + shift and its column.
+extern "C" int rgrg_debug_linear_bf16_argmax(const uint16_t* A16, const uint16_t* Wb, const float* shift, int M, int N, int K,
+                                             float* cand_val, int* cand_idx, int fp16, void* stream) {
+    int rc = init_gemm_bf16_attrs();
+    if (rc) return rc;
+    RGRG_CHECK_ARG(A16 && Wb && cand_val && cand_idx && M > 0 && N > 0 && K >= 256 && K % 256 == 0);
+    GemmLnFold f{};
+    f.cand_val = cand_val; f.cand_idx = cand_idx;
+    return launch_gemm_bf16w_ex(nullptr, A16, Wb, shift, nullptr, nullptr, nullptr, M, N, K, N, RGRG_ACT_NONE, as_stream(stream), fp16, &f);
 }
 
 // Test hook for the LayerNorm-folded variants of the LDS-DMA kernel (the decoder uses them internally, decoder.hip

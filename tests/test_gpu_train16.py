@@ -210,3 +210,47 @@ def test_configs4_shape_partition_property_and_oracle_subset():
     assert abs(lA - o_loss.item()) <= 3e-2
     _compare({k: v.cpu() for k, v in gA.items()}, o_grads, 0.99, 0.03)
     m.invalidate_engine()
+
+
+@pytest.mark.parametrize("fp16", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(923, 50257, 1024), (300, 1000, 256), (513, 257, 512)])
+def test_pingpong_gemm_argmax_epilogue(M, N, K, fp16):
+    """The greedy lm_head of the many-sequence decode step (language_model.py:420-428 `argmax(-1)`): the 256 x 256 kernel leaves
+    per row and 256-column tile the maximum and its column instead of the logits.  Against the SAME kernel's logits (tile 5,
+    fp32 output): values bit-identical, columns = torch.argmax per tile - including exact ties (duplicated weight rows inside a
+    tile, across the lane halves / column quarters / tiles: the first maximum must win), ragged last row and column tiles."""
+    lib = _hip.load()
+    t16 = T16[fp16]
+    g = torch.Generator().manual_seed(M + N + K + fp16)
+    A = torch.randn((M, K), generator=g).to(t16)
+    W = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(t16)
+    b = torch.randn((N,), generator=g) * 0.1
+    # exact ties: copies of one weight row (and its shift) at columns that meet at every level of the reduction
+    for src, dsts in ((5, (5 + 32, 5 + 64, 5 + 130)), (200, (201,)), (70, (70 + 256 if N > 600 else 71,))):
+        for dcol in dsts:
+            if dcol < N:
+                W[dcol] = W[src]; b[dcol] = b[src]
+    A16, Wb = A.view(torch.int16).to(DEV), W.view(torch.int16).to(DEV)
+    bd = b.to(DEV)
+    # make the tied columns the row maximum for a third of the rows: a large shift on them
+    bd_t = bd.clone()
+    bd_t[[c for c in (5, 37, 69, 135, 200, 201) if c < N]] += 50.0
+    nt = (N + 255) // 256
+    for shift in (bd, bd_t):
+        y = torch.empty((M, N), device=DEV)
+        _hip.check(lib.rgrg_debug_linear_bf16_train(A16.data_ptr(), Wb.data_ptr(), shift.data_ptr(), None, y.data_ptr(), None, None, None,
+                                                    M, N, K, N, 0, 5, fp16, _stream()), "logits")
+        cv = torch.full((M, nt), float("nan"), device=DEV)
+        ci = torch.full((M, nt), -1, device=DEV, dtype=torch.int32)
+        _hip.check(lib.rgrg_debug_linear_bf16_argmax(A16.data_ptr(), Wb.data_ptr(), shift.data_ptr(), M, N, K, cv.data_ptr(), ci.data_ptr(),
+                                                     fp16, _stream()), "argmax epilogue")
+        torch.cuda.synchronize()
+        pad = torch.full((M, nt * 256 - N), float("-inf"), device=DEV)
+        tiles = torch.cat([y, pad], dim=1).view(M, nt, 256)
+        ref_v, ref_i = tiles.max(dim=2)
+        first = (tiles == ref_v[..., None]).int().argmax(dim=2) + torch.arange(nt, device=DEV)[None, :] * 256   # first maximum of the tile
+        assert torch.equal(cv, ref_v)
+        assert torch.equal(ci.long(), first)
+        # and the row's token = torch.argmax of the full logits row
+        best_tile = (cv == cv.max(dim=1, keepdim=True).values).int().argmax(dim=1)
+        assert torch.equal(ci.long().gather(1, best_tile[:, None])[:, 0], y.argmax(dim=1))
