@@ -85,14 +85,18 @@ def rooflines(eng, S_dec, dtype, max_length):
         gemm = {"bound": "mfma", "kernel": "gemm_bf16_glds_kernel" if dtype == "bf16" else "gemm_f32_kernel", "achieved": ach, "peak": peak,
                 "unit": "TFLOP/s", "frac": ach / peak, "traffic": g_traffic, "traffic_source": g_src, "launches_per_decode_step": n,
                 "avg_launch_us": 1e3 * p["ms_gemm"] / n, "algorithmic_flops_per_launch": p["gemm_flops"] / n,
-                "note": "achieved = 2 M N K of the GEMM launches of one decode step / their duration between two HIP events on the decoder stream"}
+                "note": "achieved = 2 M N K of the GEMM launches of one decode step / their duration between two HIP events on the decoder stream, "
+                        "launched as the step launches them: >= 512 sequences in 16-bit mode run as 3 row ranges on forked streams "
+                        "(decoder.hip run_row_ranges), so launches of different ranges overlap and avg_launch_us = duration / launches is an "
+                        "effective figure (a kernel trace shows longer, overlapping launches)"}
     ach = p["kv_bytes"] / (p["ms_attn"] * 1e-3) / 1e9
     attn = {"bound": "hbm", "kernel": "attn_decode_kv16_wave_kernel" if (dtype == "bf16" and S_dec > 128) else "attn_decode_kernel",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": a_traffic, "traffic_source": a_src,
             "launches_per_decode_step": 24, "avg_launch_us": 1e3 * p["ms_attn"] / 24, "algorithmic_bytes_per_launch": p["kv_bytes"] / 24,
             "keys_per_sequence": nkeys,
-            "note": "achieved = K/V cache bytes of the 24 attention launches of one step at the mid-sequence key count / their duration "
-                    "between two HIP events on the decoder stream"}
+            "note": "achieved = K/V cache bytes of the attention launches of one step at the mid-sequence key count / their duration "
+                    "between two HIP events on the decoder stream (24 launches; 3 x 24 overlapping row-range launches on the many-sequence "
+                    "16-bit path; avg_launch_us and the bytes per launch are per layer)"}
     gemm["ms_per_decode_step"], attn["ms_per_decode_step"] = p["ms_gemm"], p["ms_attn"]
     return (gemm, attn) if p["ms_gemm"] >= p["ms_attn"] else (attn, gemm)
 

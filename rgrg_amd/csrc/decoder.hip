@@ -56,6 +56,7 @@ int launch_gemm_bf16w(const float* A, const void* Wb, const float* shift, const 
                       int ldy, int act, hipStream_t st, int f16);
 int convert_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st, int f16);
 
+constexpr int MAX_CHAINS = 4;   // row ranges of the many-sequence decode step (enqueue_step)
 constexpr int PAD_ROWS = 32;
 constexpr int SKINNY_MAX_ROWS = 128;  // 4 row tiles of 32 sequences per weight-streaming launch (RGRG_SKINNY_MAX_ROWS)
 static int skinny_max_rows() {
@@ -1545,6 +1546,10 @@ struct rgrg_decoder {
     // > 0: the last greedy generate ran the lm_head with the arg-max epilogue for this many rows - d->logits was not written;
     // rgrg_decoder_copy_last_logits recomputes it from the retained ln_f output (xn16) before copying
     int logits_stale_rows = 0;
+    // enqueue_step: extra streams + fork / join events of the multi-range many-sequence step (RGRG_DECODE_CHAINS)
+    hipStream_t streams_x[MAX_CHAINS - 1] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_CHAINS - 1] = {};
+    int chains = 3;   // measured: 1 -> 81.6, 2 -> 82.8, 3 -> 85.4, 4 -> 85.1 images/s at BASELINE configs[2] (profiles/r05_decode_row_ranges_ab.log)
     unsigned long long* sk_stamps = nullptr;
     int sk_stamp_next = 0;
     std::vector<std::pair<const char*, int>> sk_stamp_meta;   // (kernel, workgroups) per slot
@@ -1707,7 +1712,9 @@ static bool lm_head_cand_path(const rgrg_decoder* d, int S) {
            gemm_bf16_cand_epilogue_ok(S, d->lm_head.N, d->lm_head.K);
 }
 
-static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsigned short* att16, int frag_out = 0) {
+// r0: first sequence of the launch (the many-sequence step may run as two row ranges on two streams, enqueue_step); src / att16
+// are the caller's pointers for that first sequence already
+static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsigned short* att16, int frag_out = 0, int r0 = 0) {
     hipStream_t st = d->stream;
     const int D = d->D;
     float* kc = d->kv + (size_t)l * d->kv_layer_stride;
@@ -1722,8 +1729,9 @@ static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsig
             return RGRG_EINVAL;
         }
         const dim3 wgrid(S * d->H / 4), wblk(256);
-#define KV16_LAUNCH(SRC_, F16_) hipLaunchKernelGGL((attn_decode_kv16_wave_kernel<SRC_, F16_>), wgrid, wblk, 0, st, d->qkv, 3 * D, kc16, \
-                                                  kc16 + d->kv_kv_stride, d->step, d->att, S, d->H, d->T, src, att16)
+        u16* kc16r = kc16 + (size_t)r0 * d->H * d->T * 64;   // cache rows of sequence r0 (layout [sequence][head][slot][64])
+#define KV16_LAUNCH(SRC_, F16_) hipLaunchKernelGGL((attn_decode_kv16_wave_kernel<SRC_, F16_>), wgrid, wblk, 0, st, d->qkv + (size_t)r0 * 3 * D, 3 * D, kc16r, \
+                                                  kc16r + d->kv_kv_stride, d->step, d->att + (size_t)r0 * D, S, d->H, d->T, src, att16)
         if (src) { if (d->f16()) KV16_LAUNCH(true, true); else KV16_LAUNCH(true, false); }
         else { if (d->f16()) KV16_LAUNCH(false, true); else KV16_LAUNCH(false, false); }
 #undef KV16_LAUNCH
@@ -1920,6 +1928,48 @@ static int enqueue_step_fused(rgrg_decoder* d, int S, bool count, const int* tok
     return RGRG_OK;
 }
 
+// The many-sequence 16-bit step as `chains` independent row ranges (whole 64-row tiles): fn(r0, rows) enqueues a range's work on
+// d->stream; ranges 1.. run on forked streams (d->stream is swapped around the call) and are joined before this returns, so
+// one range's attention (HBM bound) and launch boundaries overlap another range's GEMMs.  Works under stream capture (the step
+// graph gets parallel branches) and eagerly.  chains < 0: the ranges one after the other on d->stream (A/B runs).
+template <class F>
+static int run_row_ranges(rgrg_decoder* d, int S, int chains, F&& fn) {
+    int nr = chains < 0 ? -chains : chains;
+    const int tiles = (S + 63) / 64;
+    int bounds[MAX_CHAINS + 1];
+    // every range must stay on the many-sequence code path (> 128 rows: 16-bit cache, tiled GEMMs): fewer ranges otherwise
+    for (; nr > 1; --nr) {
+        int least = S;
+        for (int i = 0; i <= nr; ++i) {
+            bounds[i] = std::min(S, ((tiles * i + nr - 1) / nr) * 64);
+            if (i) least = std::min(least, bounds[i] - bounds[i - 1]);
+        }
+        if (least > SKINNY_MAX_ROWS) break;
+    }
+    if (nr <= 1) return fn(0, S);
+    if (chains > 0) {
+        RGRG_HIP(hipEventRecord(d->ev_fork, d->stream));
+        for (int i = 1; i < nr; ++i) RGRG_HIP(hipStreamWaitEvent(d->streams_x[i - 1], d->ev_fork, 0));
+    }
+    int rc = RGRG_OK;
+    for (int i = 0; i < nr && !rc; ++i) {
+        if (bounds[i + 1] <= bounds[i]) continue;
+        if (chains > 0 && i > 0) std::swap(d->stream, d->streams_x[i - 1]);
+        rc = fn(bounds[i], bounds[i + 1] - bounds[i]);
+        if (chains > 0 && i > 0) std::swap(d->stream, d->streams_x[i - 1]);
+    }
+    if (chains > 0)   // join even after an error: a forked stream must not be left inside a capture
+        for (int i = 1; i < nr; ++i) {
+            RGRG_HIP(hipEventRecord(d->ev_join[i - 1], d->streams_x[i - 1]));
+            RGRG_HIP(hipStreamWaitEvent(d->stream, d->ev_join[i - 1], 0));
+        }
+    return rc;
+}
+// ... which steps run that way: greedy, LayerNorm-folded 16-bit mode, at least 512 sequences (RGRG_DECODE_CHAINS: 1 = off)
+static int step_chains(const rgrg_decoder* d, int S, bool greedy, bool fold) {
+    return (greedy && fold && S >= 512 && (d->chains < 0 || d->streams_x[0])) ? d->chains : 1;
+}
+
 // One decode step.  <= 128 token rows: the fused plan above.  More rows (many images, beam rows): tiled MFMA GEMMs
 //   embed+ln1 | per layer: c_attn, attention, attn_proj (+ residual), ln2, c_fc+gelu, mlp_proj (+ residual),
 //   ln1 of the next layer / ln_f | lm_head, per-32-column arg-max candidates, argmax + bookkeeping
@@ -1948,28 +1998,46 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
     cons.ln_stats = d->ln_stat; cons.ln_colsum = &cons_tag;
     const GemmLnFold* pf = fold ? &prod : nullptr;
     const GemmLnFold* cf = fold ? &cons : nullptr;
-    hipLaunchKernelGGL(embed_ln_kernel, dim3(S), dim3(256), 0, st, d->wte, d->ids, d->max_len, d->step,
-                       d->layers[0].ln1_g, d->layers[0].ln1_b, d->x, d->xn, D, tok_override, xn16, d->f16(), d->pos_override_cur,
-                       fold ? d->ln_stat : (float*)nullptr);
-    RGRG_LAUNCH_CHECK();
-    for (int l = 0; l < d->n_layer; ++l) {
-        const LayerW& w = d->layers[l];
-        const float* ng = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_g : d->lnf_g;
-        const float* nb = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_b : d->lnf_b;
-        if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, count, xn16, nullptr, cf))) return rc;
-        if ((rc = launch_attention(d, l, S, src, att16))) return rc;
-        if ((rc = linear(d, w.attn_proj, d->att, d->x, d->x, S, D, RGRG_ACT_NONE, count, att16, nullptr, pf))) return rc;
-        if (!fold) {
-            hipLaunchKernelGGL(ln_rows_kernel, dim3((S + 3) / 4), dim3(256), 0, st, d->x, w.ln2_g, w.ln2_b, d->xn, D, xn16, d->f16(), S);
-            RGRG_LAUNCH_CHECK();
+    // Embedding .. last LayerNorm for the sequences [r0, r0 + rows) on d->stream.  Every kernel of the chain is row-local (a
+    // sequence's token, residual stream, cache rows and LayerNorm slots), so a step can run as independent row ranges.
+    auto run_rows = [&](int r0, int rows) -> int {
+        hipStream_t rs = d->stream;
+        const size_t o = (size_t)r0 * D;
+        float* x = d->x + o; float* xn = d->xn + o;
+        unsigned short* xn16r = xn16 ? xn16 + o : nullptr;
+        unsigned short* att16r = att16 ? att16 + o : nullptr;
+        unsigned short* ff16r = ff16 ? ff16 + 4 * o : nullptr;
+        float* statr = d->ln_stat ? d->ln_stat + (size_t)r0 * 32 : nullptr;
+        GemmLnFold prod_r = prod, cons_r = cons;
+        prod_r.Yb16 = xn16r; prod_r.stats_out = statr; cons_r.ln_stats = statr;
+        const GemmLnFold* pfr = fold ? &prod_r : nullptr;
+        const GemmLnFold* cfr = fold ? &cons_r : nullptr;
+        hipLaunchKernelGGL(embed_ln_kernel, dim3(rows), dim3(256), 0, rs, d->wte, d->ids + (size_t)r0 * d->max_len, d->max_len, d->step,
+                           d->layers[0].ln1_g, d->layers[0].ln1_b, x, xn, D, tok_override ? tok_override + r0 : nullptr, xn16r, d->f16(),
+                           d->pos_override_cur ? d->pos_override_cur + r0 : nullptr, fold ? statr : (float*)nullptr);
+        RGRG_LAUNCH_CHECK();
+        int rc2;
+        for (int l = 0; l < d->n_layer; ++l) {
+            const LayerW& w = d->layers[l];
+            const float* ng = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_g : d->lnf_g;
+            const float* nb = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_b : d->lnf_b;
+            if ((rc2 = linear(d, w.c_attn, xn, nullptr, d->qkv + 3 * o, rows, 3 * D, RGRG_ACT_NONE, count, xn16r, nullptr, cfr))) return rc2;
+            if ((rc2 = launch_attention(d, l, rows, src ? src + (size_t)r0 * d->T : nullptr, att16r, 0, r0))) return rc2;
+            if ((rc2 = linear(d, w.attn_proj, d->att + o, x, x, rows, D, RGRG_ACT_NONE, count, att16r, nullptr, pfr))) return rc2;
+            if (!fold) {
+                hipLaunchKernelGGL(ln_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, rs, x, w.ln2_g, w.ln2_b, xn, D, xn16r, d->f16(), rows);
+                RGRG_LAUNCH_CHECK();
+            }
+            if ((rc2 = linear(d, w.c_fc, xn, nullptr, d->ff + 4 * o, rows, 4 * D, RGRG_ACT_GELU_NEW, count, xn16r, ff16r, cfr))) return rc2;
+            if ((rc2 = linear(d, w.mlp_proj, d->ff + 4 * o, x, x, rows, D, RGRG_ACT_NONE, count, ff16r, nullptr, pfr))) return rc2;
+            if (!fold || l + 1 == d->n_layer) {
+                hipLaunchKernelGGL(ln_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, rs, x, ng, nb, xn, D, xn16r, d->f16(), rows);
+                RGRG_LAUNCH_CHECK();
+            }
         }
-        if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, count, xn16, ff16, cf))) return rc;
-        if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->x, S, D, RGRG_ACT_NONE, count, ff16, nullptr, pf))) return rc;
-        if (!fold || l + 1 == d->n_layer) {
-            hipLaunchKernelGGL(ln_rows_kernel, dim3((S + 3) / 4), dim3(256), 0, st, d->x, ng, nb, d->xn, D, xn16, d->f16(), S);
-            RGRG_LAUNCH_CHECK();
-        }
-    }
+        return RGRG_OK;
+    };
+    if ((rc = run_row_ranges(d, S, step_chains(d, S, !beam && !tok_override && !src, fold), run_rows))) return rc;
     if (!beam && xn16 && lm_head_cand_path(d, S)) {
         // greedy: the 256 x 256 lm_head leaves one (maximum, column) pair per row and column tile; no logits, no candidates pass
         GemmLnFold ce{};
@@ -2048,6 +2116,21 @@ extern "C" int rgrg_decoder_create_with_cache(const rgrg_decoder_weights* w, int
         set_error("decoder: stream/event creation failed");
         delete d;
         return RGRG_EHIP;
+    }
+    if (const char* e = getenv("RGRG_DECODE_CHAINS")) {
+        const int v = atoi(e);
+        d->chains = (v >= -MAX_CHAINS && v <= MAX_CHAINS && v != 0 && v != -1) ? v : 1;
+    }
+    if (d->chains > 1) {
+        bool ok = hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < d->chains - 1; ++i)
+            ok = hipStreamCreateWithFlags(&d->streams_x[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&d->ev_join[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            set_error("decoder: stream/event creation failed");
+            rgrg_decoder_destroy(d);
+            return RGRG_EHIP;
+        }
     }
     if (hipHostMalloc((void**)&d->h_id_error, sizeof(int), 0) == hipSuccess) *d->h_id_error = 0;
     if (hipHostMalloc((void**)&d->h_done, 4 * sizeof(int), 0) != hipSuccess ||
@@ -2212,6 +2295,11 @@ extern "C" void rgrg_decoder_destroy(rgrg_decoder* d) {
         if (e) (void)hipEventDestroy(e);
     if (d->h_id_error) (void)hipHostFree(d->h_id_error);
     if (d->ev_in) (void)hipEventDestroy(d->ev_in);
+    if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
+    for (int i = 0; i < MAX_CHAINS - 1; ++i) {
+        if (d->ev_join[i]) (void)hipEventDestroy(d->ev_join[i]);
+        if (d->streams_x[i]) (void)hipStreamDestroy(d->streams_x[i]);
+    }
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
@@ -3339,18 +3427,33 @@ extern "C" int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, i
     for (int it = -1; it < iters && !rc; ++it) {
         const bool c = it == -1;   // the untimed replay also counts the step's bytes / flops / launches
         if (it == 0) RGRG_HIP(hipEventRecord(e0, d->stream));
-        for (int l = 0; l < d->n_layer && !rc; ++l) {
-            const LayerW& w = d->layers[l];
-            if (fused) {
-                if ((rc = enqueue_layer_gemms(d, l ? l : 1, S, c, nullptr, d->x, d->x2, 0))) break;
-                if ((rc = enqueue_layer_gemms(d, l, S, c, nullptr, d->x, d->x2, 1))) break;
-                continue;
+        // the per-layer GEMMs as the step launches them: in row ranges on forked streams where the step does (run_row_ranges)
+        rc = run_row_ranges(d, S, fused ? 1 : step_chains(d, S, true, fold), [&](int r0, int rows) -> int {
+            const size_t o = (size_t)r0 * D;
+            GemmLnFold prod_r = prod, cons_r = cons;
+            prod_r.Yb16 = xn16 ? xn16 + o : nullptr;
+            prod_r.stats_out = d->ln_stat ? d->ln_stat + (size_t)r0 * 32 : nullptr;
+            cons_r.ln_stats = prod_r.stats_out;
+            const GemmLnFold* pfr = pf ? &prod_r : nullptr;
+            const GemmLnFold* cfr = cf ? &cons_r : nullptr;
+            unsigned short* xn16r = xn16 ? xn16 + o : nullptr;
+            unsigned short* att16r = att16 ? att16 + o : nullptr;
+            unsigned short* ff16r = ff16 ? ff16 + 4 * o : nullptr;
+            int rc2 = RGRG_OK;
+            for (int l = 0; l < d->n_layer && !rc2; ++l) {
+                const LayerW& w = d->layers[l];
+                if (fused) {
+                    if ((rc2 = enqueue_layer_gemms(d, l ? l : 1, S, c, nullptr, d->x, d->x2, 0))) break;
+                    if ((rc2 = enqueue_layer_gemms(d, l, S, c, nullptr, d->x, d->x2, 1))) break;
+                    continue;
+                }
+                if ((rc2 = linear(d, w.c_attn, d->xn + o, nullptr, d->qkv + 3 * o, rows, 3 * D, RGRG_ACT_NONE, c, xn16r, nullptr, cfr))) break;
+                if ((rc2 = linear(d, w.attn_proj, d->att + o, d->x + o, d->h1 + o, rows, D, RGRG_ACT_NONE, c, att16r, nullptr, pfr))) break;
+                if ((rc2 = linear(d, w.c_fc, d->xn + o, nullptr, d->ff + 4 * o, rows, 4 * D, RGRG_ACT_GELU_NEW, c, xn16r, ff16r, cfr))) break;
+                if ((rc2 = linear(d, w.mlp_proj, d->ff + 4 * o, d->x + o, d->h1 + o, rows, D, RGRG_ACT_NONE, c, ff16r, nullptr, pfr))) break;
             }
-            if ((rc = linear(d, w.c_attn, d->xn, nullptr, d->qkv, S, 3 * D, RGRG_ACT_NONE, c, xn16, nullptr, cf))) break;
-            if ((rc = linear(d, w.attn_proj, d->att, d->x, d->h1, S, D, RGRG_ACT_NONE, c, att16, nullptr, pf))) break;
-            if ((rc = linear(d, w.c_fc, d->xn, nullptr, d->ff, S, 4 * D, RGRG_ACT_GELU_NEW, c, xn16, ff16, cf))) break;
-            if ((rc = linear(d, w.mlp_proj, d->ff, d->x, d->h1, S, D, RGRG_ACT_NONE, c, ff16, nullptr, pf))) break;
-        }
+            return rc2;
+        });
         if (!rc && fused) {
             DirectArgs h{};
             h.Xf = d->x; h.part = d->part; h.Y = d->logits; h.ldy = d->ld_logits; h.act = RGRG_ACT_NONE;
@@ -3372,7 +3475,12 @@ extern "C" int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, i
         hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, d->stream, d->step, nkeys - 2);
         for (int it = -1; it < iters && !rc; ++it) {
             if (it == 0) RGRG_HIP(hipEventRecord(e0, d->stream));
-            for (int l = 0; l < d->n_layer && !rc; ++l) rc = launch_attention(d, l, S, nullptr, att16, fused ? 1 : 0);
+            rc = run_row_ranges(d, S, fused ? 1 : step_chains(d, S, true, fold), [&](int r0, int rows) -> int {
+                int rc2 = RGRG_OK;
+                for (int l = 0; l < d->n_layer && !rc2; ++l)
+                    rc2 = launch_attention(d, l, rows, nullptr, att16 ? att16 + (size_t)r0 * D : nullptr, fused ? 1 : 0, r0);
+                return rc2;
+            });
         }
         if (!rc) {
             RGRG_HIP(hipEventRecord(e1, d->stream));

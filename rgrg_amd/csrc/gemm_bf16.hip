@@ -607,9 +607,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmBf16Param
     // waves), from where the epilogue fetches the 16 rows of its C layout
     float2* row_stat = reinterpret_cast<float2*>(glds_smem + NST * STAGE);   // [BM]
     if constexpr (LNF == 2) {
+        // ONE summation order for every tile shape (a row's result must not depend on the tile the launcher picks for M): the 16
+        // slots are added in groups of four (slot order, from zero), the groups pairwise: (G0 + G1) + (G2 + G3).  64-row tiles:
+        // a thread owns one group, the butterfly below adds them; 128-row tiles: a thread owns two groups and adds them first.
+        static_assert(PER == 4 || PER == 8, "slot reduction is written for 64- and 128-row tiles");
         float ls1 = 0.f, ls2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < PER / 2; ++j) { ls1 += lsq[j][0]; ls2 += lsq[j][1]; ls1 += lsq[j][2]; ls2 += lsq[j][3]; }
+        for (int j0 = 0; j0 < PER / 2; j0 += 2) {
+            float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+            for (int j = j0; j < j0 + 2; ++j) { g1 += lsq[j][0]; g2 += lsq[j][1]; g1 += lsq[j][2]; g2 += lsq[j][3]; }
+            if (j0 == 0) { ls1 = g1; ls2 = g2; } else { ls1 += g1; ls2 += g2; }
+        }
 #pragma unroll
         for (int o = 1; o < TPR; o <<= 1) { ls1 += __shfl_xor(ls1, o, 64); ls2 += __shfl_xor(ls2, o, 64); }
         const float mean = ls1 * (1.0f / 1024.0f);

@@ -270,3 +270,44 @@ def test_lm_head_argmax_epilogue_generates_the_same_ids_as_the_logits_path():
         live = (ids_l[:, 1:] != 50256).all(dim=1)                # rows that never emitted EOS (finished rows are padded)
         assert live.any()
         assert torch.equal(lg_l.argmax(dim=1)[live], ids_l[live, -1])   # the stored logits are the last step's
+
+
+def test_many_sequence_step_in_row_ranges_is_bit_identical_to_one_range():
+    """Round 5: the greedy 16-bit step of >= 512 sequences runs as 3 row ranges on forked streams inside the step graph
+    (decoder.hip run_row_ranges; one range's attention overlaps another's GEMMs).  Every kernel of the chain is row-local and the
+    GEMMs' per-row arithmetic does not depend on the tile the launcher picks for a range's row count (the folded LayerNorm's slot
+    reduction has ONE order for 64- and 128-row tiles), so ids and last-step logits must be bit-identical to the single-range
+    step (RGRG_DECODE_CHAINS=1), for 2 / 3 (default) / 4 requested ranges, graph replays and eager launches, bf16 and fp16.
+    700 sequences: ranges of 384 / 316 and 256 / 256 / 188 rows (ragged last tile); 4 ranges would leave 124 rows in the last one,
+    which would drop to the <= 128-row code path (fp32 cache), so the launcher falls back to 3.  Read once per process -> child
+    processes."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import gpu_model\n"
+        "m = gpu_model('ragged'); g = torch.Generator().manual_seed(12)\n"
+        "feats = torch.randn((700, 1024), generator=g).cuda()\n"
+        "eng = m.engine()\n"
+        "out = []\n"
+        "for mode, graph in ((1, True), (2, True), (1, False)):\n"
+        "    ids = eng.greedy_decode(feats, 8, use_graph=graph, bf16=mode)\n"
+        "    out.append((ids.cpu(), eng.last_logits(700).cpu()))\n"
+        "torch.save(out, sys.argv[1])\n" % (repo, os.path.join(repo, "tests")))
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, env_add in (("one", {"RGRG_DECODE_CHAINS": "1"}), ("default", {}), ("two", {"RGRG_DECODE_CHAINS": "2"}),
+                              ("four", {"RGRG_DECODE_CHAINS": "4"})):
+            path = os.path.join(tmp, name + ".pt")
+            env = {k: v for k, v in os.environ.items() if k != "RGRG_DECODE_CHAINS"}
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(env, **env_add), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[name] = torch.load(path)
+    for name in ("default", "two", "four"):
+        for (ids1, lg1), (ids0, lg0) in zip(res[name], res["one"]):
+            assert torch.equal(ids1, ids0), name
+            assert torch.equal(lg1, lg0), name
+    assert torch.equal(res["one"][0][0], res["one"][2][0])   # graph replay == eager launches

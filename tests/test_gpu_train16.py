@@ -254,3 +254,55 @@ def test_pingpong_gemm_argmax_epilogue(M, N, K, fp16):
         # and the row's token = torch.argmax of the full logits row
         best_tile = (cv == cv.max(dim=1, keepdim=True).values).int().argmax(dim=1)
         assert torch.equal(ci.long().gather(1, best_tile[:, None])[:, 0], y.argmax(dim=1))
+
+
+def test_a_rows_result_does_not_depend_on_the_tile_or_the_row_count():
+    """What lets the many-sequence decode step run as row ranges (decoder.hip run_row_ranges) with bit-identical results: the
+    16-bit GEMM of a row gives the same bits on every tile shape / stage count, and inside a launch of 923 rows as inside one of
+    512 or 320 rows (the launcher picks other tiles for those) - plain, with gelu, as the CONSUMER of a folded LayerNorm (all 16
+    statistics slots filled: their reduction has one order for 64- and 128-row tiles) and as its PRODUCER (16-bit copy + slots)."""
+    lib = _hip.load()
+    g = torch.Generator().manual_seed(3)
+    M, K = 923, 1024
+    A16 = torch.randn((M, K), generator=g).bfloat16().view(torch.int16).to(DEV)
+    for N, act in ((3072, 0), (4096, 2), (1024, 0)):
+        Wb = (torch.randn((N, K), generator=g) / math.sqrt(K)).bfloat16().view(torch.int16).to(DEV)
+        b = torch.randn((N,), generator=g).to(DEV)
+        outs = []
+        for tile in (2 + 64, 2 + 48, 3 + 48, 1 + 32, 4 + 48):   # 64x64x4, 64x64x3, 128x64x3, 128x128x2, 64x128x3
+            y = torch.empty((M, N), device=DEV)
+            _hip.check(lib.rgrg_debug_linear_bf16_tile(A16.data_ptr(), Wb.data_ptr(), b.data_ptr(), None, y.data_ptr(), M, N, K, N, act, tile,
+                                                       0, 0, 0, _stream()), "tile")
+            outs.append(y)
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, outs[0]) for o in outs[1:]), (N, act)
+    # consumer of a folded LayerNorm: statistics in all 16 slots of a row
+    N = 3072
+    Wf = (torch.randn((N, K), generator=g) / math.sqrt(K)).bfloat16().view(torch.int16).to(DEV)
+    sh, cs = torch.randn((N,), generator=g).to(DEV), torch.randn((N,), generator=g).to(DEV)
+    x = A16.view(torch.bfloat16).float().view(M, 16, 64)
+    stats = torch.stack([x.sum(2), (x * x).sum(2)], dim=2).contiguous()   # [M][16][2]
+    ys = []
+    for m in (923, 512, 320):
+        y = torch.empty((m, N), device=DEV)
+        _hip.check(lib.rgrg_debug_linear_bf16_ln(A16.data_ptr(), Wf.data_ptr(), sh.data_ptr(), None, y.data_ptr(), None, None, stats.data_ptr(),
+                                                 cs.data_ptr(), m, N, K, N, 0, 0, _stream()), "ln consumer")
+        ys.append(y)
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0][:512], ys[1]) and torch.equal(ys[0][:320], ys[2])
+    # producer (N = 1024, K = 4096, residual)
+    K2 = 4096
+    A2 = torch.randn((M, K2), generator=g).bfloat16().view(torch.int16).to(DEV)
+    W2 = (torch.randn((1024, K2), generator=g) / math.sqrt(K2)).bfloat16().view(torch.int16).to(DEV)
+    R, b2 = torch.randn((M, 1024), generator=g).to(DEV), torch.randn((1024,), generator=g).to(DEV)
+    res = []
+    for m in (923, 512, 320):
+        y = torch.empty((m, 1024), device=DEV)
+        yb = torch.empty((m, 1024), device=DEV, dtype=torch.int16)
+        so = torch.zeros((m, 16, 2), device=DEV)
+        _hip.check(lib.rgrg_debug_linear_bf16_ln(A2.data_ptr(), W2.data_ptr(), b2.data_ptr(), R.data_ptr(), y.data_ptr(), yb.data_ptr(), so.data_ptr(),
+                                                 None, None, m, 1024, K2, 1024, 0, 0, _stream()), "ln producer")
+        res.append((y, yb, so))
+    torch.cuda.synchronize()
+    for m, r in ((512, res[1]), (320, res[2])):
+        assert all(torch.equal(a[:m], b) for a, b in zip(res[0], r)), m
