@@ -1420,7 +1420,10 @@ __global__ __launch_bounds__(256) void ln_fold16_kernel(const float* __restrict_
     float a = 0.f, c = 0.f;
     for (int k = lane; k < K; k += 64) {
         const float wv = w[(size_t)n * K + k];
-        const unsigned short r = (unsigned short)to16_rt(gain[k] * wv, f16);
+        float gw = gain[k] * wv;
+        asm("" : "+v"(gw));   // the fp32 product, THEN the 16-bit rounding (what torch's (W * g).to(half) does): without this the
+                              // compiler fuses multiply + conversion into v_fma_mixlo_f16, i.e. one rounding of the exact product
+        const unsigned short r = (unsigned short)to16_rt(gw, f16);
         wb[(size_t)n * K + k] = r;
         a += from16_rt(r, f16);
         c += beta[k] * wv;
@@ -2153,10 +2156,6 @@ extern "C" int rgrg_decoder_create_with_cache(const rgrg_decoder_weights* w, int
         TRY(make_lin(d, t.attn_proj, s.attn_proj_w, s.attn_proj_b, D, D, true, true));
         TRY(make_lin(d, t.c_fc, s.c_fc_w, s.c_fc_b, 4 * D, D, true, true, s.ln2_g, s.ln2_b));
         TRY(make_lin(d, t.mlp_proj, s.mlp_proj_w, s.mlp_proj_b, D, 4 * D, true, true));
-    }
-    if (const char* e = getenv("RGRG_PROBE_ALIAS_LAYERS")) {  // TEMPORARY probe: layers cycle through the first n weight sets
-        const int n = atoi(e);
-        if (n > 0) for (int l = n; l < w->n_layer; ++l) d->layers[l] = d->layers[l % n];
     }
     const size_t R = d->rows;
     d->ld_logits = d->lm_head.NT * d->lm_head.ntile;
