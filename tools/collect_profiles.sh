@@ -17,8 +17,10 @@ cd /tmp
 B1="python $ROOT/bench.py --no-cpu-baseline --no-config2 --steps 3 --warmup 1"
 B32="python $ROOT/bench.py --no-cpu-baseline --no-config2 --batch 32 --dtype bf16 --steps 2 --warmup 1"
 P1="python $ROOT/bench.py --no-cpu-baseline --no-config2 --steps 1 --warmup 0"
-# batch-32 counter passes: the many-sequence decode process with its steps launched EAGERLY - rocprofv3 --pmc segfaults on the
-# hipGraph replays of that step (profiles/r05_rocprofv3_pmc_crash_reproducer.md)
+# batch-32 counter passes: the many-sequence decode process alone with its steps launched EAGERLY, the row ranges one after the
+# other on one stream - rocprofv3 --pmc segfaults on the hipGraph replays of that step; on the final round-5 tree it does not
+# survive this form either (profiles/r05_rocprofv3_pmc_crash_reproducer.md), the two passes then leave no CSV and
+# pmc_traffic.py keeps the previous entries
 P32="python $ROOT/tools/decode_pmc_probe.py 923 128 0"
 
 run() {  # name, rocprof args..., -- command
