@@ -131,9 +131,78 @@ class GradBuckets:
                 off += n
             self.buckets.append(flat)
 
+        self._owner = {}            # id(param) -> bucket index
+        for bi, grp in enumerate(groups):
+            for p in grp:
+                self._owner[id(p)] = bi
+        self._sizes = [len(grp) for grp in groups]
+        self._hooks = None
+        self._pending = None
+        self._works = None
+        self._order = list(reversed(range(len(self.buckets))))   # autograd reaches the LAST parameters first (DDP's bucket order)
+        self.launch_log = []        # bucket indices in the order their reduction was issued during the last step
+
     def zero(self) -> None:
         for flat in self.buckets:
             flat.zero_()
+
+    # ---- reductions issued from the backward pass (opt-in): ``arm()`` once, then per step ``begin_step()`` ... backward ...
+    # ``finish()``.  A post-accumulate hook on every parameter counts its bucket down; a bucket's asynchronous all-reduce is
+    # issued as soon as the bucket AND every bucket in front of it in the fixed launch order (last bucket first) are complete,
+    # so every rank issues the same collectives in the same order whatever its own backward looked like (a rank without
+    # selected regions produces no language-model gradients: its buckets are issued by finish()).  What this overlaps on the
+    # RGRG training step: the classifier heads' bucket with the language model's backward; the 200 MB of d(uk / uv) come out
+    # of the LAST kernel of that backward (rgrg_decoder_lm_loss_grad is one call), so nothing is left to hide them behind.
+    def arm(self, group=None) -> None:
+        if self._hooks is not None:
+            return
+        self._group = group
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def disarm(self) -> None:
+        for h in self._hooks or []:
+            h.remove()
+        self._hooks = None
+
+    def begin_step(self) -> None:
+        self._pending = list(self._sizes)
+        self._works = {}
+        self._next = 0
+        self.launch_log = []
+
+    def _issue_ready(self, force: bool = False) -> None:
+        while self._next < len(self._order):
+            bi = self._order[self._next]
+            if self._pending[bi] > 0 and not force:
+                return
+            self._works[bi] = dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+            self.launch_log.append(bi)
+            self._next += 1
+
+    def _on_grad(self, p) -> None:
+        if self._pending is None or not (dist.is_available() and dist.is_initialized()):
+            return
+        bi = self._owner[id(p)]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._issue_ready()
+
+    def finish(self, average: bool = True) -> int:
+        """Issue what the hooks could not (buckets with parameters that received no gradient this step), wait, average."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0
+        if self._pending is None:
+            raise RuntimeError("GradBuckets.finish() without begin_step()")
+        if not self.owns_all_grads():
+            raise RuntimeError("GradBuckets: a .grad no longer points into the flat buckets (use zero() / zero_grad(set_to_none=False))")
+        self._issue_ready(force=True)
+        world = dist.get_world_size(self._group)
+        for bi, w in self._works.items():
+            w.wait()
+            if average and world > 1:
+                self.buckets[bi].div_(world)
+        self._pending = None
+        return len(self._works)
 
     def owns_all_grads(self) -> bool:
         """False when something replaced a ``.grad`` (e.g. ``zero_grad(set_to_none=True)``)."""

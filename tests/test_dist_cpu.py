@@ -302,3 +302,62 @@ def test_bench_launcher_with_eight_ranks_on_the_stub():
     assert r["n_gpus"] == 8 and r["scaling"] == "weak" and r["config"]["global_batch"] == 256
     assert r["config"]["regions_generated"] == 256 * 29
     assert r["value"] > 0 and abs(r["value"] - 256 * 2 / (r["ms_per_step"] * 2e-3)) < 1e-6 * r["value"]
+
+
+# ------------------------------------------------------------------------- reductions issued from the backward pass (gloo, world 2)
+def _hooked_bucket_worker(rank, world, port, ret):
+    from rgrg_amd.dist import GradBuckets
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in [(300, 40), (40,), (1000, 64), (64,), (7, 9)]]
+        gb = GradBuckets(params, bucket_bytes=60000)          # buckets: [p0, p1] [p2] [p3, p4]
+        sizes = [b.numel() for b in gb.buckets]
+        gb.arm()
+        log = {}
+        for case in ("natural", "reversed", "missing"):
+            gb.zero()
+            gb.begin_step()
+            scale = float(rank + 1)
+            if case == "natural":       # parameters used in order: the backward reaches the LAST bucket first
+                order = [0, 1, 2, 3, 4]
+            elif case == "reversed":    # used in reverse: bucket 0 completes first and must WAIT for its turn
+                order = [4, 3, 2, 1, 0]
+            else:                       # rank 1 never touches p4 (a rank without selected regions): its last bucket never completes
+                order = [0, 1, 2, 3, 4] if rank == 0 else [0, 1, 2, 3]
+            loss = sum(((i + 1) * scale * params[i]).sum() for i in order)
+            loss.backward()
+            issued_in_backward = list(gb.launch_log)
+            n = gb.finish()
+            log[case] = (issued_in_backward, list(gb.launch_log), n, [p.grad.clone() for p in params])
+        if rank in (0, 1):
+            ret[rank] = (sizes, log)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_buckets_issue_their_allreduce_from_backward_hooks_in_one_fixed_order():
+    """a bucket's all-reduce is issued from the backward pass as soon as the bucket and every bucket in front
+    of it in the fixed launch order (last bucket first) are complete - the same order of collectives on every rank, whatever
+    order a rank's own backward produces its gradients in and even when a rank produces none for some parameter (then
+    finish() issues the rest)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_hooked_bucket_worker, args=(2, port, ret), nprocs=2, join=True)
+    sizes, log0 = ret[0]
+    _, log1 = ret[1]
+    assert len(sizes) == 3
+    for case in ("natural", "reversed", "missing"):
+        for log in (log0, log1):
+            assert log[case][1] == [2, 1, 0] and log[case][2] == 3            # one order, every bucket, on every rank
+    assert log0["natural"][0] == [2, 1, 0] and log1["natural"][0] == [2, 1, 0]  # all issued while the backward was running
+    assert log0["reversed"][0] == [2, 1, 0]                                    # ... bucket 0 was complete first and waited
+    assert log0["missing"][0] == [2, 1, 0] and log1["missing"][0] == []        # rank 1: nothing before finish()
+    for case, p4_ranks in (("natural", 2), ("reversed", 2), ("missing", 1)):
+        for log in (log0, log1):
+            for i, g in enumerate(log[case][3]):
+                want = (i + 1) * 1.5 if (i < 4 or p4_ranks == 2) else (i + 1) * 0.5   # mean over ranks of (rank + 1)(i + 1)
+                assert torch.allclose(g, torch.full_like(g, want), atol=1e-6), (case, i)
