@@ -349,6 +349,13 @@ int rgrg_debug_ln_fold16(const float* w, const float* gain, const float* beta, c
 int rgrg_debug_linear_bf16_ln(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
                               uint16_t* Yb16, float* stats_out, const float* ln_stats, const float* ln_colsum, int M, int N,
                               int K, int ldy, int act, int fp16, void* stream);
+/* The same GEMM variants (plus the plain one with a 16-bit output Y16; exactly one of Y / Y16) on the K-parity ping-pong kernel
+ * (csrc/gemm_kp.inc, round 6) when kp != 0 - the kernel the decoder selects for the per-layer projections of the many-sequence
+ * 16-bit decode step (GPT2Block's c_attn / c_proj / c_fc / mlp.c_proj, src/language_model/language_model.py:338-366): its tile
+ * is a function of (N, K) only, so a row's result does not depend on M.  kp == 0: the LDS-DMA kernel's heuristic. */
+int rgrg_debug_linear_bf16_ln_kp(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
+                                 uint16_t* Y16, uint16_t* Yb16, float* stats_out, const float* ln_stats, const float* ln_colsum,
+                                 int M, int N, int K, int ldy, int act, int fp16, int kp, void* stream);
 /* ---- detector targets and losses: ObjectDetector.forward(images, targets), the detector half of
  * ReportGenerationModel.forward(images, image_targets, ...) (src/full_model/report_generation_model.py:55,91 ->
  * src/object_detector/object_detector.py:216-224 -> custom_rpn.py:74-83, custom_roi_heads.py:225-242, and underneath
@@ -408,6 +415,15 @@ int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S, void* stre
  * the decoder exists in the wanted precision mode. */
 int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, int iters, float* ms_gemm, float* ms_attn,
                                  double* gemm_flops, double* gemm_weight_bytes, double* kv_bytes, int* gemm_launches);
+/* Measurement hook: `iters` + 1 eagerly enqueued many-sequence decode steps at `nkeys` keys (state of the last generate() of S
+ * sequences), the last one with an event behind every launch on the stream it was launched on.  recs [max_recs][3] = (first row
+ * of the launch's row range, tag, ms since the step's first launch); tag = layer * 8 + {0 c_attn, 1 attention, 2 attn c_proj,
+ * 3 c_fc, 4 mlp c_proj} (GPT2Block, src/language_model/language_model.py:338-366), 1000 embedding, 1001 ln_f, 1002 lm_head,
+ * 1003 arg-max + bookkeeping (:629-650). */
+int rgrg_decoder_trace_step(rgrg_decoder* d, int S, int nkeys, int iters, float* recs, int max_recs, int* n_out);
+/* Measurement hook: `iters` x n_layer single-query attention launches (GPT2PseudoAttention, language_model.py:124-180) of the
+ * many-sequence step at `nkeys` keys, asynchronously on `stream` (state of the last generate() of S sequences). */
+int rgrg_decoder_attention_only(rgrg_decoder* d, int S, int nkeys, int iters, void* stream);
 
 /* Measurement helper (tools/microbench.py; not on the product path): host wall
  * microseconds per kernel of a dependent chain of n trivial kernels; mode 0 = eager on a

@@ -16,7 +16,7 @@ c_float_p = C.c_void_p  # device pointers travel as void*
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p
 
 ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
-ABI_VERSION = 17  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
+ABI_VERSION = 18  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
 
 
 class RgrgHipError(RuntimeError):
@@ -81,6 +81,7 @@ SIGNATURES = {
     "rgrg_debug_linear_bf16_argmax": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i, _p]),
     "rgrg_debug_ln_fold16": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "rgrg_debug_linear_bf16_ln": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "rgrg_debug_linear_bf16_ln_kp": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rgrg_decoder_copy_last_logits": (_i, [_p, _p, _i, _p]),
     "rgrg_box_match_f32": (_i, [_p, _p, _i, _p, C.c_int64, _p, _i, _i, _f, _f, _i, _p, _p, _p]),
     "rgrg_balanced_sample": (_i, [_p, _p, _i, _p, _p, C.c_uint64, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
@@ -88,6 +89,8 @@ SIGNATURES = {
     "rgrg_roi_add_gt_f32": (_i, [_p, _p, _i, _p, _p, _i, _i, _p, _p, _p]),
     "rgrg_roi_gather_samples_f32": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
     "rgrg_fastrcnn_loss_f32": (_i, [_p, _i, _i, _p, _p, _i, _p, _p]),
+    "rgrg_decoder_trace_step": (_i, [_p, _i, _i, _i, _p, _i, C.POINTER(_i)]),
+    "rgrg_decoder_attention_only": (_i, [_p, _i, _i, _i, _p]),
     "rgrg_decoder_time_step_parts": (_i, [_p, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "rgrg_decoder_time_train_gemms": (_i, [_p, _i, _i, _i, C.POINTER(_f), C.POINTER(C.c_double), C.POINTER(_i)]),

@@ -26,7 +26,7 @@ def _hipcc() -> str:
 
 
 HASH_PATH = os.path.join(LIB_DIR, "librgrg_hip.srchash")
-HEADERS = ("common.h", "skinny_direct.inc", "persistent.inc")
+HEADERS = ("common.h", "skinny_direct.inc", "persistent.inc", "gemm_kp.inc")
 
 
 def _source_hash() -> str:

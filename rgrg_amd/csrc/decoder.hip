@@ -48,6 +48,7 @@ struct GemmLnFold {   // LayerNorm folded around the 16-bit GEMMs (gemm_bf16.hip
     unsigned* sk_cnt = nullptr;
     float* cand_val = nullptr;          // 256 x 256 kernel: per-row (maximum, column) of every column tile instead of Y (greedy lm_head)
     int* cand_idx = nullptr;
+    int kp = 0;                         // the K-parity ping-pong kernel (gemm_kp.inc), tile from (N, K) only
 };
 bool gemm_bf16_cand_epilogue_ok(int M, int N, int K);   // would launch_gemm_bf16w_ex pick the 256 x 256 kernel for this lm_head?
 int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const float* shift, const float* R, float* Y, void* Y16,
@@ -687,12 +688,17 @@ __global__ __launch_bounds__(256) void attn_decode_kv16_wave_kernel(const float*
                                                                     int S, int H, int T, const int* __restrict__ src,
                                                                     u16* __restrict__ out16) {
     const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);  // (sequence, head); grid = S * H / 4 (H is a multiple of 4)
-    const int s = item / H, hd = item - s * H;
     const int t = *step, nkeys = t + 2, slot = t + 1;
     const int g = lane >> 3, d8 = lane & 7;
-    const float* row = qkv + (size_t)s * ld_qkv;
     const int D = H * 64;
+    const __amdgpu_buffer_rsrc_t rk = dx_rsrc(kc), rv = dx_rsrc(vc);
+    // (sequence, head) items: wave w of workgroup b takes items b * 4 + w, + 4 * gridDim.x, ...  The launcher either gives every
+    // item its own wave (grid = S * H / 4) or - round 6, many-sequence step - caps the grid at a few workgroups per CU, so that
+    // the kernel keeps the HBM stream going from a handful of resident waves and leaves the CU's wave slots, registers and LDS to
+    // the GEMM workgroups of the other row ranges that run beside it (decoder.hip run_row_ranges).
+    for (int item = blockIdx.x * 4 + (threadIdx.x >> 6); item < S * H; item += gridDim.x * 4) {
+    const int s = item / H, hd = item - s * H;
+    const float* row = qkv + (size_t)s * ld_qkv;
     const int* srow = HAS_SRC ? src + (size_t)s * T : nullptr;
     Kv16Row r;
     r.q0 = *reinterpret_cast<const f32x4*>(row + hd * 64 + d8 * 8);
@@ -705,7 +711,6 @@ __global__ __launch_bounds__(256) void attn_decode_kv16_wave_kernel(const float*
     u32x4 kn16, vn16;
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    const __amdgpu_buffer_rsrc_t rk = dx_rsrc(kc), rv = dx_rsrc(vc);
 #define KV16_CHUNK(NI_, FIRST_, BASE_) \
     kv16_wave_chunk<NI_, HAS_SRC, FIRST_, F16>(rk, rv, srow, s, hd, H, T, BASE_, nkeys, slot, g, d8, r, q, kn16, vn16, m, l, acc)
     // chunks of 72 keys while more than 72 remain, then ONE chunk sized to what is left in steps of 8 keys (a wave-uniform
@@ -769,6 +774,7 @@ __global__ __launch_bounds__(256) void attn_decode_kv16_wave_kernel(const float*
             *reinterpret_cast<f32x4*>(out + o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
         }
     }
+    }   // items
 }
 
 // image key/value (uk/uv outputs) -> cache slot 0 of every layer
@@ -1532,6 +1538,12 @@ struct rgrg_decoder {
     int sk_attn = 0, sk_mlp = 0; // K slices of attn_proj / mlp_proj there (RGRG_SK_ATTN / RGRG_SK_MLP; 0 or 1 = off)
     float* ln_stat = nullptr;   // [rows][16][2]: per-row (sum, sum of squares) slots (one per 64 columns) of the residual stream (folded LayerNorm)
     bool ln_fold = true;        // 16-bit path: LayerNorms folded into the GEMMs around them; RGRG_LN_FOLD=0: ln_rows launches (A/B)
+    // rgrg_decoder_trace_step: one hipEvent after every launch of an eagerly enqueued step, on the stream it was launched on
+    struct TraceMark { hipEvent_t ev; int r0; int tag; };
+    std::vector<TraceMark>* trace = nullptr;
+    int kp_gemms = 2;           // ... and run on the K-parity ping-pong kernel (gemm_kp.inc, round 6): RGRG_GEMM_KP = 0 none (the LDS-DMA kernel), 1 all four,
+                                // 2 (default) the producers only (attn_proj / mlp_proj, N = 1024), 3 the consumers only (c_attn / c_fc, 128 x 128 row-split kernel).
+                                // Measured per mode: profiles/r06_step_trace_v3.log
     int gemm_launches_per_step = 0;
     void* a16_scratch = nullptr;   // bf16 copy of an fp32 GEMM input (teacher-forced / training passes under autocast)
     size_t a16_bytes = 0;
@@ -1552,7 +1564,9 @@ struct rgrg_decoder {
     // enqueue_step: extra streams + fork / join events of the multi-range many-sequence step (RGRG_DECODE_CHAINS)
     hipStream_t streams_x[MAX_CHAINS - 1] = {};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_CHAINS - 1] = {};
-    int chains = 3;   // measured: 1 -> 81.6, 2 -> 82.8, 3 -> 85.4, 4 -> 85.1 images/s at BASELINE configs[2] (profiles/r05_decode_row_ranges_ab.log)
+    int chains = 4;   // round 5 (LDS-DMA kernel everywhere): 1 -> 81.6, 2 -> 82.8, 3 -> 85.4, 4 -> 85.1 images/s at BASELINE configs[2]
+                      // (profiles/r05_decode_row_ranges_ab.log); round 6, attn_proj / mlp_proj on the K-parity kernel: ms per decode step
+                      // 2.89 (3 ranges, round-5 kernels), 2.83 (3), 2.785 (4) - profiles/r06_step_trace_v3.log
     unsigned long long* sk_stamps = nullptr;
     int sk_stamp_next = 0;
     std::vector<std::pair<const char*, int>> sk_stamp_meta;   // (kernel, workgroups) per slot
@@ -1691,6 +1705,7 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
             if (!l.wb_ln || !X16) { set_error("decoder: folded LayerNorm weights missing"); return RGRG_EINVAL; }
             GemmLnFold f = *ln;
             f.ln_colsum = l.cs16;
+            f.kp = (d->kp_gemms == 1 || d->kp_gemms == 3) ? 1 : 0;
             return launch_gemm_bf16w_ex(nullptr, X16, l.wb_ln, l.c2_16, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream, d->f16(), &f);
         }
         if (ln && ln->Yb16 && d->sk_ws && M <= d->rows) {
@@ -1701,6 +1716,11 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
                 f.ksplit = ks; f.sk_ws = d->sk_ws; f.sk_cnt = d->sk_cnt;
                 return launch_gemm_bf16w_ex(nullptr, X16, l.wb, l.b, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream, d->f16(), &f);
             }
+        }
+        if (ln && ln->Yb16 && X16 && (d->kp_gemms == 1 || d->kp_gemms == 2)) {   // producer of the folded LayerNorm (attn_proj / mlp_proj)
+            GemmLnFold f = *ln;
+            f.kp = 1;
+            return launch_gemm_bf16w_ex(nullptr, X16, l.wb, l.b, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream, d->f16(), &f);
         }
         return launch_gemm_bf16w_ex(X16 ? nullptr : X, X16, l.wb, l.b, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream, d->f16(), ln);
     }
@@ -1731,7 +1751,10 @@ static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsig
                       "lower the batch or max_length", (size_t)d->kv_kv_stride * sizeof(u16));
             return RGRG_EINVAL;
         }
-        const dim3 wgrid(S * d->H / 4), wblk(256);
+        // RGRG_ATTN_WGS_PER_CU = n > 0: at most n * 256 workgroups, each wave walks several (sequence, head) items
+        static const int cap = [] { const char* e = getenv("RGRG_ATTN_WGS_PER_CU"); return e ? atoi(e) : 0; }();
+        const int wgs = S * d->H / 4;
+        const dim3 wgrid(cap > 0 ? std::min(wgs, cap * 256) : wgs), wblk(256);
         u16* kc16r = kc16 + (size_t)r0 * d->H * d->T * 64;   // cache rows of sequence r0 (layout [sequence][head][slot][64])
 #define KV16_LAUNCH(SRC_, F16_) hipLaunchKernelGGL((attn_decode_kv16_wave_kernel<SRC_, F16_>), wgrid, wblk, 0, st, d->qkv + (size_t)r0 * 3 * D, 3 * D, kc16r, \
                                                   kc16r + d->kv_kv_stride, d->step, d->att + (size_t)r0 * D, S, d->H, d->T, src, att16)
@@ -1973,6 +1996,17 @@ static int step_chains(const rgrg_decoder* d, int S, bool greedy, bool fold) {
     return (greedy && fold && S >= 512 && (d->chains < 0 || d->streams_x[0])) ? d->chains : 1;
 }
 
+// measurement only (rgrg_decoder_trace_step): an event on the current stream behind the launch just made.
+// tag = layer * 8 + {0 c_attn, 1 attention, 2 attn_proj, 3 c_fc, 4 mlp_proj}; 1000 embedding, 1001 ln_f, 1002 lm_head, 1003 arg-max
+static int trace_mark(rgrg_decoder* d, int r0, int tag) {
+    if (!d->trace) return RGRG_OK;
+    hipEvent_t e;
+    RGRG_HIP(hipEventCreate(&e));
+    RGRG_HIP(hipEventRecord(e, d->stream));
+    d->trace->push_back({e, r0, tag});
+    return RGRG_OK;
+}
+
 // One decode step.  <= 128 token rows: the fused plan above.  More rows (many images, beam rows): tiled MFMA GEMMs
 //   embed+ln1 | per layer: c_attn, attention, attn_proj (+ residual), ln2, c_fc+gelu, mlp_proj (+ residual),
 //   ln1 of the next layer / ln_f | lm_head, per-32-column arg-max candidates, argmax + bookkeeping
@@ -2020,22 +2054,29 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
                            d->pos_override_cur ? d->pos_override_cur + r0 : nullptr, fold ? statr : (float*)nullptr);
         RGRG_LAUNCH_CHECK();
         int rc2;
+        if ((rc2 = trace_mark(d, r0, 1000))) return rc2;
         for (int l = 0; l < d->n_layer; ++l) {
             const LayerW& w = d->layers[l];
             const float* ng = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_g : d->lnf_g;
             const float* nb = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_b : d->lnf_b;
             if ((rc2 = linear(d, w.c_attn, xn, nullptr, d->qkv + 3 * o, rows, 3 * D, RGRG_ACT_NONE, count, xn16r, nullptr, cfr))) return rc2;
+            if ((rc2 = trace_mark(d, r0, l * 8 + 0))) return rc2;
             if ((rc2 = launch_attention(d, l, rows, src ? src + (size_t)r0 * d->T : nullptr, att16r, 0, r0))) return rc2;
+            if ((rc2 = trace_mark(d, r0, l * 8 + 1))) return rc2;
             if ((rc2 = linear(d, w.attn_proj, d->att + o, x, x, rows, D, RGRG_ACT_NONE, count, att16r, nullptr, pfr))) return rc2;
+            if ((rc2 = trace_mark(d, r0, l * 8 + 2))) return rc2;
             if (!fold) {
                 hipLaunchKernelGGL(ln_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, rs, x, w.ln2_g, w.ln2_b, xn, D, xn16r, d->f16(), rows);
                 RGRG_LAUNCH_CHECK();
             }
             if ((rc2 = linear(d, w.c_fc, xn, nullptr, d->ff + 4 * o, rows, 4 * D, RGRG_ACT_GELU_NEW, count, xn16r, ff16r, cfr))) return rc2;
+            if ((rc2 = trace_mark(d, r0, l * 8 + 3))) return rc2;
             if ((rc2 = linear(d, w.mlp_proj, d->ff + 4 * o, x, x, rows, D, RGRG_ACT_NONE, count, ff16r, nullptr, pfr))) return rc2;
+            if ((rc2 = trace_mark(d, r0, l * 8 + 4))) return rc2;
             if (!fold || l + 1 == d->n_layer) {
                 hipLaunchKernelGGL(ln_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, rs, x, ng, nb, xn, D, xn16r, d->f16(), rows);
                 RGRG_LAUNCH_CHECK();
+                if ((rc2 = trace_mark(d, r0, 1001))) return rc2;
             }
         }
         return RGRG_OK;
@@ -2046,10 +2087,11 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
         GemmLnFold ce{};
         ce.cand_val = d->cand_val; ce.cand_idx = d->cand_idx;
         if ((rc = linear(d, d->lm_head, d->xn, nullptr, nullptr, S, d->ld_logits, RGRG_ACT_NONE, count, xn16, nullptr, &ce))) return rc;
+        if ((rc = trace_mark(d, 0, 1002))) return rc;
         hipLaunchKernelGGL(argmax_update_kernel, dim3(S), dim3(256), 0, st, d->cand_val, d->cand_idx, (d->lm_head.N + 255) / 256, d->ids,
                            d->max_len, d->finished, d->step, d->done_len, d->sync, S);
         RGRG_LAUNCH_CHECK();
-        return RGRG_OK;
+        return trace_mark(d, 0, 1003);
     }
     if ((rc = linear(d, d->lm_head, d->xn, nullptr, d->logits, S, d->ld_logits, RGRG_ACT_NONE, count, xn16))) return rc;
     if (beam) return RGRG_OK;  // the caller ranks the logits (beam_row_topk / beam_merge)
@@ -2120,6 +2162,7 @@ extern "C" int rgrg_decoder_create_with_cache(const rgrg_decoder_weights* w, int
         delete d;
         return RGRG_EHIP;
     }
+    if (const char* e = getenv("RGRG_GEMM_KP")) d->kp_gemms = atoi(e);
     if (const char* e = getenv("RGRG_DECODE_CHAINS")) {
         const int v = atoi(e);
         d->chains = (v >= -MAX_CHAINS && v <= MAX_CHAINS && v != 0 && v != -1) ? v : 1;
@@ -3397,6 +3440,56 @@ extern "C" int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S,
 //     (fused fragment-direct kernels <= 128 rows, tiled fp32 / bf16-weight MFMA GEMMs above);
 //   * the single-query attention at `nkeys` keys per sequence (the step counter is set to nkeys - 2 for the timing).
 // Token / cache contents are whatever the last generate() left: timing only.
+// Measurement hook (tools/overlap_probe.py): `iters` x n_layer attention launches of the many-sequence step at `nkeys` keys on the
+// caller's stream (asynchronous; the state of the last generate() of S sequences) - the HBM-bound half of a decode step as a
+// background load beside other work.
+extern "C" int rgrg_decoder_attention_only(rgrg_decoder* d, int S, int nkeys, int iters, void* stream) {
+    RGRG_CHECK_ARG(d && S > skinny_max_rows() && S <= d->rows && nkeys >= 2 && nkeys <= d->T && iters > 0);
+    hipStream_t keep = d->stream;
+    d->stream = as_stream(stream);
+    hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, d->stream, d->step, nkeys - 2);
+    int rc = RGRG_OK;
+    unsigned short* att16 = (kv_is_bf16(d, S) && d->xn16) ? d->att16 : nullptr;
+    for (int it = 0; it < iters && !rc; ++it)
+        for (int l = 0; l < d->n_layer && !rc; ++l) rc = launch_attention(d, l, S, nullptr, att16, 0, 0);
+    hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, d->stream, d->step, 0);
+    d->stream = keep;
+    return rc;
+}
+
+// Measurement hook (tools/step_trace.py): enqueue `iters` + 1 many-sequence decode steps EAGERLY at `nkeys` keys (the state of
+// the last generate() of S sequences), the last one with a hipEvent behind every launch on the stream it went to, and return
+// (first row of the range, tag, ms since the step's first launch) per launch - the true timeline of the row-range chains
+// under concurrency (rocprofv3's kernel trace serialises the queues).  recs: 3 floats per launch.
+extern "C" int rgrg_decoder_trace_step(rgrg_decoder* d, int S, int nkeys, int iters, float* recs, int max_recs, int* n_out) {
+    RGRG_CHECK_ARG(d && S > skinny_max_rows() && S <= d->rows && nkeys >= 2 && nkeys <= d->T && recs && n_out && iters >= 0);
+    std::vector<rgrg_decoder::TraceMark> marks;
+    hipEvent_t base;
+    RGRG_HIP(hipEventCreate(&base));
+    int rc = RGRG_OK;
+    for (int it = 0; it <= iters && !rc; ++it) {
+        hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, d->stream, d->step, nkeys - 2);
+        if (it == iters) { d->trace = &marks; RGRG_HIP(hipEventRecord(base, d->stream)); }
+        rc = enqueue_step(d, S, false);
+    }
+    d->trace = nullptr;
+    (void)hipStreamSynchronize(d->stream);
+    int n = 0;
+    for (auto& m : marks) {
+        float ms = 0.f;
+        if (!rc && n < max_recs && hipEventElapsedTime(&ms, base, m.ev) == hipSuccess) {
+            recs[3 * n] = (float)m.r0; recs[3 * n + 1] = (float)m.tag; recs[3 * n + 2] = ms;
+            ++n;
+        }
+        (void)hipEventDestroy(m.ev);
+    }
+    (void)hipEventDestroy(base);
+    hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, d->stream, d->step, 0);
+    (void)hipStreamSynchronize(d->stream);
+    *n_out = n;
+    return rc;
+}
+
 extern "C" int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, int iters, float* ms_gemm, float* ms_attn,
                                             double* gemm_flops, double* gemm_weight_bytes, double* kv_bytes,
                                             int* gemm_launches) {

@@ -31,6 +31,7 @@ struct GemmLnFold {
     unsigned* sk_cnt = nullptr;
     float* cand_val = nullptr;    // arg-max candidates instead of Y (GemmBf16Params::cand_val / cand_idx)
     int* cand_idx = nullptr;
+    int kp = 0;                   // 1: the K-parity ping-pong kernel (gemm_kp.inc), tile picked from (N, K) only
 };
 
 struct GemmBf16Params {
@@ -1171,6 +1172,9 @@ static int glds_attrs() {
     return glds_attr<BM, BN, 4>();
 }
 
+static int gemm_gm_override();
+#include "gemm_kp.inc"
+
 constexpr int PP_LDS = 2 * (256 + 256) * 128;   // two stages of the 256 x 256 ping-pong kernel
 
 int init_gemm_bf16_attrs() {
@@ -1181,6 +1185,7 @@ int init_gemm_bf16_attrs() {
     if ((rc = glds_attrs<128, 128>()) || (rc = glds_attrs<64, 64>()) || (rc = glds_attrs<128, 64>()) || (rc = glds_attrs<64, 128>())) return rc;
     RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
     RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
+    if ((rc = kp_attr<128, 128, 2>()) || (rc = kp_attr<64, 64, 4>()) || (rc = kp_attr<64, 64, 3>()) || (rc = kp_attr<128, 64, 3>()) || (rc = kp_attr<64, 128, 3>()) || (rc = pr_attrs())) return rc;
     done = true;
     return RGRG_OK;
 }
@@ -1257,8 +1262,19 @@ static bool pp_lm_head() {   // RGRG_GEMM_PP_LMHEAD=0: keep the decode lm_head o
 //   c_attn   (N 3072, K 1024)       64 x 64,   3 stages                                    15.7 us (128^2: 18.6)
 //   attn_proj (N 1024, K 1024)      64 x 64,   4 stages                                     8.1 us (2 stages: 14.4)
 //   mlp_proj (N 1024, K 4096)       64 x 64,   4 stages (long K: depth pays)               20.7 us (2 stages: 47)
+// shapes 6 .. 10: the K-parity ping-pong kernel (gemm_kp.inc): 6 = 128x128x2, 7 = 64x64x4, 8 = 128x64x3, 9 = 64x128x3,
+// 10 = 64x64x3, 11 = its (N, K) heuristic; 12 = the 128 x 128 row-split ping-pong kernel (gemm_kp.inc)
 static int launch_glds(const GemmBf16Params& p, int tile, hipStream_t st) {
     int shape = tile & 15, nst = tile >> 4;
+    switch (shape) {
+        case 6: return launch_kp_cfg<128, 128, 2>(p, st);
+        case 7: return launch_kp_cfg<64, 64, 4>(p, st);
+        case 8: return launch_kp_cfg<128, 64, 3>(p, st);
+        case 9: return launch_kp_cfg<64, 128, 3>(p, st);
+        case 10: return launch_kp_cfg<64, 64, 3>(p, st);
+        case 11: return launch_kp_auto(p, st);
+        case 12: return launch_pr(p, st);
+    }
     if (shape == 5) {
         if (!pp_eligible(p)) { set_error("bf16 GEMM: the 256 x 256 kernel does not take this variant"); return RGRG_EINVAL; }
         return launch_pp(p, st);
@@ -1328,6 +1344,7 @@ int launch_gemm_bf16w_ex(const float* A, const void* A16, const void* Wb, const 
         p.cand_val = ln->cand_val; p.cand_idx = ln->cand_idx;
         return launch_glds(p, 5, st);
     }
+    if (ln && ln->kp && A16 && (size_t)128 * K * 2 < ((size_t)1 << 31) && kp_eligible(p, 4)) return launch_glds(p, 11, st);
     if (A16 && (size_t)128 * K * 2 < ((size_t)1 << 31)) return launch_glds(p, 0, st);  // both operands bf16: LDS-DMA kernel
     // fp32 activations (rounded to bf16 while they are staged through registers)
     const long tiles_big = (long)((M + 127) / 128) * ((N + 127) / 128);
@@ -1432,6 +1449,18 @@ extern "C" int rgrg_debug_linear_bf16_ln(const uint16_t* A16, const uint16_t* Wb
     GemmLnFold f{};
     f.Yb16 = Yb16; f.stats_out = stats_out; f.ln_stats = ln_stats; f.ln_colsum = ln_colsum;
     return launch_gemm_bf16w_ex(nullptr, A16, Wb, shift, R, Y, nullptr, M, N, K, ldy, act, as_stream(stream), fp16, &f);
+}
+
+// The same on the K-parity ping-pong kernel (gemm_kp.inc), which the decoder selects for the many-sequence step: kp != 0.
+extern "C" int rgrg_debug_linear_bf16_ln_kp(const uint16_t* A16, const uint16_t* Wb, const float* shift, const float* R, float* Y,
+                                            uint16_t* Y16, uint16_t* Yb16, float* stats_out, const float* ln_stats, const float* ln_colsum,
+                                            int M, int N, int K, int ldy, int act, int fp16, int kp, void* stream) {
+    int rc = init_gemm_bf16_attrs();
+    if (rc) return rc;
+    RGRG_CHECK_ARG(A16 && Wb && ((Y != nullptr) != (Y16 != nullptr)));
+    GemmLnFold f{};
+    f.Yb16 = Yb16; f.stats_out = stats_out; f.ln_stats = ln_stats; f.ln_colsum = ln_colsum; f.kp = kp;
+    return launch_gemm_bf16w_ex(nullptr, A16, Wb, shift, R, Y, Y16, M, N, K, ldy, act, as_stream(stream), fp16, &f);
 }
 
 // nn.Conv2d (+ folded eval BatchNorm + residual + ReLU) as an implicit GEMM on the bf16 matrix core, for the detector

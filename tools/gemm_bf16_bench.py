@@ -14,7 +14,8 @@ from rgrg_amd import _hip  # noqa: E402
 
 SHAPES = [("c_attn", 3072, 1024, 0, False), ("attn_proj", 1024, 1024, 0, True), ("c_fc", 4096, 1024, 2, False),
           ("mlp_proj", 1024, 4096, 0, True), ("lm_head", 50257, 1024, 0, False)]
-SHAPE_NAMES = {0: "auto", 1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128"}
+SHAPE_NAMES = {0: "auto", 1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 5: "pp256x256", 6: "kp128x128x2", 7: "kp64x64x4", 8: "kp128x64x3",
+               9: "kp64x128x3", 10: "kp64x64x3", 11: "kp-auto", 12: "pr128x128x4"}
 
 
 def timed(call, n=20):
@@ -41,7 +42,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("M", nargs="?", type=int, default=923)
     ap.add_argument("--shapes", default=",".join(s[0] for s in SHAPES))
-    ap.add_argument("--tiles", default="0,1,2,3,4", help="shapes: 0 auto, 1 128x128, 2 64x64, 3 128x64, 4 64x128")
+    ap.add_argument("--tiles", default="0,1,2,3,4", help="shapes: 0 auto, 1 128x128, 2 64x64, 3 128x64, 4 64x128, 5 256x256 ping-pong, 6-11 K-parity ping-pong (gemm_kp.inc)")
     ap.add_argument("--stages", default="2,3,4")
     ap.add_argument("--pads", default="0")
     ap.add_argument("--iters", type=int, default=20)
@@ -90,7 +91,7 @@ def main():
             Ap = padded(A16, pad) if pad else A16
             Wp = torch.stack([padded(Wb[c], pad) for c in range(ncopy)]) if pad else Wb
             for shape in map(int, args.tiles.split(",")):
-                for nst in ([0] if shape == 0 else list(map(int, args.stages.split(",")))):
+                for nst in ([0] if shape == 0 or shape >= 5 else list(map(int, args.stages.split(",")))):
                     tile = shape + 16 * nst
 
                     def call(out=Y, r=R, a=act):
@@ -101,7 +102,7 @@ def main():
                     it[0] = -1
                     call(Y2, None, 0)
                     err = (Y2 - ref).abs().max().item()
-                    print(f"   {SHAPE_NAMES[shape]:8s} stages {nst} pad {pad:3d}  {us:7.1f} us {2.0 * M * N * K / us / 1e6:5.0f} TF/s  (err {err:.1e})",
+                    print(f"   {SHAPE_NAMES[shape]:11s} stages {nst} pad {pad:3d}  {us:7.1f} us {2.0 * M * N * K / us / 1e6:5.0f} TF/s  (err {err:.1e})",
                           flush=True)
 
 if __name__ == "__main__":
