@@ -212,6 +212,11 @@ int rgrg_decoder_set_precision(rgrg_decoder* d, int mode);
  *               with the labels of attention_mask == 0 positions ignored (:368-396); nan when no label is scored.
  * Runs on the decoder's stream between two event edges with `stream`; does not synchronise the host.  Work space
  * for S*T token rows is grown on demand (first call of a larger size allocates). */
+/* position_ids of the teacher-forced passes (src/language_model/language_model.py:293-307 embeds whatever it is given; the
+ * default is arange(T)): int64 device array of S * T entries (per sentence) or T entries (one row, broadcast over the
+ * sentences), consumed by the NEXT rgrg_decoder_lm_forward / rgrg_decoder_lm_loss_grad call; NULL restores the default.  Like the
+ * reference's, they index the TOKEN table (wte[position_ids], :307) and are range-checked on the device with the token ids. */
+int rgrg_decoder_set_lm_positions(rgrg_decoder* d, const int64_t* pos, int64_t n);
 int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, const int64_t* input_ids, const float* attention_mask,
                             int S, int T, float* logits_out, float* loss_out, void* stream);
 /* Replaces `language_model_loss.backward()` of the training loop (src/full_model/train_full_model.py:172-208) for the
@@ -253,9 +258,12 @@ int rgrg_dropout_mask_f32(uint64_t seed, uint32_t stream_id, float p, int64_t n,
  * tokens input_ids [S,T] (int64) go to cache slots past_len + 1 .. past_len + T; their embedding is wte[token] +
  * wte[position] with position = position_ids[s][j] (int64 [S,T] on the device, any values in [0, vocab): :293-307) or, when
  * position_ids is NULL, past_len + j (what prepare_inputs_for_generation passes, :498-520); each appends its key / value;
- * logits_out f32 [S,T,vocab] receives lm_logits of every fed position.  past_len + T <= the decoder's max_len.  All-ones
- * attention mask (generation).  Runs on the decoder's stream between two event edges with `stream`. */
+ * logits_out f32 [S,T,vocab] receives lm_logits of every fed position.  past_len + T <= the decoder's max_len.
+ * attention_mask: NULL (all ones: generation) or f32 [S][past_len + T] over ALL token keys so far - the reference adds
+ * (1 - mask) * -1e4 to the scores of a masked key for every query, the image key is never masked (:316-334).  Runs on the
+ * decoder's stream between two event edges with `stream`. */
 int rgrg_decoder_forward_cached(rgrg_decoder* d, const float* feats, const int64_t* input_ids, const int64_t* position_ids,
+                                const float* attention_mask,
                                 int S, int T, int past_len, float* logits_out, void* stream);
 /* Device address and geometry of one cache plane (layer, kv = 0 key / 1 value): f32 [max_seqs][16][slots][64]; the host
  * wraps rows [:S], slots [:1 + tokens] as the `presents` views of forward(use_cache=True) - no copy. */

@@ -160,13 +160,14 @@ def teacher_forced_trace(sd: SD, ids: Tensor, image_hidden_states: Tensor, bf16:
 
 @torch.no_grad()
 def lm_teacher_forced(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_states: Tensor,
-                      return_loss: bool = True, p: str = "language_model."):
-    """LanguageModel.forward(..., past_key_values=None, position_ids=None, use_cache=False) in eval mode
-    (:258-399): positions default to arange(T) (:298-300); with ``return_loss`` the labels are ``input_ids``
+                      return_loss: bool = True, p: str = "language_model.", position_ids: Optional[Tensor] = None):
+    """LanguageModel.forward(..., past_key_values=None, position_ids, use_cache=False) in eval mode
+    (:258-399): positions default to arange(T) (:298-300), given ones ([S,T] or [1,T]) are embedded as they are (:293-307);
+    with ``return_loss`` the labels are ``input_ids``
     with attention_mask == 0 positions set to -100, shifted one to the left, CrossEntropyLoss(ignore_index=-100)
     (:368-396).  Returns the scalar loss, or the logits [S,T,50257]."""
     S, T = input_ids.shape
-    pos = torch.arange(T, dtype=torch.long)[None, :]
+    pos = torch.arange(T, dtype=torch.long)[None, :] if position_ids is None else position_ids.view(-1, T)
     logits, _ = lm_forward(sd, input_ids, attention_mask.to(torch.int64) if attention_mask.dtype == torch.bool else attention_mask,
                            image_hidden_states, None, pos, p)
     if not return_loss:
@@ -187,7 +188,7 @@ def trainable_keys(p: str = "language_model.") -> List[str]:
 
 
 def lm_loss_and_grads(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_hidden_states: Tensor, p: str = "language_model.",
-                      drop_masks: Optional[Dict[Tuple[int, int], Tensor]] = None):
+                      drop_masks: Optional[Dict[Tuple[int, int], Tensor]] = None, position_ids: Optional[Tensor] = None):
     """``loss = LanguageModel.forward(return_loss=True); loss.backward()``: torch autograd through the restated forward.
     Dropout off (modules in eval mode, gradients enabled) unless explicit ``drop_masks`` are given.
     Returns (loss, {key: grad})."""
@@ -197,7 +198,7 @@ def lm_loss_and_grads(sd: SD, input_ids: Tensor, attention_mask: Tensor, image_h
         sd2[k] = sd[k].detach().clone().requires_grad_(True)
     with torch.enable_grad():
         S, T = input_ids.shape
-        pos = torch.arange(T, dtype=torch.long)[None, :]
+        pos = torch.arange(T, dtype=torch.long)[None, :] if position_ids is None else position_ids.view(-1, T)
         logits, _ = lm_forward(sd2, input_ids, attention_mask, image_hidden_states, None, pos, p, drop_masks)
         labels = input_ids.clone()
         labels[~attention_mask.to(torch.bool)] = -100

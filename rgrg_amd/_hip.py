@@ -63,7 +63,7 @@ SIGNATURES = {
     "rgrg_dropout_mask_f32": (_i, [C.c_uint64, C.c_uint32, C.c_float, C.c_int64, _i, _p, _p]),
     "rgrg_decoder_refresh_trainable": (_i, [_p, _p]),
     "rgrg_decoder_take_id_error": (_i, [_p, C.POINTER(_i)]),
-    "rgrg_decoder_forward_cached": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "rgrg_decoder_forward_cached": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "rgrg_decoder_cache_plane": (_i, [_p, _i, _i, C.POINTER(C.c_void_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "rgrg_transpose_pad_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "rgrg_colsum_f32": (_i, [_p, _p, _i, _i, _p]),
@@ -91,6 +91,7 @@ SIGNATURES = {
     "rgrg_fastrcnn_loss_f32": (_i, [_p, _i, _i, _p, _p, _i, _p, _p]),
     "rgrg_decoder_trace_step": (_i, [_p, _i, _i, _i, _p, _i, C.POINTER(_i)]),
     "rgrg_decoder_attention_only": (_i, [_p, _i, _i, _i, _p]),
+    "rgrg_decoder_set_lm_positions": (_i, [_p, _p, C.c_int64]),
     "rgrg_decoder_time_step_parts": (_i, [_p, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "rgrg_decoder_time_train_gemms": (_i, [_p, _i, _i, _i, C.POINTER(_f), C.POINTER(C.c_double), C.POINTER(_i)]),

@@ -452,21 +452,24 @@ __device__ __forceinline__ float group16_sum_dpp(float v) {  // sum over the 16 
 }
 
 // one chunk of 16 * NI keys starting at `base` (see the kernel below)
-template <bool HAS_SRC, int NI>
+template <bool HAS_SRC, int NI, bool HAS_MASK = false>
 __device__ __forceinline__ void attn_chunk(const float* __restrict__ kc, const float* __restrict__ vc, const int* __restrict__ srow, int s,
                                            int hd, int H, int T, int base, int nkeys, int slot, int wave, int g, int d4,
-                                           const f32x4& q4, const f32x4& k4, const f32x4& v4, float& m, float& l, f32x4& acc) {
+                                           const f32x4& q4, const f32x4& k4, const f32x4& v4, float& m, float& l, f32x4& acc,
+                                           const float* __restrict__ kmask = nullptr) {
     int rowi[NI];  // beam search: the table entries are the oldest loads of the chunk, so that waiting for them waits for nothing else
 #pragma unroll
     for (int i = 0; i < NI; ++i) rowi[i] = HAS_SRC ? srow[min(base + (i * 4 + wave) * 4 + g, nkeys - 1)] : s;
     // slot t + 1 of the table is stale: that key comes from k4 / v4 below
     f32x4 kk[NI], vv[NI];
+    float mk[NI];   // HAS_MASK: the additive padding mask of the key's slot, (1 - attention_mask) * -1e4 (language_model.py:325-334)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int jc = min(base + (i * 4 + wave) * 4 + g, nkeys - 1);
         const size_t off = (((size_t)rowi[i] * H + hd) * T + jc) * 64 + d4 * 4;
         kk[i] = *reinterpret_cast<const f32x4*>(kc + off);
         vv[i] = *reinterpret_cast<const f32x4*>(vc + off);
+        mk[i] = HAS_MASK ? kmask[(size_t)s * T + jc] : 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);  // all 2 * NI loads are in flight before the first dot product waits
     float sc[NI];
@@ -476,7 +479,7 @@ __device__ __forceinline__ void attn_chunk(const float* __restrict__ kc, const f
         const int j = base + (i * 4 + wave) * 4 + g;
         if (j == slot) { kk[i] = k4; vv[i] = v4; }  // selects, not branches: the new token's key / value
         const float dot = group16_sum_dpp((q4[0] * kk[i][0] + q4[1] * kk[i][1]) + (q4[2] * kk[i][2] + q4[3] * kk[i][3]));
-        sc[i] = j < nkeys ? dot / 8.0f : -INFINITY;
+        sc[i] = j < nkeys ? (HAS_MASK ? dot / 8.0f + mk[i] : dot / 8.0f) : -INFINITY;
         cmax = fmaxf(cmax, sc[i]);
     }
     const float m_new = fmaxf(m, cmax);
@@ -501,12 +504,15 @@ __device__ __forceinline__ void attn_chunk(const float* __restrict__ kc, const f
 // rows whatever the step, 2.2x what a 128-token decode needs on average); 2 when thousands of workgroups queue up
 // (throughput bound: fewer registers -> more resident workgroups).  A key's group and register do not depend on the
 // chunk size: results are unchanged bit for bit.
-template <bool HAS_SRC, int ATT_NI>  // HAS_SRC (beam search): per-slot ancestor table (one more dependent load per key, requested first)
+// HAS_MASK (round 6, forward(use_cache=True) with padding): kmask [S][T] = the additive mask of every cache slot (slot 0, the image,
+// holds 0); the default instantiation carries none of it.
+template <bool HAS_SRC, int ATT_NI, bool HAS_MASK = false>  // HAS_SRC (beam search): per-slot ancestor table (one more dependent load per key, requested first)
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                           float* __restrict__ kc, float* __restrict__ vc,
                                                           const int* __restrict__ step, float* __restrict__ out,
                                                           int S, int H, int T, const int* __restrict__ src, int frag_out,
-                                                          unsigned long long* __restrict__ stamps) {   // stamps: -DRGRG_SKINNY_STAMPS builds, else null
+                                                          unsigned long long* __restrict__ stamps,   // stamps: -DRGRG_SKINNY_STAMPS builds, else null
+                                                          const float* __restrict__ kmask = nullptr) {
     __shared__ float pm[16], pl[16];
     __shared__ __attribute__((aligned(16))) float pacc[16][64];
     SKS_DECL;
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     const f32x4 v4 = *reinterpret_cast<const f32x4*>(row + 2 * D + hd * 64 + d4 * 4);
     float m = -INFINITY, l = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#define ATT_CHUNK_CALL(NI_, BASE_) attn_chunk<HAS_SRC, NI_>(kc, vc, srow, s, hd, H, T, BASE_, nkeys, slot, wave, g, d4, q4, k4, v4, m, l, acc)
+#define ATT_CHUNK_CALL(NI_, BASE_) attn_chunk<HAS_SRC, NI_, HAS_MASK>(kc, vc, srow, s, hd, H, T, BASE_, nkeys, slot, wave, g, d4, q4, k4, v4, m, l, acc, kmask)
     if constexpr (ATT_NI == 9) {
         int base = 0;
         for (; nkeys - base > ATT_CHUNK; base += ATT_CHUNK) ATT_CHUNK_CALL(9, base);
@@ -1059,7 +1065,7 @@ __global__ __launch_bounds__(256) void beam_init_kernel(int* __restrict__ src, i
 __global__ __launch_bounds__(256) void embed_seq_ln_kernel(const float* __restrict__ wte, const long long* __restrict__ ids,
                                                            int T, const float* __restrict__ g, const float* __restrict__ b,
                                                            float* __restrict__ x, float* __restrict__ xn, int D, int V,
-                                                           int* __restrict__ id_error) {
+                                                           int* __restrict__ id_error, const long long* __restrict__ pos_ids, int pos_rows) {
     __shared__ float sh[4];
     const int row = blockIdx.x, tid = threadIdx.x;
     long long tok = ids[row];
@@ -1067,7 +1073,17 @@ __global__ __launch_bounds__(256) void embed_seq_ln_kernel(const float* __restri
         if (tid == 0) atomicOr(id_error, 1);
         tok = tok < 0 ? 0 : V - 1;
     }
-    const int pos = row % T;
+    // position_ids (language_model.py:293-307): default arange(T); given ones ([S,T], or [1,T] broadcast over the sentences:
+    // pos_rows = T) index the TOKEN table like the default ones do (the reference's wte[position_ids] quirk), so their range
+    // is the vocabulary's and they are checked like the token ids
+    long long pos = row % T;
+    if (pos_ids) {
+        pos = pos_ids[row % pos_rows];
+        if (pos < 0 || pos >= V) {
+            if (tid == 0) atomicOr(id_error, 1);
+            pos = pos < 0 ? 0 : V - 1;
+        }
+    }
     const f32x4 v = reinterpret_cast<const f32x4*>(wte + (size_t)tok * D)[tid] + reinterpret_cast<const f32x4*>(wte + (size_t)pos * D)[tid];
     reinterpret_cast<f32x4*>(x + (size_t)row * D)[tid] = v;
     reinterpret_cast<f32x4*>(xn + (size_t)row * D)[tid] = ln_row(v, g, b, sh, D);
@@ -1538,6 +1554,10 @@ struct rgrg_decoder {
     int sk_attn = 0, sk_mlp = 0; // K slices of attn_proj / mlp_proj there (RGRG_SK_ATTN / RGRG_SK_MLP; 0 or 1 = off)
     float* ln_stat = nullptr;   // [rows][16][2]: per-row (sum, sum of squares) slots (one per 64 columns) of the residual stream (folded LayerNorm)
     bool ln_fold = true;        // 16-bit path: LayerNorms folded into the GEMMs around them; RGRG_LN_FOLD=0: ln_rows launches (A/B)
+    float* key_mask = nullptr;             // [rows][T] additive padding mask of the cache slots (forward(use_cache=True) with padding)
+    const float* key_mask_cur = nullptr;   // set around the steps of rgrg_decoder_forward_cached when a mask was given
+    const long long* tf_pos = nullptr;   // position_ids of the NEXT teacher-forced pass (rgrg_decoder_set_lm_positions), [tf_pos_rows] int64
+    int tf_pos_rows = 1;
     // rgrg_decoder_trace_step: one hipEvent after every launch of an eagerly enqueued step, on the stream it was launched on
     struct TraceMark { hipEvent_t ev; int r0; int tag; };
     std::vector<TraceMark>* trace = nullptr;
@@ -1713,7 +1733,12 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
             const int ks = l.K >= 2048 ? d->sk_mlp : d->sk_attn;
             if (ks > 1) {
                 GemmLnFold f = *ln;
-                f.ksplit = ks; f.sk_ws = d->sk_ws; f.sk_cnt = d->sk_cnt;
+                // slabs and tickets are indexed by the launch-local tile id: a row range (enqueue_step runs several of them
+                // concurrently on forked streams) gets the slice of the work space that belongs to its first 64-row tile -
+                // ranges start on whole tiles, the allocation covers every tile of d->rows (shared slabs raced)
+                const size_t r0 = d->xn16 ? (size_t)(reinterpret_cast<const unsigned short*>(ln->Yb16) - d->xn16) / (size_t)d->D : 0;
+                const size_t tile0 = (r0 / 64) * (size_t)(l.N / 64);
+                f.ksplit = ks; f.sk_ws = d->sk_ws + tile0 * 4 * 4096; f.sk_cnt = d->sk_cnt + tile0;
                 return launch_gemm_bf16w_ex(nullptr, X16, l.wb, l.b, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream, d->f16(), &f);
             }
         }
@@ -1765,7 +1790,12 @@ static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsig
         const dim3 grid(S * d->H), blk(256);
 #define ATT_LAUNCH(SRC_, NI_) hipLaunchKernelGGL((attn_decode_kernel<SRC_, NI_>), grid, blk, 0, st, d->qkv, 3 * D, kc, vc, d->step, d->att, S, d->H, d->T, src, frag_out, \
                                                  stamp_slot(d, "attention", S * d->H))
-        if (S * d->H <= 4096) { if (src) ATT_LAUNCH(true, 9); else ATT_LAUNCH(false, 9); }
+        if (d->key_mask_cur && !src) {   // forward(use_cache=True) with a padded attention_mask (rgrg_decoder_forward_cached)
+#define ATT_LAUNCH_MASK(NI_) hipLaunchKernelGGL((attn_decode_kernel<false, NI_, true>), grid, blk, 0, st, d->qkv, 3 * D, kc, vc, d->step, d->att, S, d->H, d->T, \
+                                                  src, frag_out, (unsigned long long*)nullptr, d->key_mask_cur)
+            if (S * d->H <= 4096) ATT_LAUNCH_MASK(9); else ATT_LAUNCH_MASK(2);
+#undef ATT_LAUNCH_MASK
+        } else if (S * d->H <= 4096) { if (src) ATT_LAUNCH(true, 9); else ATT_LAUNCH(false, 9); }
         else { if (src) ATT_LAUNCH(true, 2); else ATT_LAUNCH(false, 2); }
 #undef ATT_LAUNCH
     }
@@ -2592,6 +2622,14 @@ extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int
 }
 
 namespace rgrg {
+// forward(use_cache=True): attention_mask [S][L] over the L = past_len + T token keys -> additive mask of the cache slots,
+// slot 0 (the image key) never masked (language_model.py:316-334: a ones column is concatenated in front)
+__global__ __launch_bounds__(256) void key_mask_kernel(const float* __restrict__ am, int L, int S, int T, float* __restrict__ kmask) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S * T) return;
+    const int s = i / T, j = i - s * T;
+    kmask[i] = (j >= 1 && j <= L) ? (1.0f - am[(size_t)s * L + (j - 1)]) * -10000.0f : 0.f;
+}
 __global__ void set_int_kernel(int* p, int v) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *p = v;
 }
@@ -2696,11 +2734,23 @@ static int tf_linear(rgrg_decoder* d, const Lin& l, const float* X, const float*
 }
 }  // namespace rgrg
 
+// position_ids of the teacher-forced passes (language_model.py:293-307): `pos` = int64 device array of S * T entries (per sentence)
+// or T entries (one row, broadcast), read by the NEXT rgrg_decoder_lm_forward / rgrg_decoder_lm_loss_grad call of that shape and
+// dropped by it; NULL = the default arange(T).  Like the token ids they index the token table (the reference's
+// wte[position_ids]) and are range-checked on the device.
+extern "C" int rgrg_decoder_set_lm_positions(rgrg_decoder* d, const int64_t* pos, int64_t n) {
+    RGRG_CHECK_ARG(d && (pos == nullptr || n > 0));
+    d->tf_pos = reinterpret_cast<const long long*>(pos);
+    d->tf_pos_rows = pos ? (int)n : 1;
+    return RGRG_OK;
+}
+
 extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, const int64_t* input_ids,
                                        const float* attention_mask, int S, int T, float* logits_out, float* loss_out,
                                        void* stream) {
     RGRG_CHECK_ARG(d && feats && input_ids && S > 0 && S <= d->max_seqs && T >= 1 && T <= TF_MAX_T && (logits_out || loss_out));
     RGRG_CHECK_ARG(!loss_out || T >= 2);
+    RGRG_CHECK_ARG(!d->tf_pos || d->tf_pos_rows == T || d->tf_pos_rows == S * T);   // rgrg_decoder_set_lm_positions: [T] or [S * T]
     const int D = d->D, M = S * T;
     int rc = check_id_error(d);
     if (rc) return rc;
@@ -2716,8 +2766,9 @@ extern "C" int rgrg_decoder_lm_forward(rgrg_decoder* d, const float* feats, cons
     if ((rc = linear(d, d->ukv, d->img, nullptr, d->ukv_out, S, d->ld_ukv, RGRG_ACT_NONE, false))) return rc;
     const long long* ids = reinterpret_cast<const long long*>(input_ids);
     hipLaunchKernelGGL(embed_seq_ln_kernel, dim3(M), dim3(256), 0, st, d->wte, ids, T, d->layers[0].ln1_g, d->layers[0].ln1_b,
-                       d->tf_x, d->tf_xn, D, d->V, d->id_error);
+                       d->tf_x, d->tf_xn, D, d->V, d->id_error, d->tf_pos, d->tf_pos_rows);
     RGRG_LAUNCH_CHECK();
+    d->tf_pos = nullptr; d->tf_pos_rows = 1;   // consumed (rgrg_decoder_set_lm_positions)
     for (int l = 0; l < d->n_layer; ++l) {
         const LayerW& w = d->layers[l];
         const float* ng = (l + 1 < d->n_layer) ? d->layers[l + 1].ln1_g : d->lnf_g;
@@ -2942,8 +2993,9 @@ static int tr_body16(rgrg_decoder* d, const long long* ids, const float* attenti
     if (a16 && (rc = convert_f32_to_bf16(d->ukv_out, d->tr_ukv16, (size_t)S * LD, st, f16))) return rc;
 
     hipLaunchKernelGGL(embed_seq_ln_kernel, dim3(M), dim3(256), 0, st, d->wte, ids, T, d->layers[0].ln1_g, d->layers[0].ln1_b,
-                       xs(0), d->tf_xn, D, d->V, d->id_error);
+                       xs(0), d->tf_xn, D, d->V, d->id_error, d->tf_pos, d->tf_pos_rows);
     RGRG_LAUNCH_CHECK();
+    d->tf_pos = nullptr; d->tf_pos_rows = 1;   // consumed (rgrg_decoder_set_lm_positions)
     // self.drop on the embeddings (language_model.py:311) and ln_1 of layer 0 as 16 bit
     if ((rc = launch_resid_dropout_ln16(xs(0), nullptr, nullptr, xs(0), d->layers[0].ln1_g, d->layers[0].ln1_b, d->tr_xn16, dp(0, 0), f16, M, D, st)))
         return rc;
@@ -3039,6 +3091,7 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
                    grad_fst2_b);
     RGRG_CHECK_ARG(S > 0 && S <= d->max_seqs && T >= 2 && T <= TF_MAX_T);
     RGRG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f);
+    RGRG_CHECK_ARG(!d->tf_pos || d->tf_pos_rows == T || d->tf_pos_rows == S * T);   // rgrg_decoder_set_lm_positions: [T] or [S * T]
     const int D = d->D, M = S * T, L = d->n_layer, V = d->V, VP = pad256(V), Sp = pad32(S), LD = d->ld_ukv;
     int rc;
     if ((rc = check_id_error(d))) return rc;
@@ -3063,8 +3116,9 @@ extern "C" int rgrg_decoder_lm_loss_grad(rgrg_decoder* d, const float* feats, co
         if ((rc = tr_body16(d, ids, attention_mask, S, T, loss_scale, dropout_p, dropout_seed, loss_out))) return rc;
     } else {
     hipLaunchKernelGGL(embed_seq_ln_kernel, dim3(M), dim3(256), 0, st, d->wte, ids, T, d->layers[0].ln1_g, d->layers[0].ln1_b,
-                       xs(0), d->tf_xn, D, d->V, d->id_error);
+                       xs(0), d->tf_xn, D, d->V, d->id_error, d->tf_pos, d->tf_pos_rows);
     RGRG_LAUNCH_CHECK();
+    d->tf_pos = nullptr; d->tf_pos_rows = 1;   // consumed (rgrg_decoder_set_lm_positions)
     if (dropout_p > 0.f) {  // self.drop on the embeddings (language_model.py:311), then ln_1 of layer 0 again
         if ((rc = launch_dropout_add(xs(0), nullptr, xs(0), MD, DropoutParams{dropout_seed, 0u, dropout_p}, st))) return rc;
         hipLaunchKernelGGL(ln_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, xs(0), d->layers[0].ln1_g,
@@ -3244,7 +3298,7 @@ extern "C" int rgrg_decoder_time_train_gemms(rgrg_decoder* d, int S, int T, int 
 // are fed one position at a time (position = past_len + j; wte[token] + wte[position], :298-307), each appending its
 // key / value to the cache; logits_out [S, T, vocab] receives lm_head of every fed position.  No arg-max, no EOS bookkeeping.
 extern "C" int rgrg_decoder_forward_cached(rgrg_decoder* d, const float* feats, const int64_t* input_ids, const int64_t* position_ids,
-                                           int S, int T, int past_len, float* logits_out, void* stream) {
+                                           const float* attention_mask, int S, int T, int past_len, float* logits_out, void* stream) {
     RGRG_CHECK_ARG(d && input_ids && logits_out && S > 0 && S <= d->max_seqs && T >= 1 && past_len >= 0);
     // feats == NULL with past_len == 0: the caller put a past that holds ONLY the image slot into the cache (a foreign
     // past_key_values of shape [.., 1, 64], language_model.py:162-166 uses the supplied past and ignores the image then)
@@ -3256,14 +3310,21 @@ extern "C" int rgrg_decoder_forward_cached(rgrg_decoder* d, const float* feats, 
     int rc;
     d->logits_stale_rows = 0;   // every step below writes d->logits
     if (past_len == 0 && feats && (rc = enqueue_prefill(d, feats, S))) return rc;   // also resets the step counter to 0
+    if (attention_mask) {   // [S][past_len + T]: padding inside the prompt / the past -> additive mask per cache slot
+        if (!d->key_mask && (rc = dmalloc(d, (void**)&d->key_mask, (size_t)d->rows * d->T * sizeof(float), true))) return rc;
+        hipLaunchKernelGGL(key_mask_kernel, dim3((S * d->T + 255) / 256), dim3(256), 0, st, attention_mask, past_len + T, S, d->T, d->key_mask);
+        RGRG_LAUNCH_CHECK();
+    }
     for (int j = 0; j < T; ++j) {
         hipLaunchKernelGGL(forward_cached_tokens_kernel, dim3((S + 255) / 256), dim3(256), 0, st,
                            reinterpret_cast<const long long*>(input_ids), reinterpret_cast<const long long*>(position_ids), T, j, S, d->V,
                            d->beam_tok, d->row_pos, d->step, past_len + j);
         RGRG_LAUNCH_CHECK();
         d->pos_override_cur = position_ids ? d->row_pos : nullptr;   // embedding rows wte[position_ids[s][j]]; the cache slot stays past_len + j + 1
+        d->key_mask_cur = attention_mask ? d->key_mask : nullptr;
         rc = enqueue_step(d, S, false, d->beam_tok, nullptr, true);   // ... lm_head: logits, nothing else
         d->pos_override_cur = nullptr;
+        d->key_mask_cur = nullptr;
         if (rc) return rc;
         RGRG_HIP(hipMemcpy2DAsync(logits_out + (size_t)j * d->V, (size_t)T * d->V * sizeof(float), d->logits,
                                   (size_t)d->ld_logits * sizeof(float), (size_t)d->V * sizeof(float), S, hipMemcpyDeviceToDevice, st));

@@ -26,30 +26,35 @@ def shard_bounds(n_images: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def generate_sharded(model, images_local: torch.Tensor, max_length: Optional[int], group: Optional[dist.ProcessGroup] = None,
-                     equal_shards: bool = True) -> GenerateOutput:
+                     equal_shards: bool = True, gather_device: Optional[torch.device] = None) -> GenerateOutput:
     """``generate()`` of the whole (rank-order concatenated) batch: every rank runs the three
     stages on its own image shard, then ONE all_gather assembles the single-process result.
 
     The collective has a fixed shape, so it needs the same number of images on every rank and a bound on the
     sequence length.  When the caller cannot promise the former (``equal_shards=False``: ``shard_bounds`` of a batch
     that does not divide by the world size) or gives no ``max_length`` (the reference's greedy search then runs until
-    every row has emitted EOS), one extra 2-word all_reduce(MAX) agrees on the padded shard size and length first."""
+    every row has emitted EOS), one extra 2-word all_reduce(MAX) agrees on the padded shard size and length first.
+
+    ``gather_device``: where the collectives run (default: the images' device - RCCL).  ``torch.device("cpu")`` stages the
+    payload through host memory for a process group whose backend cannot take device tensors (gloo: several ranks on one
+    GPU, tests/test_gpu_dist2.py); the returned tensors live on the images' device either way."""
     _, detections, top_region_features, class_detected = model.object_detector(images_local)
     selected, feats = model.binary_classifier_region_selection(top_region_features, class_detected, return_loss=False)
     ids = model.language_model.generate(feats, max_length) if feats.shape[0] > 0 else None
     n_pad = images_local.shape[0]
     if max_length is None or not equal_shards:
-        t = torch.tensor([0 if ids is None else ids.shape[1], n_pad], dtype=torch.int64, device=images_local.device)
+        t = torch.tensor([0 if ids is None else ids.shape[1], n_pad], dtype=torch.int64, device=gather_device or images_local.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         if max_length is None:
             max_length = max(int(t[0]), 1)
         n_pad = int(t[1])
-    return gather_generate_outputs(ids, selected, detections, class_detected, max_length, images_local.device, group, n_pad)
+    return gather_generate_outputs(ids, selected, detections, class_detected, max_length, images_local.device, group, n_pad, gather_device)
 
 
 def gather_generate_outputs(out_ids: Optional[torch.Tensor], sel: torch.Tensor, det: Dict[str, torch.Tensor],
                             cd: torch.Tensor, max_length: int, device: torch.device,
-                            group: Optional[dist.ProcessGroup] = None, n_pad: Optional[int] = None) -> GenerateOutput:
+                            group: Optional[dist.ProcessGroup] = None, n_pad: Optional[int] = None,
+                            gather_device: Optional[torch.device] = None) -> GenerateOutput:
     """All-gather the per-rank stage outputs (``out_ids`` is None when the rank selected no
     region) into what a single process would have returned for the concatenated batch.
 
@@ -57,7 +62,7 @@ def gather_generate_outputs(out_ids: Optional[torch.Tensor], sel: torch.Tensor, 
     per-image record (selected | detected | score bits | box bits | valid | L'), ~31 KB per image, so there
     is exactly one collective; ``n_pad`` >= the local image count pads short shards with invalid images that are
     dropped again after the gather.  The single-process L' is the longest row of the WHOLE batch:
-    after the gather the ids are trimmed to the global maximum length."""
+    after the gather the ids are trimmed to the global maximum length.  ``gather_device``: see ``generate_sharded``."""
     world = dist.get_world_size(group)
     n_local_images = sel.shape[0]
     n_pad = n_local_images if n_pad is None else int(n_pad)
@@ -74,28 +79,28 @@ def gather_generate_outputs(out_ids: Optional[torch.Tensor], sel: torch.Tensor, 
         ids[: out_ids.shape[0], : out_ids.shape[1]] = out_ids
         meta[:, 204] = out_ids.shape[1]
     payload = torch.cat([ids.view(n_pad, -1), meta], dim=1).contiguous()
+    if gather_device is not None and torch.device(gather_device) != payload.device:
+        payload = payload.to(gather_device)
     gathered = [torch.empty_like(payload) for _ in range(world)]
     dist.all_gather(gathered, payload, group=group)
-    allp = torch.cat(gathered, 0)
-    ids_all = allp[:, : NUM_REGIONS * max_length].reshape(world * n_pad, NUM_REGIONS, max_length)
+    allp = torch.cat(gathered, 0).to(device)
+    ids_all = allp[:, : NUM_REGIONS * max_length].reshape(world, n_pad * NUM_REGIONS, max_length)
     meta_all = allp[:, NUM_REGIONS * max_length:]
     valid = meta_all[:, 203].bool()
     sel_pad = meta_all[:, 0:29].bool()
-    if int(sel_pad.sum()) == 0:
+    # each rank's rows are compact (its selected regions first): re-compact over the whole batch - the first n_sel[r] rows of
+    # every rank's block, in rank order, picked with ONE mask (one host sync, whatever the world size)
+    n_sel = sel_pad.view(world, -1).sum(1)
+    keep = torch.arange(n_pad * NUM_REGIONS, device=device)[None, :] < n_sel[:, None]
+    rows = ids_all[keep]
+    if rows.shape[0] == 0:
         return -1
-    # each rank's rows are compact (its selected regions first): re-compact over the whole batch
-    out_rows = []
-    for r in range(world):
-        blk = slice(r * n_pad, (r + 1) * n_pad)
-        n_sel = int(sel_pad[blk].sum())
-        out_rows.append(ids_all[blk].reshape(-1, max_length)[:n_sel])
     L = int(meta_all[:, 204].max())
     m = meta_all[valid]
     n_img = m.shape[0]
     scores = m[:, 58:87].to(torch.int32).view(torch.float32)
     boxes = m[:, 87:203].to(torch.int32).view(torch.float32).view(n_img, NUM_REGIONS, 4)
-    return (torch.cat(out_rows, 0)[:, :L].contiguous(), m[:, 0:29].bool(), {"top_region_boxes": boxes, "top_scores": scores},
-            m[:, 29:58].bool())
+    return (rows[:, :L].contiguous(), m[:, 0:29].bool(), {"top_region_boxes": boxes, "top_scores": scores}, m[:, 29:58].bool())
 
 
 class GradBuckets:
@@ -139,6 +144,7 @@ class GradBuckets:
         self._hooks = None
         self._pending = None
         self._works = None
+        self._group = None
         self._order = list(reversed(range(len(self.buckets))))   # autograd reaches the LAST parameters first (DDP's bucket order)
         self.launch_log = []        # bucket indices in the order their reduction was issued during the last step
 
@@ -165,6 +171,9 @@ class GradBuckets:
         self._hooks = None
 
     def begin_step(self) -> None:
+        """One backward pass per ``begin_step()``: a second one (gradient accumulation) would find its buckets reduced already."""
+        if not self.owns_all_grads():   # before any collective of the step is issued: raising later would strand the other ranks
+            raise RuntimeError("GradBuckets: a .grad no longer points into the flat buckets (use zero() / zero_grad(set_to_none=False))")
         self._pending = list(self._sizes)
         self._works = {}
         self._next = 0
@@ -184,6 +193,9 @@ class GradBuckets:
             return
         bi = self._owner[id(p)]
         self._pending[bi] -= 1
+        if self._pending[bi] < 0:
+            raise RuntimeError("GradBuckets: a second backward pass after begin_step() - this bucket's all-reduce has been issued already; "
+                               "accumulate micro-steps before begin_step(), or call it once per backward")
         if self._pending[bi] == 0:
             self._issue_ready()
 
@@ -193,15 +205,16 @@ class GradBuckets:
             return 0
         if self._pending is None:
             raise RuntimeError("GradBuckets.finish() without begin_step()")
-        if not self.owns_all_grads():
-            raise RuntimeError("GradBuckets: a .grad no longer points into the flat buckets (use zero() / zero_grad(set_to_none=False))")
-        self._issue_ready(force=True)
+        owned = self.owns_all_grads()
+        self._issue_ready(force=True)   # every rank issues every bucket, whatever happened on this one
         world = dist.get_world_size(self._group)
         for bi, w in self._works.items():
             w.wait()
             if average and world > 1:
                 self.buckets[bi].div_(world)
         self._pending = None
+        if not owned:   # after the collectives: the other ranks are not left waiting for this one
+            raise RuntimeError("GradBuckets: a .grad stopped pointing into the flat buckets during the step (zero_grad(set_to_none=True)?)")
         return len(self._works)
 
     def owns_all_grads(self) -> bool:
@@ -209,18 +222,23 @@ class GradBuckets:
         spans = [(f.data_ptr(), f.data_ptr() + f.numel() * f.element_size()) for f in self.buckets]
         return all(p.grad is not None and any(lo <= p.grad.data_ptr() < hi for lo, hi in spans) for p in self.params)
 
-    def allreduce(self, group=None, average: bool = True) -> int:
+    def allreduce(self, group=None, average: bool = True, via_host: bool = False) -> int:
         """Sum (average) the buckets over the ranks with asynchronous all-reduces (RCCL over xGMI: a ring moves
         2(N-1)/N x 215 MB per rank per step; large buckets keep the per-link ring efficient).  The HIP backward is one
-        fused call per module, so there is nothing to overlap the reduction with except the other buckets."""
+        fused call per module, so there is nothing to overlap the reduction with except the other buckets.
+        ``via_host``: stage every bucket through host memory (a process group that cannot take device tensors - gloo with
+        several ranks on one GPU, tests/test_gpu_dist2.py)."""
         if not (dist.is_available() and dist.is_initialized()):
             return 0
         if not self.owns_all_grads():
             raise RuntimeError("GradBuckets: a .grad no longer points into the flat buckets (use zero() / zero_grad(set_to_none=False))")
         world = dist.get_world_size(group)
-        works = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True) for flat in self.buckets]
-        for w, flat in zip(works, self.buckets):
+        bufs = [flat.cpu() for flat in self.buckets] if via_host else self.buckets
+        works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True) for b in bufs]
+        for w, b, flat in zip(works, bufs, self.buckets):
             w.wait()
+            if via_host:
+                flat.copy_(b)
             if average and world > 1:
                 flat.div_(world)
         return len(self.buckets)

@@ -762,8 +762,20 @@ class HipEngine:
                 raise IndexError(str(e)) from None
             raise
 
+    def _set_lm_positions(self, dec, position_ids: Optional[Tensor], S: int, T: int, device):
+        """``position_ids`` of a teacher-forced pass ([S,T], or anything that views as [1,T]; None = arange(T)): handed to the
+        decoder for its next pass; the tensor is returned so that the caller keeps it alive across the launch."""
+        if position_ids is None:
+            _hip.check(self.lib.rgrg_decoder_set_lm_positions(dec, None, 0), "rgrg_decoder_set_lm_positions")
+            return None
+        pos = position_ids.reshape(-1, T).to(device=device, dtype=torch.int64).contiguous()
+        if pos.shape[0] not in (1, S):
+            raise ValueError(f"position_ids has {pos.shape[0]} rows, expected 1 or {S}")
+        _hip.check(self.lib.rgrg_decoder_set_lm_positions(dec, _hip.ptr(pos), pos.numel()), "rgrg_decoder_set_lm_positions")
+        return pos
+
     def lm_forward(self, feats: Tensor, input_ids: Tensor, attention_mask: Optional[Tensor], want_logits: bool = False,
-                   want_loss: bool = True, bf16=False) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+                   want_loss: bool = True, bf16=False, position_ids: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Optional[Tensor]]:
         """LanguageModel.forward without cache (teacher forcing): feats [S,1024], input_ids int64 [S,T],
         attention_mask [S,T] -> (logits f32 [S,T,V] or None, loss f32 scalar tensor or None)."""
         _require_gpu(feats.device)
@@ -781,6 +793,7 @@ class HipEngine:
         am = None if attention_mask is None else attention_mask.to(torch.float32).contiguous()
         logits = torch.empty((S, T, self.vocab), dtype=torch.float32, device=feats.device) if want_logits else None
         loss = torch.empty((), dtype=torch.float32, device=feats.device) if want_loss else None
+        _pos = self._set_lm_positions(dec, position_ids, S, T, feats.device)  # noqa: F841 (kept alive across the launch)
         self._check_ids(self.lib.rgrg_decoder_lm_forward(dec, _hip.ptr(feats), _hip.ptr(ids), None if am is None else _hip.ptr(am),
                                                          S, T, None if logits is None else _hip.ptr(logits),
                                                          None if loss is None else _hip.ptr(loss), self._s()),
@@ -788,7 +801,7 @@ class HipEngine:
         return logits, loss
 
     def lm_loss_grad(self, feats: Tensor, input_ids: Tensor, attention_mask: Optional[Tensor], loss_scale: float = 1.0,
-                     bf16=False, dropout_p: float = 0.0, dropout_seed: int = 0):
+                     bf16=False, dropout_p: float = 0.0, dropout_seed: int = 0, position_ids: Optional[Tensor] = None):
         """Teacher-forced loss and its gradients w.r.t. the trainable decoder weights (rgrg_decoder_lm_loss_grad):
         -> (loss, {"ukv_w" [L*2*1024,1024], "ukv_b", "fst0_w", "fst0_b", "fst2_w", "fst2_b"}).  bf16=True (torch.autocast,
         as the reference's training loop uses): the frozen-weight GEMMs of forward and backward run on the bf16 MFMA
@@ -812,6 +825,7 @@ class HipEngine:
              "fst2_w": torch.empty((1024, 1024), dtype=torch.float32, device=dev), "fst2_b": torch.empty((1024,), dtype=torch.float32, device=dev)}
         loss = torch.empty((), dtype=torch.float32, device=dev)
         self.last_train_shape = (int(S), int(T))   # (sentences, tokens) of the last training pass: bench.py times its GEMMs at this shape
+        _pos = self._set_lm_positions(dec, position_ids, S, T, dev)  # noqa: F841 (kept alive across the launch)
         self._check_ids(self.lib.rgrg_decoder_lm_loss_grad(dec, _hip.ptr(feats), _hip.ptr(ids), None if am is None else _hip.ptr(am), S, T,
                                                            float(loss_scale), float(dropout_p), int(dropout_seed) & (2 ** 64 - 1), _hip.ptr(loss),
                                                            _hip.ptr(g["ukv_w"]), _hip.ptr(g["ukv_b"]),
@@ -862,7 +876,7 @@ class HipEngine:
         return max(2, min(int(want), fit))
 
     def forward_cached(self, feats: Optional[Tensor], input_ids: Tensor, past_len: int, cache_len: int = 1024,
-                       position_ids: Optional[Tensor] = None, adopt_past=None):
+                       position_ids: Optional[Tensor] = None, adopt_past=None, attention_mask: Optional[Tensor] = None):
         """LanguageModel.forward(use_cache=True[, past_key_values]) over the decoder's K/V cache (rgrg_decoder_forward_cached):
         feeds input_ids [S,T] into cache slots past_len + 1 .. past_len + T -> (logits f32 [S,T,V], presents) where presents is
         the reference's tuple of 24 (key, value) pairs, each a VIEW [S,16,1 + past_len + T,64] of the cache.  ``position_ids``
@@ -870,7 +884,8 @@ class HipEngine:
         past_len + j.  ``adopt_past``: a FOREIGN past_key_values (24 pairs of [S,16,1 + past_len,64] tensors that are not views of
         this decoder's cache, e.g. clones or another model's presents): copied into the cache first.  ``cache_len`` = token slots
         to provide for when the cache is created: the reference's 1024 positions, clipped to what half of the free device memory
-        holds for this many rows."""
+        holds for this many rows.  ``attention_mask`` [S, past_len + T] (None: all ones): keys whose entry is 0 get the
+        reference's additive -1e4 for every query (language_model.py:316-334); the image key is never masked."""
         S, T = input_ids.shape
         # torch.nn.Embedding raises on an id outside the vocabulary in the same call; so does this path (one read-back: it is
         # the incremental API, not the generate loop)
@@ -934,8 +949,13 @@ class HipEngine:
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
         f = None if (past_len or feats is None) else feats.to(torch.float32).contiguous()
         logits = torch.empty((S, T, self.vocab), dtype=torch.float32, device=self.device)
-        _hip.check(self.lib.rgrg_decoder_forward_cached(dec, _hip.ptr(f), _hip.ptr(ids), _hip.ptr(pos), S, T, int(past_len), _hip.ptr(logits),
-                                                        self._s()), "rgrg_decoder_forward_cached")
+        am = None
+        if attention_mask is not None:
+            am = attention_mask.to(device=self.device, dtype=torch.float32).reshape(S, -1).contiguous()
+            if am.shape[1] != past_len + T:   # the reference broadcasts [S,1,1,1+L] against scores [S,16,T,1+past+T]
+                raise ValueError(f"attention_mask covers {am.shape[1]} tokens, the keys of this call are {past_len} cached + {T} new")
+        _hip.check(self.lib.rgrg_decoder_forward_cached(dec, _hip.ptr(f), _hip.ptr(ids), _hip.ptr(pos), _hip.ptr(am), S, T, int(past_len),
+                                                        _hip.ptr(logits), self._s()), "rgrg_decoder_forward_cached")
         self._cached["tokens"] = past_len + T
         return logits, self._cache_views(dec, S, 1 + past_len + T)
 

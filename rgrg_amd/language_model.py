@@ -83,11 +83,11 @@ class _TeacherForcedLoss(torch.autograd.Function):
     feature_space_transformation_nn) to autograd, scaled by the incoming gradient."""
 
     @staticmethod
-    def forward(ctx, lm, input_ids, attention_mask, feats, *params):
+    def forward(ctx, lm, input_ids, attention_mask, feats, position_ids, *params):
         low = _hip.autocast_mode()
         lm.dropout_seed += 1  # a fresh counter-based stream per pass
         loss, g = lm.engine().lm_loss_grad(feats, input_ids, attention_mask, bf16=low, dropout_p=float(lm.dropout_p),
-                                           dropout_seed=lm.pass_dropout_seed())
+                                           dropout_seed=lm.pass_dropout_seed(), position_ids=position_ids)
         D, grads = 1024, []
         for l in range(len(lm.gpt.h)):  # same order as LanguageModel.trainable_parameters()
             grads += [g["ukv_w"][(2 * l) * D:(2 * l + 1) * D], g["ukv_b"][(2 * l) * D:(2 * l + 1) * D],
@@ -98,7 +98,7 @@ class _TeacherForcedLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        return (None, None, None, None) + tuple(g * grad_out for g in ctx.grads)
+        return (None, None, None, None, None) + tuple(g * grad_out for g in ctx.grads)
 
 
 class LanguageModel(EngineOwner):
@@ -133,17 +133,14 @@ class LanguageModel(EngineOwner):
                 return_loss: bool = False, past_key_values=None, position_ids: Optional[torch.LongTensor] = None,
                 use_cache: Optional[bool] = False):
         """Teacher-forced pass of language_model.py:258-399 in eval mode (LM part):
-        ``return_loss=True`` -> the scalar language-modelling loss (float32 tensor).  Like the reference, the
+        ``return_loss=True`` -> the scalar language-modelling loss (float32 tensor); ``position_ids`` ([S,T] or [1,T]; default
+        arange(T)) are embedded as given - through the token table, the reference's quirk (:293-307).  Like the reference, the
         positions of ``input_ids`` whose ``attention_mask`` is 0 are overwritten with -100 IN PLACE (:371-374),
         and ``return_loss=False, use_cache=False`` returns None (:396-399).  The incremental
         ``use_cache=True`` form belongs to the reference's own generate loop; here ``generate()`` owns the cache.
         In ``train()`` mode with gradients enabled the returned loss carries a ``grad_fn`` (HIP backward pass)."""
         if past_key_values is not None or use_cache:
             return self._forward_cached(input_ids, attention_mask, image_hidden_states, return_loss, past_key_values, position_ids)
-        if position_ids is not None:
-            T = input_ids.shape[-1]
-            if not torch.equal(position_ids.view(-1, T).cpu(), torch.arange(T).view(1, T).expand(position_ids.view(-1, T).shape[0], T)):
-                raise NotImplementedError("only the default position_ids = arange(seq_len) are supported")
         if not return_loss:
             return None
         ids2 = input_ids.view(-1, input_ids.shape[-1])
@@ -153,11 +150,12 @@ class LanguageModel(EngineOwner):
             # (what the reference trains in the decoder).  GPT-2's four dropout sites are active with self.dropout_p
             # (0.1 as in the reference; 0 = deterministic), bf16 GEMMs under torch.autocast.
             self.sync_trainable_if_stale()
-            loss = _TeacherForcedLoss.apply(self, ids2, am2, image_hidden_states, *self.trainable_parameters())
+            loss = _TeacherForcedLoss.apply(self, ids2, am2, image_hidden_states, position_ids, *self.trainable_parameters())
         else:
             self.sync_trainable_if_stale()
             low = _hip.autocast_mode()
-            _, loss = self.engine().lm_forward(image_hidden_states, ids2, am2, want_logits=False, want_loss=True, bf16=low)
+            _, loss = self.engine().lm_forward(image_hidden_states, ids2, am2, want_logits=False, want_loss=True, bf16=low,
+                                               position_ids=position_ids)
         ids2[~am2.to(torch.bool)] = -100  # the reference's in-place label write (labels IS input_ids)
         return loss
 
@@ -170,8 +168,9 @@ class LanguageModel(EngineOwner):
         ``position_ids`` may be anything the embedding table holds ([S,T] or [1,T]; default, as in the reference :293-304,
         arange(past_length, past_length + T) where past_length counts the image key when a past is given), and a FOREIGN
         ``past_key_values`` (clones, tensors of another model instance) is copied into the cache and continued from.  Still
-        raised: stale views of this decoder's own cache (generate() or another call chain has rewritten it since), padding
-        inside the prompt, train mode, a loss."""
+        raised: stale views of this decoder's own cache (generate() or another call chain has rewritten it since), train mode, a
+        loss.  Round 6: an ``attention_mask`` with zeros ([S, past + T], padding inside the prompt or the past) adds the
+        reference's -1e4 to the scores of the masked keys (:316-334)."""
         if return_loss or self.training:
             raise NotImplementedError("forward(use_cache=True) is the generation form: eval mode, return_loss=False")
         self.sync_trainable_if_stale()
@@ -190,13 +189,14 @@ class LanguageModel(EngineOwner):
                                               "been rewritten since)")
                 adopt = past_key_values
                 past = int(past_key_values[0][0].shape[-2]) - 1   # slot 0 = the image key
+        am = None
         if attention_mask is not None and not bool((attention_mask.reshape(S, -1) != 0).all()):
-            raise NotImplementedError("forward(use_cache=True) supports the all-ones attention mask of generation only")
+            am = attention_mask   # padding inside the prompt / the past: the reference's additive -1e4 per masked key (:316-334)
         if position_ids is None and past_key_values is not None:
             # the reference's default counts the image key: arange(past_length, past_length + T), past_length = keys in the cache
             position_ids = torch.arange(past + 1, past + 1 + T).view(1, T)
         return eng.forward_cached(image_hidden_states if (past == 0 and adopt is None) else None, ids2, past, position_ids=position_ids,
-                                  adopt_past=adopt)
+                                  adopt_past=adopt, attention_mask=am)
 
     def trainable_parameters(self):
         """uk/uv of every layer, then feature_space_transformation_nn: the language-model tensors the reference
@@ -228,9 +228,10 @@ class LanguageModel(EngineOwner):
 
     @torch.no_grad()
     def teacher_forced_logits(self, input_ids: torch.LongTensor, attention_mask: torch.FloatTensor,
-                              image_hidden_states: torch.FloatTensor) -> torch.FloatTensor:
+                              image_hidden_states: torch.FloatTensor, position_ids: Optional[torch.LongTensor] = None) -> torch.FloatTensor:
         """lm_logits [S,T,50257] of the same pass (what the reference returns next to ``presents``, :398-399)."""
-        logits, _ = self.engine().lm_forward(image_hidden_states, input_ids, attention_mask, want_logits=True, want_loss=False)
+        logits, _ = self.engine().lm_forward(image_hidden_states, input_ids, attention_mask, want_logits=True, want_loss=False,
+                                             position_ids=position_ids)
         return logits
 
     @torch.no_grad()

@@ -184,7 +184,7 @@ def test_training_and_preprocessing_host_modules_fail_loudly_without_a_gpu(model
         lm(ids, am, torch.zeros(2, 1024), return_loss=False, use_cache=True)
     with pytest.raises(NotImplementedError, match="return_loss=False"):
         lm(ids, am, torch.zeros(2, 1024), return_loss=True, use_cache=True)
-    with pytest.raises(NotImplementedError, match="position_ids"):
+    with pytest.raises(_hip.RgrgHipError, match="no CPU fallback"):          # round 6: position_ids are embedded as given - on the GPU
         lm(ids, am, torch.zeros(2, 1024), return_loss=True, position_ids=torch.ones((2, 5), dtype=torch.int64))
     assert lm(ids, am, torch.zeros(2, 1024), return_loss=False) is None   # language_model.py:396-399
     assert lm.dropout_p == 0.1                                            # GPT-2's train-mode dropout, as in the reference

@@ -194,7 +194,8 @@ def test_configs2_full_size_properties_batch32_bf16():
     assert torch.equal(pad(ids)[rows], pad(ids_p))
 
 
-def test_opt_in_split_k_of_the_decode_projections_matches_the_default_path():
+@pytest.mark.parametrize("S", [200, 600])
+def test_opt_in_split_k_of_the_decode_projections_matches_the_default_path(S):
     """VERDICT r04 item 1a was built and measured slower (profiles/r05_splitk_decode_ab.log), so it is opt-in: RGRG_SK_MLP /
     RGRG_SK_ATTN = K slices per tile of mlp_proj / attn_proj in the many-sequence 16-bit decode step (write-through slabs, one
     ticket per tile, the last arriver adds the slabs in slice order and runs the LayerNorm-producer epilogue).  Read once per
@@ -202,7 +203,8 @@ def test_opt_in_split_k_of_the_decode_projections_matches_the_default_path():
     sums are re-associated, which a 16-bit evaluation amplifies to its quantisation-noise level within a few layers,
     and a sequence whose arg-max flips on a near-tie continues with other inputs.  So: >= 90 % of the token ids identical, and on
     the sequences whose ids are identical throughout (same inputs at every step) the last-step logits within 2e-2 of their range -
-    the bounds of the 16-bit parity tests."""
+    the bounds of the 16-bit parity tests.  600 sequences (round 6): the step then runs as concurrent row ranges on
+    forked streams, each range with its own slice of the split-K slabs and tickets (they used to share one and raced)."""
     import os
     import subprocess
     import sys
@@ -212,11 +214,11 @@ def test_opt_in_split_k_of_the_decode_projections_matches_the_default_path():
         "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "from conftest import gpu_model\n"
         "m = gpu_model('ragged'); g = torch.Generator().manual_seed(9)\n"
-        "feats = torch.randn((200, 1024), generator=g).cuda()\n"
+        "feats = torch.randn((%d, 1024), generator=g).cuda()\n"
         "eng = m.engine()\n"
         "ids = eng.greedy_decode(feats, 6, bf16=1)\n"
-        "lg = eng.last_logits(200)\n"
-        "torch.save((ids.cpu(), lg.cpu()), sys.argv[1])\n" % (repo, os.path.join(repo, "tests")))
+        "lg = eng.last_logits(%d)\n"
+        "torch.save((ids.cpu(), lg.cpu()), sys.argv[1])\n" % (repo, os.path.join(repo, "tests"), S, S))
     res = {}
     with tempfile.TemporaryDirectory() as tmp:
         for name, env_add in (("off", {}), ("mlp2", {"RGRG_SK_MLP": "2", "RGRG_SK_ATTN": "2"}), ("mlp4", {"RGRG_SK_MLP": "4"})):

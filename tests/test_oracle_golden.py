@@ -184,6 +184,28 @@ def test_incremental_forward_oracle_matches_reference_cached_steps(sd_ragged):
         assert torch.equal(past[l][0], k) and torch.equal(past[l][1], v)
 
 
+def test_oracle_matches_reference_with_position_ids_and_with_padding(sd_ragged):
+    """lm_positions_padding.pt (tests/golden/make_golden_lm_positions_padding.py, round 6): the REAL reference's teacher-forced
+    pass with arbitrary position_ids (language_model.py:293-307) and its incremental form over a left-padded prompt
+    (additive -1e4 per masked key, :316-334) - the oracle reproduces both exactly."""
+    fx = load_golden("lm_positions_padding.pt")
+    assert fx["meta"]["oracle_matches_reference"] is True
+    for name, c in fx["teacher_forced"].items():
+        loss = o_lm.lm_teacher_forced(sd_ragged, c["input_ids"], c["attention_mask"], c["feats"], return_loss=True, position_ids=c["position_ids"])
+        assert torch.equal(loss, c["loss"]), name
+        assert abs(float(c["loss"]) - float(c["loss_default_positions"])) > 1e-3, name   # the positions matter
+        logits = o_lm.lm_teacher_forced(sd_ragged, c["input_ids"], c["attention_mask"], c["feats"], return_loss=False, position_ids=c["position_ids"])
+        assert torch.equal(torch.stack([logits[s, t] for s, t in c["probes"]]), c["probe_logits"]), name
+    c = fx["cached"]
+    l1, past = o_lm.lm_forward(sd_ragged, c["prompt"], c["mask"], c["feats"], None, c["position_ids"])
+    l2, past = o_lm.lm_forward(sd_ragged, c["next"], c["mask2"], c["feats"], past, c["position_ids2"])
+    assert torch.equal(l1[:, -1], c["logits_prompt_last"]) and torch.equal(l1[:, :, ::97], c["logits_prompt_probe"])
+    assert torch.equal(l2[:, -1], c["logits_next"])
+    for l, (k, v) in c["presents"].items():
+        assert torch.equal(past[l][0], k) and torch.equal(past[l][1], v)
+    assert c["unmasked_last_logit_gap"] > 0.1   # the mask matters
+
+
 def test_bf16_oracle_is_within_quantisation_noise_of_the_reference_under_autocast(sd_bench):
     """lm_autocast_bf16.pt: the REAL reference's LanguageModel.forward under torch.autocast(bfloat16) (CPU: the closest the
     real code runs here to the fp16 autocast its scripts use).  The bf16 mode of the oracle - the parity target of the HIP
