@@ -43,7 +43,7 @@ def pmc_traffic(family, S_dec, dtype):
     detector finds on the synthetic batch moves by one or two between builds).  -> (bytes per launch, "file:key") or
     (None, None) when there is none: the quoted number always names the profile it comes from."""
     import re
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # newest committed measurement that has the key
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # newest committed measurement that has the key
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 table = json.load(f)
@@ -68,10 +68,13 @@ def rooflines(eng, S_dec, dtype, max_length):
     algorithmic bytes = the fp32 weights of the step, each read once); above: MFMA bound (2 M N K flops against the
     dense peak of the compute dtype).  Attention is HBM bound on the K/V cache bytes it must read."""
     nkeys = (2 + (max_length + 1)) // 2
-    p = eng.time_step_parts(S_dec, nkeys, iters=10)   # (3 replays read 3-6 % slow: the first one runs on ramping clocks)
-    n = max(p["gemm_launches"], 1)
-    g_traffic, g_src = pmc_traffic("gemm", S_dec, dtype)
-    a_traffic, a_src = pmc_traffic("attn", S_dec, dtype)
+    # Many-sequence 16-bit step: the step runs as 4 row ranges on forked streams whose launches overlap each other (and the other
+    # ranges' attention), so there is no per-launch duration to take from it.  The roofline times every kernel ALONE on the GPU at
+    # the step's full row count (one_range) - the figure a serialising profiler gives for a 1-range step (profiles/
+    # r06_kernel_trace_summary_b32_bf16_one_range.md) - and quotes the as-launched (concurrent) family times next to it.
+    ranged = S_dec > 128 and dtype == "bf16"
+    p = eng.time_step_parts(S_dec, nkeys, iters=10, one_range=ranged)   # (3 replays read 3-6 % slow: the first one runs on ramping clocks)
+    p_conc = eng.time_step_parts(S_dec, nkeys, iters=10) if ranged else None
     if S_dec <= 128:
         ach = p["gemm_weight_bytes"] / (p["ms_gemm"] * 1e-3) / 1e9
         gemm = {"bound": "hbm", "kernel": "rgrg_skinny_direct_f32 (+ _half, rgrg_lm_head_wave_f32)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -82,21 +85,26 @@ def rooflines(eng, S_dec, dtype, max_length):
     else:
         peak = MFMA_PEAK_TFS[dtype]
         ach = p["gemm_flops"] / (p["ms_gemm"] * 1e-3) / 1e12
-        gemm = {"bound": "mfma", "kernel": "gemm_bf16_glds_kernel" if dtype == "bf16" else "gemm_f32_kernel", "achieved": ach, "peak": peak,
+        gemm = {"bound": "mfma", "kernel": ("gemm_bf16_glds_kernel (c_attn, c_fc) + gemm_bf16_kp_kernel (attn_proj, mlp_proj) + gemm_bf16_pp_kernel (lm_head)"
+                                            if dtype == "bf16" else "gemm_f32_kernel"), "achieved": ach, "peak": peak,
                 "unit": "TFLOP/s", "frac": ach / peak, "traffic": g_traffic, "traffic_source": g_src, "launches_per_decode_step": n,
                 "avg_launch_us": 1e3 * p["ms_gemm"] / n, "algorithmic_flops_per_launch": p["gemm_flops"] / n,
                 "note": "achieved = 2 M N K of the GEMM launches of one decode step / their duration between two HIP events on the decoder stream, "
-                        "launched as the step launches them: >= 512 sequences in 16-bit mode run as 3 row ranges on forked streams "
-                        "(decoder.hip run_row_ranges), so launches of different ranges overlap and avg_launch_us = duration / launches is an "
-                        "effective figure (a kernel trace shows longer, overlapping launches)"}
+                        "every launch over ALL rows of the step, back to back (each kernel alone on the GPU).  The step itself launches them as "
+                        "4 row ranges on forked streams (decoder.hip run_row_ranges) that overlap each other and the other ranges' attention: "
+                        "`as_launched_*` = the same launches issued that way, GEMMs only"}
+        if p_conc is not None:
+            gemm["as_launched_ms_per_decode_step"] = p_conc["ms_gemm"]
+            gemm["as_launched_launches_per_decode_step"] = p_conc["gemm_launches"]
     ach = p["kv_bytes"] / (p["ms_attn"] * 1e-3) / 1e9
     attn = {"bound": "hbm", "kernel": "attn_decode_kv16_wave_kernel" if (dtype == "bf16" and S_dec > 128) else "attn_decode_kernel",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": a_traffic, "traffic_source": a_src,
             "launches_per_decode_step": 24, "avg_launch_us": 1e3 * p["ms_attn"] / 24, "algorithmic_bytes_per_launch": p["kv_bytes"] / 24,
             "keys_per_sequence": nkeys,
             "note": "achieved = K/V cache bytes of the attention launches of one step at the mid-sequence key count / their duration "
-                    "between two HIP events on the decoder stream (24 launches; 3 x 24 overlapping row-range launches on the many-sequence "
-                    "16-bit path; avg_launch_us and the bytes per launch are per layer)"}
+                    "between two HIP events on the decoder stream (24 launches, each over all sequences of the step)"}
+    if p_conc is not None:
+        attn["as_launched_ms_per_decode_step"] = p_conc["ms_attn"]
     gemm["ms_per_decode_step"], attn["ms_per_decode_step"] = p["ms_gemm"], p["ms_attn"]
     return (gemm, attn) if p["ms_gemm"] >= p["ms_attn"] else (attn, gemm)
 
@@ -241,6 +249,46 @@ def detector_rooflines(eng, images, bf16):
     return det, ra
 
 
+def workload_name(batch, max_length, dtype, world):
+    """config.workload of the headline line: which BASELINE configuration the per-GPU work is."""
+    base = f"full_model.generate() batch={batch}/GPU, 29 regions, greedy max_len={max_length}, "
+    if dtype == "f32":
+        return base + "fp32" + (" (BASELINE configs[1])" if batch == 1 and max_length == 128 else "")
+    tag = ""
+    if batch == 32 and max_length == 128:
+        tag = " (BASELINE configs[2])" if world == 1 else (f" (BASELINE configs[3]{'' if world == 8 else ': the 8-GPU shape at this N'}: "
+                                                          f"batch={32 * world} sharded 32 / GPU, one RCCL all_gather of the token ids)")
+    return base + "bf16 autocast: 16-bit detector, 16-bit decode GEMMs + K/V cache, hipGraph-captured decode step" + tag
+
+
+def generate_leg(model, synth, batch, dtype, max_length, steps, warmup, dev, num_beams=1, early_stopping=False, with_rooflines=True):
+    """One more generate() workload inside the same process (N = 1 legs: `config1`, `beam4`): `warmup` + `steps` calls between device
+    synchronisations, with the rooflines of its decode-step kernel families and of its detector call."""
+    import contextlib
+    images = synth.make_images(batch, 1234).to(dev)
+    ctx = (lambda: torch.autocast("cuda", dtype={"bf16": torch.bfloat16, "f16": torch.float16}[dtype])) if dtype != "f32" else contextlib.nullcontext
+
+    def step():
+        with ctx():
+            return model.generate(images, max_length=max_length, num_beams=num_beams, early_stopping=early_stopping)
+    out = None
+    for _ in range(warmup):
+        out = step()
+    dt, out = _bracketed(step, steps, False, dev)
+    S = 0 if isinstance(out, int) else int(out[0].shape[0])
+    res = {"value": steps * batch / dt, "unit": "images/sec", "n_gpus": 1, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+           "dtype": dtype, "global_batch": batch, "regions_generated": S, "tokens_per_region": 0 if isinstance(out, int) else int(out[0].shape[1])}
+    if with_rooflines:
+        try:
+            rows = S * num_beams
+            res["roofline"], res["roofline_secondary"] = rooflines(model.engine(), max(rows, 1), "bf16" if (dtype != "f32" and rows > 128) else "f32",
+                                                                   max_length)
+            res["roofline_detector"], res["roofline_roialign"] = detector_rooflines(model.engine(), images, dtype != "f32")
+        except Exception as e:  # noqa: BLE001
+            res["roofline"] = {"error": str(e)}
+    return res
+
+
 def _free_port() -> int:
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -301,38 +349,6 @@ def _bracketed(fn, calls, use_dist, dev):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     return dt, out
-
-
-def config2_line(model, synth, max_length, world=1, use_dist=False, dev=None, with_detector_rooflines=True):
-    """BASELINE configs[2] (world == 1) / configs[3] (world > 1: the same 32 images PER GPU, batch-sharded, ONE RCCL gather of
-    the token ids) in the same process: bf16 autocast (bf16-weight MFMA decode GEMMs, bf16 K/V cache, hipGraph-captured
-    step), 1 warm-up + 2 timed generate() calls between barriers, MAX over ranks, with its own rooflines."""
-    from rgrg_amd.dist import generate_sharded
-    dev = dev or next(iter(model.parameters())).device
-    images = synth.make_images(32, 1234).to(dev)
-
-    def step():
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            if use_dist:
-                return generate_sharded(model, images, max_length)
-            return model.generate(images, max_length=max_length, num_beams=1)
-
-    step()
-    dt, out = _bracketed(step, 2, use_dist, dev)
-    S = 0 if isinstance(out, int) else int(out[0].shape[0])
-    which = ("batch=32, 29 regions, greedy max_len=%d, bf16 autocast (BASELINE configs[2])" % max_length) if world == 1 else \
-            ("batch=%d synthetic CXR sharded 32 / GPU over %d GPUs, bf16 autocast, one RCCL all_gather of the token ids "
-             "(BASELINE configs[3]%s)" % (32 * world, world, "" if world == 8 else ": the 8-GPU shape at this N"))
-    res = {"workload": "full_model.generate() " + which, "value": 2 * 32 * world / dt, "unit": "images/sec", "n_gpus": world,
-           "ms_per_step": 1e3 * dt / 2, "steps": 2, "warmup": 1, "dtype": "bf16", "scaling": "weak", "global_batch": 32 * world,
-           "regions_generated": S, "tokens_per_region": 0 if isinstance(out, int) else int(out[0].shape[1])}
-    try:
-        res["roofline"], res["roofline_secondary"] = rooflines(model.engine(), max(S // max(world, 1), 1), "bf16", max_length)
-        if with_detector_rooflines:
-            res["roofline_detector"], res["roofline_roialign"] = detector_rooflines(model.engine(), images, True)
-    except Exception as e:  # noqa: BLE001
-        res["roofline"] = {"error": str(e)}
-    return res
 
 
 def config4_line(model, synth, world=1, use_dist=False, dev=None, steps=3, T=64):
@@ -411,20 +427,21 @@ def config4_line(model, synth, world=1, use_dist=False, dev=None, steps=3, T=64)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (BASELINE configs[1]: 1)")
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step (BASELINE configs[2] / configs[3]: 32; configs[1]: --batch 1 --dtype f32)")
     ap.add_argument("--max-length", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-all-cores", action="store_true",
-                    help="cpu_baseline additionally times ONE full run of the oracle on all physical cores (minutes on a 128-core host)")
-    ap.add_argument("--no-config2", action="store_true",
-                    help="skip the secondary legs of the default run: batch 32 / GPU under bf16 (BASELINE configs[2]; configs[3] at N > 1) "
-                         "and the training step (configs[4])")
+    ap.add_argument("--no-cpu-baseline-all-cores", action="store_true",
+                    help="cpu_baseline skips its ONE full run of the oracle on all physical cores (~2 minutes on a 128-core host)")
+    ap.add_argument("--cpu-baseline-all-cores", action="store_true", help=argparse.SUPPRESS)   # round-5 spelling: now the default
+    ap.add_argument("--no-config2", "--no-extra-legs", dest="no_config2", action="store_true",
+                    help="skip the secondary legs of the default run: batch 1 in fp32 (BASELINE configs[1], `config1`), the scripts' beam mode "
+                         "(`beam4`) and the training step (configs[4], `config4`)")
     ap.add_argument("--train", action="store_true", help="the headline line IS the training step (BASELINE configs[4]) instead of generate()")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="bf16: run generate() under torch.autocast(bfloat16) - bf16 MFMA decode GEMMs for > 128 sequences "
-                         "(BASELINE configs[2]); not bit-exact, never the default")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="bf16",
+                    help="bf16 (default, BASELINE configs[2] / [3]): generate() under torch.autocast(bfloat16) - 16-bit matrix-core GEMMs, 16-bit K/V "
+                         "cache, 16-bit detector; parity there is statistical (README).  f32: the bit-exact path (configs[1] with --batch 1)")
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)  # tests: launcher / gather path on gloo, no GPU
     args = ap.parse_args()
 
@@ -533,8 +550,7 @@ def main():
         "value": n_images / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"full_model.generate() batch={args.batch}/GPU, 29 regions, greedy max_len={args.max_length}, {'fp32' if args.dtype == 'f32' else 'bf16 decode GEMMs (fp32 detector/LN/attention)'}"
-                               + (" (BASELINE configs[1])" if args.batch == 1 and args.max_length == 128 and args.dtype == "f32" else ""),
+        "config": {"workload": workload_name(args.batch, args.max_length, args.dtype, world),
                    "global_batch": args.batch * world, "regions_generated": S, "tokens_per_region": Lp,
                    "parallelism": f"dp{world} (image shards, one RCCL all_gather of token ids)" if use_dist else "single GPU",
                    "weights": "seeded random init (rgrg_amd.synth, profile bench)", "hipGraph_decode": True},
@@ -548,12 +564,12 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
-    default_workload = args.batch == 1 and args.dtype == "f32"
-    if world > 1 and default_workload:
-        res["config"]["note"] = ("the per-GPU work of this line is BASELINE configs[1] at every N, so that the driver's per-N values form ONE weak-"
-                                 "scaling curve; BASELINE configs[3] (32 images / GPU, bf16, one gather) and configs[4] (training step, gradient "
-                                 "all-reduce) ride in the same line as `config3` / `config4`, their N = 1 points are `config2` / `config4` of the "
-                                 "--gpus 1 line")
+    default_workload = args.batch == 32 and args.dtype == "bf16" and args.max_length == 128
+    if default_workload:
+        res["config"]["note"] = ("headline = 32 images per GPU under bf16 autocast at every N: BASELINE configs[2] at N = 1, configs[3] at N = 8, one weak-"
+                                 "scaling curve of ONE workload; the bit-exact fp32 batch-1 path (configs[1]) rides along as `config1`, the scripts' "
+                                 "beam mode as `beam4`, the training step (configs[4]) as `config4`.  16-bit parity is statistical (README, DESIGN 7.2): "
+                                 "token ids are bit-exact against the reference on the fp32 path only")
     # rooflines of the two kernel families of the decode loop, dominant one first (timed live, HIP events), per rank 0
     if rank == 0:
         try:
@@ -561,16 +577,24 @@ def main():
             res["roofline"], res["roofline_secondary"] = rooflines(model.engine(), S_dec, args.dtype, args.max_length)
             res["roofline_detector"], res["roofline_roialign"] = detector_rooflines(model.engine(), images, args.dtype == "bf16")
         except Exception as e:  # noqa: BLE001
-            res.setdefault("roofline", {"bound": "hbm", "error": str(e)})
-    if default_workload and not args.no_config2:   # every rank takes part: the legs below contain collectives at N > 1
-        key2 = "config2" if world == 1 else "config3"
-        try:
-            res[key2] = config2_line(model, synth, args.max_length, world, use_dist, dev, with_detector_rooflines=(rank == 0))
+            res.setdefault("roofline", {"bound": "mfma", "error": str(e)})
+    extra = default_workload and not args.no_config2
+    if extra and world == 1 and rank == 0:
+        try:   # BASELINE configs[1]: batch 1, fp32, greedy, 29 x 128 tokens - the path whose token ids are bit-exact against the reference
+            res["config1"] = dict(generate_leg(model, synth, 1, "f32", args.max_length, 5, 1, dev),
+                                  workload=workload_name(1, args.max_length, "f32", 1), metric=res["metric"])
         except Exception as e:  # noqa: BLE001
-            res[key2] = {"error": str(e)}
+            res["config1"] = {"error": str(e)}
+        try:   # what the reference's scripts run: num_beams=4, max_length=300, early_stopping under fp16 autocast
+            res["beam4"] = dict(generate_leg(model, synth, 1, "f16", 300, 3, 1, dev, num_beams=4, early_stopping=True),
+                                workload="generate_reports_for_images.py:108-114 mode: 1 image, num_beams=4 (116 beam rows), max_length=300, "
+                                         "early_stopping=True, torch.autocast(float16): 16-bit detector; 116 rows <= 128 keep the fp32 decode kernels",
+                                metric="images/sec full 29-region report gen, 512x512 CXR, beam search num_beams=4 max_len=300")
+        except Exception as e:  # noqa: BLE001
+            res["beam4"] = {"error": str(e)}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(sd, images_cpu, args.max_length, all_cores_full_run=args.cpu_baseline_all_cores)
-    if default_workload and not args.no_config2:   # last: it updates the weights
+        res["cpu_baseline"] = cpu_baseline(sd, images_cpu, args.max_length, all_cores_full_run=not args.no_cpu_baseline_all_cores)
+    if extra:   # last: it updates the weights; every rank takes part (gradient all-reduce at N > 1)
         try:
             res["config4"] = config4_line(model, synth, world, use_dist, dev)
         except Exception as e:  # noqa: BLE001

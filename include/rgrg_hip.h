@@ -420,8 +420,10 @@ int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S, void* stre
  * keys per sequence, each family between one pair of HIP events on the decoder's stream.  Returns total ms of each,
  * the algorithmic flops and weight bytes of the GEMMs of ONE step, the K/V cache bytes ONE step reads at `nkeys`
  * keys (24 x 2 x S x 1024 x nkeys x element size), and the GEMM launches per step.  Call after a generate() so that
- * the decoder exists in the wanted precision mode. */
-int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, int iters, float* ms_gemm, float* ms_attn,
+ * the decoder exists in the wanted precision mode.  one_range != 0: every launch covers all S rows (each kernel alone on the
+ * GPU at the step's full size - what a serialising profiler sees of a 1-range step); 0: as the step launches them (the
+ * many-sequence 16-bit step runs as concurrent row ranges on forked streams, whose launches overlap). */
+int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, int iters, int one_range, float* ms_gemm, float* ms_attn,
                                  double* gemm_flops, double* gemm_weight_bytes, double* kv_bytes, int* gemm_launches);
 /* Measurement hook: `iters` + 1 eagerly enqueued many-sequence decode steps at `nkeys` keys (state of the last generate() of S
  * sequences), the last one with an event behind every launch on the stream it was launched on.  recs [max_recs][3] = (first row

@@ -92,7 +92,7 @@ SIGNATURES = {
     "rgrg_decoder_trace_step": (_i, [_p, _i, _i, _i, _p, _i, C.POINTER(_i)]),
     "rgrg_decoder_attention_only": (_i, [_p, _i, _i, _i, _p]),
     "rgrg_decoder_set_lm_positions": (_i, [_p, _p, C.c_int64]),
-    "rgrg_decoder_time_step_parts": (_i, [_p, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), C.POINTER(C.c_double),
+    "rgrg_decoder_time_step_parts": (_i, [_p, _i, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "rgrg_decoder_time_train_gemms": (_i, [_p, _i, _i, _i, C.POINTER(_f), C.POINTER(C.c_double), C.POINTER(_i)]),
     "rgrg_debug_chain": (_i, [_i, _i, _i, C.POINTER(_f)]),

@@ -3551,10 +3551,15 @@ extern "C" int rgrg_decoder_trace_step(rgrg_decoder* d, int S, int nkeys, int it
     return rc;
 }
 
-extern "C" int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, int iters, float* ms_gemm, float* ms_attn,
+extern "C" int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, int iters, int one_range, float* ms_gemm, float* ms_attn,
                                             double* gemm_flops, double* gemm_weight_bytes, double* kv_bytes,
                                             int* gemm_launches) {
     RGRG_CHECK_ARG(d && S > 0 && S <= d->max_seqs && nkeys >= 2 && nkeys <= d->T && iters > 0 && ms_gemm && ms_attn);
+    // one_range: every launch covers all S rows (the kernels alone on the GPU at the step's full size), whatever the step's own
+    // row-range split is; 0: as the step launches them (concurrent row ranges on forked streams where it does that)
+    const int keep_chains = d->chains;
+    if (one_range) d->chains = 1;
+    struct Restore { rgrg_decoder* d; int c; ~Restore() { d->chains = c; } } restore{d, keep_chains};
     hipEvent_t e0, e1;
     RGRG_HIP(hipEventCreate(&e0));
     RGRG_HIP(hipEventCreate(&e1));

@@ -1000,12 +1000,13 @@ class HipEngine:
                    "rgrg_decoder_time_train_gemms")
         return {"ms_gemm": ms.value, "gemm_flops": fl.value, "gemm_launches": n.value}
 
-    def time_step_parts(self, S: int, nkeys: int, iters: int = 3) -> Dict[str, float]:
+    def time_step_parts(self, S: int, nkeys: int, iters: int = 3, one_range: bool = False) -> Dict[str, float]:
         """Per decode step, measured with HIP events on the decoder's stream (bench.py roofline): ms spent in the
         projection GEMM launches and in the 24 attention launches (at ``nkeys`` keys), with the algorithmic flops /
-        weight bytes / K/V bytes of one step.  Uses the decoder of the last generate() (its precision mode)."""
+        weight bytes / K/V bytes of one step.  Uses the decoder of the last generate() (its precision mode).  ``one_range``:
+        every launch covers all S rows (the kernels alone on the GPU) instead of the step's concurrent row ranges."""
         mg, ma, fl, wb, kv, n = C.c_float(0), C.c_float(0), C.c_double(0), C.c_double(0), C.c_double(0), C.c_int(0)
-        _hip.check(self.lib.rgrg_decoder_time_step_parts(self._decoder, S, nkeys, iters, C.byref(mg), C.byref(ma), C.byref(fl),
+        _hip.check(self.lib.rgrg_decoder_time_step_parts(self._decoder, S, nkeys, iters, int(bool(one_range)), C.byref(mg), C.byref(ma), C.byref(fl),
                                                          C.byref(wb), C.byref(kv), C.byref(n)), "rgrg_decoder_time_step_parts")
         return {"ms_gemm": mg.value / iters, "ms_attn": ma.value / iters, "gemm_flops": fl.value, "gemm_weight_bytes": wb.value,
                 "kv_bytes": kv.value, "gemm_launches": n.value}

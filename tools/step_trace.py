@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--nkeys", type=int, default=65)
     ap.add_argument("--dtype", choices=("f16", "bf16"), default="bf16")
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--parts", action="store_true", help="also rgrg_decoder_time_step_parts (the bench line's GEMM / attention family timings)")
     ap.add_argument("--generate", type=int, default=2, help="timed generate() calls of 128 tokens (0: none)")
     args = ap.parse_args()
     model = rgrg_amd.ReportGenerationModel(pretrain_without_lm_model=True)
@@ -48,6 +49,10 @@ def main():
             print(json.dumps({"rows": args.S, "ms_per_generate": ms, "ms_per_step": ms / 127}), flush=True)
     eng = model.language_model.engine()
     lib = _hip.load()
+    if args.parts:
+        p = eng.time_step_parts(args.S, args.nkeys, iters=10)
+        print(json.dumps({"parts": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in p.items()},
+                          "gemm_tflops": p["gemm_flops"] / (p["ms_gemm"] * 1e-3) / 1e12}), flush=True)
     maxr = 4096
     recs = (C.c_float * (3 * maxr))()
     n = C.c_int(0)
