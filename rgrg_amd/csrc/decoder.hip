@@ -1554,6 +1554,7 @@ struct rgrg_decoder {
     int sk_attn = 0, sk_mlp = 0; // K slices of attn_proj / mlp_proj there (RGRG_SK_ATTN / RGRG_SK_MLP; 0 or 1 = off)
     float* ln_stat = nullptr;   // [rows][16][2]: per-row (sum, sum of squares) slots (one per 64 columns) of the residual stream (folded LayerNorm)
     bool ln_fold = true;        // 16-bit path: LayerNorms folded into the GEMMs around them; RGRG_LN_FOLD=0: ln_rows launches (A/B)
+    bool tr_seen_a16 = false, tr_seen_a32 = false, tr_seen_h16 = false, tr_seen_h32 = false, tr_seen_h16_a32 = false;   // tr_reserve: modes seen
     float* key_mask = nullptr;             // [rows][T] additive padding mask of the cache slots (forward(use_cache=True) with padding)
     const float* key_mask_cur = nullptr;   // set around the steps of rgrg_decoder_forward_cached when a mask was given
     const long long* tf_pos = nullptr;   // position_ids of the NEXT teacher-forced pass (rgrg_decoder_set_lm_positions), [tf_pos_rows] int64
@@ -1581,6 +1582,8 @@ struct rgrg_decoder {
     // > 0: the last greedy generate ran the lm_head with the arg-max epilogue for this many rows - d->logits was not written;
     // rgrg_decoder_copy_last_logits recomputes it from the retained ln_f output (xn16) before copying
     int logits_stale_rows = 0;
+    bool logits_valid = false;   // d->logits / the retained ln_f rows belong to the last step of a completed generate / beam / cached call (ADVICE r05:
+                                 // the timing hooks and a precision change overwrite them - rgrg_decoder_copy_last_logits then refuses)
     // enqueue_step: extra streams + fork / join events of the multi-range many-sequence step (RGRG_DECODE_CHAINS)
     hipStream_t streams_x[MAX_CHAINS - 1] = {};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_CHAINS - 1] = {};
@@ -2384,6 +2387,7 @@ extern "C" int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S,
     hipStream_t caller = as_stream(stream);
     RGRG_HIP(hipEventRecord(d->ev_in, caller));
     RGRG_HIP(hipStreamWaitEvent(d->stream, d->ev_in, 0));
+    d->logits_valid = false;   // until this call has completed (an early error return leaves no logits to copy)
     int rc = enqueue_prefill(d, feats, S);
     if (rc) return rc;
 
@@ -2446,6 +2450,7 @@ extern "C" int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S,
     done = *d->h_done;
     *out_len = (done > 0 && done < limit) ? done : limit;
     d->logits_stale_rows = lm_head_cand_path(d, S) ? S : 0;
+    d->logits_valid = true;
     return RGRG_OK;
 }
 
@@ -2512,6 +2517,7 @@ extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int
     std::vector<float> nscore(R);
     std::vector<int> ntok(R), nidx(R);
     d->logits_stale_rows = 0;   // beam steps write d->logits
+    d->logits_valid = false;
     while (true) {
         RGRG_HIP(hipMemcpyAsync(d->beam_tok, beam_tok.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
         RGRG_HIP(hipMemcpyAsync(d->beam_scores, beam_scores.data(), R * sizeof(float), hipMemcpyHostToDevice, st));
@@ -2618,6 +2624,7 @@ extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int
                               (size_t)L * sizeof(long long), NR, hipMemcpyHostToDevice, st));
     RGRG_HIP(hipStreamSynchronize(st));
     *out_len = L;
+    d->logits_valid = true;
     return RGRG_OK;
 }
 
@@ -2885,29 +2892,44 @@ static void tr_free(rgrg_decoder* d) {
 constexpr int TR_LOGIT_ROWS_H16 = 16384;
 
 static int tr_reserve(rgrg_decoder* d, size_t rows, size_t seqs, bool h16, bool a16) {
-    if (rows <= d->tr_rows && seqs <= d->tr_seqs && h16 == d->tr_h16 && a16 == d->tr_a16) return RGRG_OK;
-    const size_t keep = d->tr_rows;
-    tr_free(d);
-    rows = rows > keep ? rows : keep;
-    const size_t D = (size_t)d->D, L = (size_t)d->n_layer, Sp = (size_t)pad32((int)seqs), VP = (size_t)pad256(d->V);
+    // The work space holds the buffers of EVERY mode seen so far (16-bit / fp32 activation flow x 16-bit / fp32 attention): a16
+    // follows T + 1 <= 128 and h16 follows S * T > 128, so batches whose padded length moves across those edges flip the mode
+    // back and forth - freeing and re-allocating multi-GB buffers (plus a 1.6 GB memset) on every flip.  A mode
+    // that is new to this decoder costs one re-allocation; after that only a larger batch does.
+    bool& seen_a = a16 ? d->tr_seen_a16 : d->tr_seen_a32;
+    bool& seen_h = h16 ? d->tr_seen_h16 : d->tr_seen_h32;
     const size_t cap = h16 ? (size_t)TR_LOGIT_ROWS_H16 : (size_t)TF_LOGIT_ROWS;
-    const size_t chunk = rows < cap ? rows : cap;
+    if (rows <= d->tr_rows && seqs <= d->tr_seqs && seen_a && seen_h && (!h16 || a16 || d->tr_seen_h16_a32 || d->tr_seen_a16)) {
+        d->tr_h16 = h16; d->tr_a16 = a16;
+        d->tr_chunk = d->tr_rows < cap ? d->tr_rows : cap;
+        return RGRG_OK;
+    }
+    const size_t keep = d->tr_rows, keep_s = d->tr_seqs;
+    tr_free(d);
+    seen_a = true; seen_h = true;
+    if (h16 && !a16) d->tr_seen_h16_a32 = true;
+    rows = rows > keep ? rows : keep;
+    seqs = seqs > keep_s ? seqs : keep_s;
+    const size_t D = (size_t)d->D, L = (size_t)d->n_layer, Sp = (size_t)pad32((int)seqs), VP = (size_t)pad256(d->V);
+    const size_t cap_all = d->tr_seen_h16 ? (size_t)TR_LOGIT_ROWS_H16 : (size_t)TF_LOGIT_ROWS;   // the larger chunk of the modes seen
+    const size_t chunk = rows < cap_all ? rows : cap_all;
     d->tr_h16 = h16;
     d->tr_a16 = a16;
-    d->tr_chunk = chunk;
+    d->tr_chunk = rows < cap ? rows : cap;
     RGRG_HIP(hipMalloc((void**)&d->tr_xs, (2 * L + 1) * rows * D * 4));
-    if (a16) {
+    if (d->tr_seen_a16) {
         RGRG_HIP(hipMalloc((void**)&d->tr_qkv16, L * rows * 3 * D * 2));
-        RGRG_HIP(hipMalloc((void**)&d->tr_att16, L * rows * D * 2));
+        RGRG_HIP(hipMalloc((void**)&d->tr_att16, L * rows * D * 2));   // (the fp32-attention 16-bit flow uses its first rows x D)
         RGRG_HIP(hipMalloc((void**)&d->tr_datt16, rows * D * 2));
         RGRG_HIP(hipMalloc((void**)&d->tr_ukv16, seqs * (size_t)d->ld_ukv * 2));
-    } else {
+    }
+    if (d->tr_seen_a32) {
         RGRG_HIP(hipMalloc((void**)&d->tr_qkv, L * rows * 3 * D * 4));
         RGRG_HIP(hipMalloc((void**)&d->tr_att, L * rows * D * 4));
         RGRG_HIP(hipMalloc((void**)&d->tr_delta, rows * (size_t)d->H * 4));
-        if (h16) RGRG_HIP(hipMalloc((void**)&d->tr_att16, rows * D * 2));
+        if (d->tr_seen_h16_a32 && !d->tr_seen_a16) RGRG_HIP(hipMalloc((void**)&d->tr_att16, rows * D * 2));
     }
-    if (h16) {
+    if (d->tr_seen_h16) {
         RGRG_HIP(hipMalloc((void**)&d->tr_xn16, rows * D * 2));
         RGRG_HIP(hipMalloc((void**)&d->tr_ff16, rows * 4 * D * 2));
         RGRG_HIP(hipMalloc((void**)&d->tr_ffpre16, L * rows * 4 * D * 2));
@@ -2916,7 +2938,8 @@ static int tr_reserve(rgrg_decoder* d, size_t rows, size_t seqs, bool h16, bool 
         RGRG_HIP(hipMalloc((void**)&d->tr_dqkv16, rows * 3 * D * 2));
         RGRG_HIP(hipMalloc((void**)&d->tr_dl16, chunk * VP * 2));
         RGRG_HIP(hipMemset(d->tr_dl16, 0, chunk * VP * 2));   // the K-padding columns stay 0 for the backward GEMM
-    } else {
+    }
+    if (d->tr_seen_h32) {
         RGRG_HIP(hipMalloc((void**)&d->tr_ffpre, L * rows * 4 * D * 4));
         RGRG_HIP(hipMalloc((void**)&d->tr_ff, rows * 4 * D * 4));
     }
@@ -3309,6 +3332,7 @@ extern "C" int rgrg_decoder_forward_cached(rgrg_decoder* d, const float* feats, 
     RGRG_HIP(hipStreamWaitEvent(st, d->ev_in, 0));
     int rc;
     d->logits_stale_rows = 0;   // every step below writes d->logits
+    d->logits_valid = false;
     if (past_len == 0 && feats && (rc = enqueue_prefill(d, feats, S))) return rc;   // also resets the step counter to 0
     if (attention_mask) {   // [S][past_len + T]: padding inside the prompt / the past -> additive mask per cache slot
         if (!d->key_mask && (rc = dmalloc(d, (void**)&d->key_mask, (size_t)d->rows * d->T * sizeof(float), true))) return rc;
@@ -3333,6 +3357,7 @@ extern "C" int rgrg_decoder_forward_cached(rgrg_decoder* d, const float* feats, 
     RGRG_LAUNCH_CHECK();
     RGRG_HIP(hipEventRecord(d->ev_in, st));
     RGRG_HIP(hipStreamWaitEvent(caller, d->ev_in, 0));
+    d->logits_valid = true;
     return RGRG_OK;
 }
 
@@ -3411,6 +3436,7 @@ extern "C" int rgrg_decoder_set_precision(rgrg_decoder* d, int mode) {
     return rc;
 }
 static int set_precision_impl(rgrg_decoder* d, int mode) {
+    d->logits_valid = false;   // (called on a mode CHANGE only) the retained ln_f rows belong to the other mode's weights
     const int prev = d->bf16_gemms;
     d->bf16_gemms = mode;   // d->f16() below is the NEW type
     if (mode) {
@@ -3481,6 +3507,11 @@ static int set_precision_impl(rgrg_decoder* d, int mode) {
 
 extern "C" int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S, void* stream) {
     RGRG_CHECK_ARG(d && dst && S > 0 && S <= d->max_seqs);
+    if (!d->logits_valid) {
+        set_error("decoder: no logits of a completed step to copy - the last generate / beam / cached call failed, or a timing hook or a "
+                  "precision change has reused the decoder's work space since");
+        return RGRG_EINVAL;
+    }
     if (d->logits_stale_rows > 0) {   // the greedy step kept only arg-max candidates: the logits of its last step from the retained ln_f rows
         const int rows = d->logits_stale_rows;
         RGRG_CHECK_ARG(S <= rows);
@@ -3524,6 +3555,7 @@ extern "C" int rgrg_decoder_attention_only(rgrg_decoder* d, int S, int nkeys, in
 // under concurrency (rocprofv3's kernel trace serialises the queues).  recs: 3 floats per launch.
 extern "C" int rgrg_decoder_trace_step(rgrg_decoder* d, int S, int nkeys, int iters, float* recs, int max_recs, int* n_out) {
     RGRG_CHECK_ARG(d && S > skinny_max_rows() && S <= d->rows && nkeys >= 2 && nkeys <= d->T && recs && n_out && iters >= 0);
+    d->logits_valid = false;
     std::vector<rgrg_decoder::TraceMark> marks;
     hipEvent_t base;
     RGRG_HIP(hipEventCreate(&base));
@@ -3557,6 +3589,7 @@ extern "C" int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, i
     RGRG_CHECK_ARG(d && S > 0 && S <= d->max_seqs && nkeys >= 2 && nkeys <= d->T && iters > 0 && ms_gemm && ms_attn);
     // one_range: every launch covers all S rows (the kernels alone on the GPU at the step's full size), whatever the step's own
     // row-range split is; 0: as the step launches them (concurrent row ranges on forked streams where it does that)
+    d->logits_valid = false;   // the replays below overwrite x / xn16 / the logits work space
     const int keep_chains = d->chains;
     if (one_range) d->chains = 1;
     struct Restore { rgrg_decoder* d; int c; ~Restore() { d->chains = c; } } restore{d, keep_chains};

@@ -1185,7 +1185,7 @@ int init_gemm_bf16_attrs() {
     if ((rc = glds_attrs<128, 128>()) || (rc = glds_attrs<64, 64>()) || (rc = glds_attrs<128, 64>()) || (rc = glds_attrs<64, 128>())) return rc;
     RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
     RGRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
-    if ((rc = kp_attr<128, 128, 2>()) || (rc = kp_attr<64, 64, 4>()) || (rc = kp_attr<64, 64, 3>()) || (rc = kp_attr<128, 64, 3>()) || (rc = kp_attr<64, 128, 3>()) || (rc = pr_attrs())) return rc;
+    if ((rc = kp_attr<128, 128, 2>()) || (rc = kp_attr<64, 64, 4>()) || (rc = kp_attr<64, 64, 3>()) || (rc = kp_attr<128, 64, 3>()) || (rc = kp_attr<64, 128, 3>()) || (rc = kp_attr<64, 64, 2>()) || (rc = pr_attrs())) return rc;
     done = true;
     return RGRG_OK;
 }
@@ -1274,6 +1274,7 @@ static int launch_glds(const GemmBf16Params& p, int tile, hipStream_t st) {
         case 10: return launch_kp_cfg<64, 64, 3>(p, st);
         case 11: return launch_kp_auto(p, st);
         case 12: return launch_pr(p, st);
+        case 13: return launch_kp_cfg<64, 64, 2>(p, st);
     }
     if (shape == 5) {
         if (!pp_eligible(p)) { set_error("bf16 GEMM: the 256 x 256 kernel does not take this variant"); return RGRG_EINVAL; }

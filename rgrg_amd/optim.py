@@ -54,15 +54,17 @@ class AdamW(torch.optim.Optimizer):
         return loss
 
     def _multi_step(self, group, b1, b2, grad_scale) -> bool:
-        """All tensors of the group in ceil(n / 64) launches (rgrg_adamw_multi_step_f32) when they share device and step count - the
-        normal case; the per-tensor loop above remains for anything else."""
-        ps = [p for p in group["params"] if p.grad is not None]
+        """All tensors of the group in ceil(n / 64) launches per distinct step count (rgrg_adamw_multi_step_f32) when they are
+        contiguous fp32 tensors on one device - the normal case; the per-tensor loop above remains for anything else.  Tensors
+        whose step counts differ (a parameter that received no gradient in an earlier step - e.g. a rank without selected
+        regions) are partitioned by count, one multi launch per partition; zero-element tensors are skipped."""
+        ps = [p for p in group["params"] if p.grad is not None and p.numel() > 0]
         if len(ps) < 2:
             return False
         dev = ps[0].device
-        for p in ps:
+        for p in ps:   # every record is validated before the first launch: a later partition cannot fail after an earlier one ran
             if not (p.is_cuda and p.device == dev and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
-                    and p.grad.dtype == torch.float32):
+                    and p.grad.dtype == torch.float32 and p.grad.device == dev and p.grad.numel() == p.numel()):
                 return False
         for p in ps:
             st = self.state[p]
@@ -70,19 +72,19 @@ class AdamW(torch.optim.Optimizer):
                 st["step"] = 0
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-        steps = {int(self.state[p]["step"]) for p in ps}
-        if len(steps) != 1:
-            return False
         if self._lib is None:
             self._lib = _hip.load()
-        rows = torch.tensor([(p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
-                              p.numel()) for p in ps], dtype=torch.int64)   # host table: the records travel in the kernel arguments
-        step = steps.pop() + 1
-        with torch.cuda.device(dev):
-            _hip.check(self._lib.rgrg_adamw_multi_step_f32(rows.data_ptr(), len(ps), float(group["lr"]), float(b1), float(b2),
-                                                           float(group["eps"]), float(group["weight_decay"]), step, float(grad_scale),
-                                                           torch.cuda.current_stream(dev).cuda_stream), "rgrg_adamw_multi_step_f32")
+        by_step = {}
         for p in ps:
-            self.state[p]["step"] = step
-            torch._C._increment_version(p)
+            by_step.setdefault(int(self.state[p]["step"]), []).append(p)
+        for step0, part in sorted(by_step.items()):
+            rows = torch.tensor([(p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
+                                  p.numel()) for p in part], dtype=torch.int64)   # host table: the records travel in the kernel arguments
+            with torch.cuda.device(dev):
+                _hip.check(self._lib.rgrg_adamw_multi_step_f32(rows.data_ptr(), len(part), float(group["lr"]), float(b1), float(b2),
+                                                               float(group["eps"]), float(group["weight_decay"]), step0 + 1, float(grad_scale),
+                                                               torch.cuda.current_stream(dev).cuda_stream), "rgrg_adamw_multi_step_f32")
+            for p in part:
+                self.state[p]["step"] = step0 + 1
+                torch._C._increment_version(p)
         return True

@@ -509,6 +509,34 @@ def test_adamw_kernel_matches_torch():
     assert _rel(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]) <= 1e-5   # fp32, fma contraction differs
 
 
+def test_adamw_multi_tensor_path_with_mixed_step_counts_and_empty_tensors():
+    """a group whose tensors have DIFFERENT step counts (a parameter that got no gradient in an earlier step) keeps the
+    multi-tensor launches - one per step count - and a zero-element parameter is skipped instead of failing the whole group;
+    every tensor follows torch.optim.AdamW with the same gradient history."""
+    from rgrg_amd import optim
+    g = torch.Generator().manual_seed(5)
+    shapes = [(300, 7), (64,), (0,), (129, 3), (5,)]
+    init = [torch.randn(sh, generator=g) for sh in shapes]
+    ours = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    ref = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    oa = optim.AdamW(ours, lr=3e-3, weight_decay=0.05)
+    ob = torch.optim.AdamW(ref, lr=3e-3, weight_decay=0.05)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(ours, ref)):
+            if step == 1 and i in (1, 3):          # no gradient for two of the tensors in the second step
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(shapes[i], generator=g).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+        for a, b in zip(ours, ref):
+            if a.numel():
+                assert (a - b).abs().max().item() <= 2e-6, step
+    assert oa.state[ours[0]]["step"] == 4 and oa.state[ours[1]]["step"] == 3 and oa.state[ours[3]]["step"] == 3
+    assert not oa.state[ours[2]]                   # the empty tensor never entered a launch
+
+
 def test_two_training_steps_follow_the_oracle():
     """loss -> backward -> HIP AdamW -> (engine picks the new uk/uv/fst weights up) -> loss again, against the same two
     steps done with torch autograd + torch.optim.AdamW on the CPU oracle.  lr is large so that step 2 differs visibly."""

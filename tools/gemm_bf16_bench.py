@@ -15,7 +15,7 @@ from rgrg_amd import _hip  # noqa: E402
 SHAPES = [("c_attn", 3072, 1024, 0, False), ("attn_proj", 1024, 1024, 0, True), ("c_fc", 4096, 1024, 2, False),
           ("mlp_proj", 1024, 4096, 0, True), ("lm_head", 50257, 1024, 0, False)]
 SHAPE_NAMES = {0: "auto", 1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 5: "pp256x256", 6: "kp128x128x2", 7: "kp64x64x4", 8: "kp128x64x3",
-               9: "kp64x128x3", 10: "kp64x64x3", 11: "kp-auto", 12: "pr128x128x4"}
+               9: "kp64x128x3", 10: "kp64x64x3", 11: "kp-auto", 12: "pr128x128x4", 13: "kp64x64x2"}
 
 
 def timed(call, n=20):
