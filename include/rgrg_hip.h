@@ -10,7 +10,7 @@
  * 0 on success (RGRG_OK) or a negative RGRG_E* code and never allocates or
  * synchronises unless its comment says so.  Activations are NHWC ("channels
  * last"); weight repacking into the layouts named here is done once at load time
- * by the host side (rgrg_amd/weights.py).
+ * by the host side (rgrg_amd/engine.py: HipEngine.__init__ and its _pack_* helpers).
  */
 #ifndef RGRG_HIP_H_
 #define RGRG_HIP_H_
