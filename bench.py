@@ -72,10 +72,14 @@ def rooflines(eng, S_dec, dtype, max_length):
     # ranges' attention), so there is no per-launch duration to take from it.  The roofline times every kernel ALONE on the GPU at
     # the step's full row count (one_range) - the figure a serialising profiler gives for a 1-range step (profiles/
     # r06_kernel_trace_summary_b32_bf16_one_range.md) - and quotes the as-launched (concurrent) family times next to it.
-    ranged = S_dec > 128 and dtype == "bf16"
+    many = S_dec > (128 if dtype == "f32" else 32)   # the many-sequence path: > 128 rows, or > 32 under autocast (decoder.hip decode_row_limit)
+    ranged = S_dec >= 512 and dtype != "f32"
     p = eng.time_step_parts(S_dec, nkeys, iters=10, one_range=ranged)   # (3 replays read 3-6 % slow: the first one runs on ramping clocks)
     p_conc = eng.time_step_parts(S_dec, nkeys, iters=10) if ranged else None
-    if S_dec <= 128:
+    n = max(p["gemm_launches"], 1)
+    g_traffic, g_src = pmc_traffic("gemm", S_dec, dtype)
+    a_traffic, a_src = pmc_traffic("attn", S_dec, dtype)
+    if not many:
         ach = p["gemm_weight_bytes"] / (p["ms_gemm"] * 1e-3) / 1e9
         gemm = {"bound": "hbm", "kernel": "rgrg_skinny_direct_f32 (+ _half, rgrg_lm_head_wave_f32)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": g_traffic, "traffic_source": g_src, "launches_per_decode_step": n,
@@ -83,10 +87,10 @@ def rooflines(eng, S_dec, dtype, max_length):
                 "note": "achieved = fp32 weight bytes of the GEMM launches of one decode step (each weight read once) / their duration "
                         "between two HIP events on the decoder stream, launched back to back in step order"}
     else:
-        peak = MFMA_PEAK_TFS[dtype]
+        peak = MFMA_PEAK_TFS["f32" if dtype == "f32" else "bf16"]
         ach = p["gemm_flops"] / (p["ms_gemm"] * 1e-3) / 1e12
         gemm = {"bound": "mfma", "kernel": ("gemm_bf16_glds_kernel (c_attn, c_fc) + gemm_bf16_kp_kernel (attn_proj, mlp_proj) + gemm_bf16_pp_kernel (lm_head)"
-                                            if dtype == "bf16" else "gemm_f32_kernel"), "achieved": ach, "peak": peak,
+                                            if dtype != "f32" else "gemm_f32_kernel"), "achieved": ach, "peak": peak,
                 "unit": "TFLOP/s", "frac": ach / peak, "traffic": g_traffic, "traffic_source": g_src, "launches_per_decode_step": n,
                 "avg_launch_us": 1e3 * p["ms_gemm"] / n, "algorithmic_flops_per_launch": p["gemm_flops"] / n,
                 "note": "achieved = 2 M N K of the GEMM launches of one decode step / their duration between two HIP events on the decoder stream, "
@@ -97,7 +101,7 @@ def rooflines(eng, S_dec, dtype, max_length):
             gemm["as_launched_ms_per_decode_step"] = p_conc["ms_gemm"]
             gemm["as_launched_launches_per_decode_step"] = p_conc["gemm_launches"]
     ach = p["kv_bytes"] / (p["ms_attn"] * 1e-3) / 1e9
-    attn = {"bound": "hbm", "kernel": "attn_decode_kv16_wave_kernel" if (dtype == "bf16" and S_dec > 128) else "attn_decode_kernel",
+    attn = {"bound": "hbm", "kernel": "attn_decode_kv16_wave_kernel" if (dtype != "f32" and many) else "attn_decode_kernel",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": a_traffic, "traffic_source": a_src,
             "launches_per_decode_step": 24, "avg_launch_us": 1e3 * p["ms_attn"] / 24, "algorithmic_bytes_per_launch": p["kv_bytes"] / 24,
             "keys_per_sequence": nkeys,
@@ -281,8 +285,7 @@ def generate_leg(model, synth, batch, dtype, max_length, steps, warmup, dev, num
     if with_rooflines:
         try:
             rows = S * num_beams
-            res["roofline"], res["roofline_secondary"] = rooflines(model.engine(), max(rows, 1), "bf16" if (dtype != "f32" and rows > 128) else "f32",
-                                                                   max_length)
+            res["roofline"], res["roofline_secondary"] = rooflines(model.engine(), max(rows, 1), dtype if (dtype != "f32" and rows > 32) else "f32", max_length)
             res["roofline_detector"], res["roofline_roialign"] = detector_rooflines(model.engine(), images, dtype != "f32")
         except Exception as e:  # noqa: BLE001
             res["roofline"] = {"error": str(e)}
@@ -588,7 +591,8 @@ def main():
         try:   # what the reference's scripts run: num_beams=4, max_length=300, early_stopping under fp16 autocast
             res["beam4"] = dict(generate_leg(model, synth, 1, "f16", 300, 3, 1, dev, num_beams=4, early_stopping=True),
                                 workload="generate_reports_for_images.py:108-114 mode: 1 image, num_beams=4 (116 beam rows), max_length=300, "
-                                         "early_stopping=True, torch.autocast(float16): 16-bit detector; 116 rows <= 128 keep the fp32 decode kernels",
+                                         "early_stopping=True, torch.autocast(float16): 16-bit detector, and - round 6 - the 116 beam rows on the 16-bit "
+                                         "many-sequence decode path (> 32 rows under autocast; the fp32 fused plan before)",
                                 metric="images/sec full 29-region report gen, 512x512 CXR, beam search num_beams=4 max_len=300")
         except Exception as e:  # noqa: BLE001
             res["beam4"] = {"error": str(e)}

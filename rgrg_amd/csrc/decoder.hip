@@ -1685,7 +1685,23 @@ static int init_skinny_attrs() {
 
 // bf16 K/V cache: with the bf16 GEMMs, i.e. on the many-sequence path of the opt-in bf16 mode.  `rows` is the
 // number of token rows of the decode steps (sequences x beams), the same for every launch of one generate call.
-static bool kv_is_bf16(const rgrg_decoder* d, int rows) { return d->bf16_gemms && rows > skinny_max_rows(); }
+// Rows up to which a decode step runs the fused fp32 plan (fragment-direct skinny kernels, bit-exact): 128 without autocast.
+// Round 6: under torch.autocast (16-bit mode) only up to 32 rows (RGRG_SKINNY_MAX_ROWS_16) - one row tile, i.e. batch-1 greedy
+// decoding stays on the bit-exact path - and anything larger takes the many-sequence 16-bit path: the reference computes these
+// GEMMs in 16 bit under autocast anyway, and the exact-fp32 MFMA is 1/16 of the 16-bit rate - the scripts' own mode (1 image,
+// 4 beams = 116 rows, fp16 autocast) went from 914 to 584 ms per image, greedy batch 4 from 11.4 to 20.1 images/s
+// (profiles/r06_small_batch_16bit_threshold.log).
+static int skinny_max_rows16() {
+    static const int v = [] {
+        const char* e = getenv("RGRG_SKINNY_MAX_ROWS_16");
+        int n = e ? atoi(e) : 32;
+        n = n < 32 ? 32 : n;
+        return n > skinny_max_rows() ? skinny_max_rows() : n;
+    }();
+    return v;
+}
+static int decode_row_limit(const rgrg_decoder* d) { return d->bf16_gemms ? skinny_max_rows16() : skinny_max_rows(); }
+static bool kv_is_bf16(const rgrg_decoder* d, int rows) { return d->bf16_gemms && rows > decode_row_limit(d); }
 
 // Measurement builds: the stamp block of the next launch of the fused decode step (null in the product build / without
 // RGRG_SKINNY_TRACE).  The pointers are baked into the captured graph, so a dump holds the LAST replayed step.
@@ -1759,7 +1775,7 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
 
 // Greedy many-sequence step in 16-bit mode: the lm_head leaves per-tile arg-max candidates instead of logits (gemm_bf16.hip)
 static bool lm_head_cand_path(const rgrg_decoder* d, int S) {
-    return S > skinny_max_rows() && kv_is_bf16(d, S) && d->xn16 && d->lm_head.wb && d->lm_head.K % 256 == 0 &&
+    return S > decode_row_limit(d) && kv_is_bf16(d, S) && d->xn16 && d->lm_head.wb && d->lm_head.K % 256 == 0 &&
            gemm_bf16_cand_epilogue_ok(S, d->lm_head.N, d->lm_head.K);
 }
 
@@ -2045,7 +2061,7 @@ static int trace_mark(rgrg_decoder* d, int r0, int tag) {
 //   ln1 of the next layer / ln_f | lm_head, per-32-column arg-max candidates, argmax + bookkeeping
 static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_override = nullptr, const int* src = nullptr,
                         bool beam = false) {
-    if (S <= skinny_max_rows()) return enqueue_step_fused(d, S, count, tok_override, src, beam);
+    if (S <= decode_row_limit(d)) return enqueue_step_fused(d, S, count, tok_override, src, beam);
     if (count) { d->gemm_bytes_per_step = 0; d->gemm_flops_per_step = 0.0; d->gemm_launches_per_step = 0; }
     hipStream_t st = d->stream;
     const int D = d->D;
@@ -3536,7 +3552,7 @@ extern "C" int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S,
 // caller's stream (asynchronous; the state of the last generate() of S sequences) - the HBM-bound half of a decode step as a
 // background load beside other work.
 extern "C" int rgrg_decoder_attention_only(rgrg_decoder* d, int S, int nkeys, int iters, void* stream) {
-    RGRG_CHECK_ARG(d && S > skinny_max_rows() && S <= d->rows && nkeys >= 2 && nkeys <= d->T && iters > 0);
+    RGRG_CHECK_ARG(d && S > decode_row_limit(d) && S <= d->rows && nkeys >= 2 && nkeys <= d->T && iters > 0);
     hipStream_t keep = d->stream;
     d->stream = as_stream(stream);
     hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, d->stream, d->step, nkeys - 2);
@@ -3554,7 +3570,7 @@ extern "C" int rgrg_decoder_attention_only(rgrg_decoder* d, int S, int nkeys, in
 // (first row of the range, tag, ms since the step's first launch) per launch - the true timeline of the row-range chains
 // under concurrency (rocprofv3's kernel trace serialises the queues).  recs: 3 floats per launch.
 extern "C" int rgrg_decoder_trace_step(rgrg_decoder* d, int S, int nkeys, int iters, float* recs, int max_recs, int* n_out) {
-    RGRG_CHECK_ARG(d && S > skinny_max_rows() && S <= d->rows && nkeys >= 2 && nkeys <= d->T && recs && n_out && iters >= 0);
+    RGRG_CHECK_ARG(d && S > decode_row_limit(d) && S <= d->rows && nkeys >= 2 && nkeys <= d->T && recs && n_out && iters >= 0);
     d->logits_valid = false;
     std::vector<rgrg_decoder::TraceMark> marks;
     hipEvent_t base;
@@ -3597,7 +3613,7 @@ extern "C" int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, i
     RGRG_HIP(hipEventCreate(&e0));
     RGRG_HIP(hipEventCreate(&e1));
     const int D = d->D;
-    const bool fused = d->lm_head.direct && S <= skinny_max_rows();
+    const bool fused = d->lm_head.direct && S <= decode_row_limit(d);
     const bool bf = kv_is_bf16(d, S);
     unsigned short* xn16 = (bf && d->xn16) ? d->xn16 : nullptr;
     unsigned short* att16 = xn16 ? d->att16 : nullptr;
