@@ -2,7 +2,10 @@
 stream really overlap on one MI355X, and if not, which resource do they share?  Stream A loops the four GEMMs; stream B loops a
 read-only reduction over (a) 2 GB (HBM), (b) 96 MB (Infinity-Cache resident), (c) 2 MB (L2 resident: same CU occupancy, no
 memory-side traffic).  Reported: the GEMM chain's time per layer alone and beside each stream, and the stream's rate alone and
-beside the GEMMs.  Usage: python tools/overlap_probe.py [M] [kp]"""
+beside the GEMMs.  Run it with RGRG_DECODE_CHAINS=3 (or fewer): the process has 4 hardware queues (GPU_MAX_HW_QUEUES; 2, 6 and
+8 were measured much slower or crashing, profiles/r06_hw_queues_sweep.log) and a 4-range decoder owns 4 streams - the probe's two
+streams then share a queue and serialise (profiles/r06_overlap_probe_v4_chunks.log reads "x0.95" for that reason).
+Usage: python tools/overlap_probe.py [M] [tile] [attn-only]"""
 import os
 import sys
 import time
