@@ -1585,6 +1585,14 @@ struct rgrg_decoder {
     bool logits_valid = false;   // d->logits / the retained ln_f rows belong to the last step of a completed generate / beam / cached call (ADVICE r05:
                                  // the timing hooks and a precision change overwrite them - rgrg_decoder_copy_last_logits then refuses)
     // enqueue_step: extra streams + fork / join events of the multi-range many-sequence step (RGRG_DECODE_CHAINS)
+    // free-running row ranges (round 6, rgrg_decoder_generate): every range owns a step counter / done length / ticket word
+    // (range_state [MAX_CHAINS][4] on the device), a step graph and a stream, and never meets the other ranges inside the loop
+    int* range_state = nullptr;
+    int* step_ptr = nullptr;            // the step counter the kernels of the launch being enqueued read (default: step)
+    int* h_rdone = nullptr;             // pinned [3][MAX_CHAINS]: two in-flight polls + the final read
+    hipEvent_t ev_rpoll[2][MAX_CHAINS] = {};
+    bool free_ranges = false;           // RGRG_DECODE_FREE=1 (opt-in, measured: profiles/r06_free_ranges_ab.log); default: the ranges join in
+                                        // front of the lm_head in every step
     hipStream_t streams_x[MAX_CHAINS - 1] = {};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_CHAINS - 1] = {};
     int chains = 4;   // round 5 (LDS-DMA kernel everywhere): 1 -> 81.6, 2 -> 82.8, 3 -> 85.4, 4 -> 85.1 images/s at BASELINE configs[2]
@@ -1801,16 +1809,16 @@ static int launch_attention(rgrg_decoder* d, int l, int S, const int* src, unsig
         const dim3 wgrid(cap > 0 ? std::min(wgs, cap * 256) : wgs), wblk(256);
         u16* kc16r = kc16 + (size_t)r0 * d->H * d->T * 64;   // cache rows of sequence r0 (layout [sequence][head][slot][64])
 #define KV16_LAUNCH(SRC_, F16_) hipLaunchKernelGGL((attn_decode_kv16_wave_kernel<SRC_, F16_>), wgrid, wblk, 0, st, d->qkv + (size_t)r0 * 3 * D, 3 * D, kc16r, \
-                                                  kc16r + d->kv_kv_stride, d->step, d->att + (size_t)r0 * D, S, d->H, d->T, src, att16)
+                                                  kc16r + d->kv_kv_stride, d->step_ptr, d->att + (size_t)r0 * D, S, d->H, d->T, src, att16)
         if (src) { if (d->f16()) KV16_LAUNCH(true, true); else KV16_LAUNCH(true, false); }
         else { if (d->f16()) KV16_LAUNCH(false, true); else KV16_LAUNCH(false, false); }
 #undef KV16_LAUNCH
     } else {
         const dim3 grid(S * d->H), blk(256);
-#define ATT_LAUNCH(SRC_, NI_) hipLaunchKernelGGL((attn_decode_kernel<SRC_, NI_>), grid, blk, 0, st, d->qkv, 3 * D, kc, vc, d->step, d->att, S, d->H, d->T, src, frag_out, \
+#define ATT_LAUNCH(SRC_, NI_) hipLaunchKernelGGL((attn_decode_kernel<SRC_, NI_>), grid, blk, 0, st, d->qkv, 3 * D, kc, vc, d->step_ptr, d->att, S, d->H, d->T, src, frag_out, \
                                                  stamp_slot(d, "attention", S * d->H))
         if (d->key_mask_cur && !src) {   // forward(use_cache=True) with a padded attention_mask (rgrg_decoder_forward_cached)
-#define ATT_LAUNCH_MASK(NI_) hipLaunchKernelGGL((attn_decode_kernel<false, NI_, true>), grid, blk, 0, st, d->qkv, 3 * D, kc, vc, d->step, d->att, S, d->H, d->T, \
+#define ATT_LAUNCH_MASK(NI_) hipLaunchKernelGGL((attn_decode_kernel<false, NI_, true>), grid, blk, 0, st, d->qkv, 3 * D, kc, vc, d->step_ptr, d->att, S, d->H, d->T, \
                                                   src, frag_out, (unsigned long long*)nullptr, d->key_mask_cur)
             if (S * d->H <= 4096) ATT_LAUNCH_MASK(9); else ATT_LAUNCH_MASK(2);
 #undef ATT_LAUNCH_MASK
@@ -2007,12 +2015,11 @@ static int enqueue_step_fused(rgrg_decoder* d, int S, bool count, const int* tok
 // d->stream; ranges 1.. run on forked streams (d->stream is swapped around the call) and are joined before this returns, so
 // one range's attention (HBM bound) and launch boundaries overlap another range's GEMMs.  Works under stream capture (the step
 // graph gets parallel branches) and eagerly.  chains < 0: the ranges one after the other on d->stream (A/B runs).
-template <class F>
-static int run_row_ranges(rgrg_decoder* d, int S, int chains, F&& fn) {
-    int nr = chains < 0 ? -chains : chains;
+// the row ranges of a step: whole 64-row tiles, as even as possible, every range above the fused plan's row limit (fewer ranges
+// otherwise); -> number of ranges, bounds[0 .. nr]
+static int range_bounds(int S, int want, int (&bounds)[MAX_CHAINS + 1]) {
+    int nr = want < 1 ? 1 : (want > MAX_CHAINS ? MAX_CHAINS : want);
     const int tiles = (S + 63) / 64;
-    int bounds[MAX_CHAINS + 1];
-    // every range must stay on the many-sequence code path (> 128 rows: 16-bit cache, tiled GEMMs): fewer ranges otherwise
     for (; nr > 1; --nr) {
         int least = S;
         for (int i = 0; i <= nr; ++i) {
@@ -2021,6 +2028,14 @@ static int run_row_ranges(rgrg_decoder* d, int S, int chains, F&& fn) {
         }
         if (least > SKINNY_MAX_ROWS) break;
     }
+    if (nr <= 1) { nr = 1; bounds[0] = 0; bounds[1] = S; }
+    return nr;
+}
+template <class F>
+static int run_row_ranges(rgrg_decoder* d, int S, int chains, F&& fn) {
+    int bounds[MAX_CHAINS + 1];
+    // every range must stay on the many-sequence code path (> 128 rows: 16-bit cache, tiled GEMMs): fewer ranges otherwise
+    const int nr = range_bounds(S, chains < 0 ? -chains : chains, bounds);
     if (nr <= 1) return fn(0, S);
     if (chains > 0) {
         RGRG_HIP(hipEventRecord(d->ev_fork, d->stream));
@@ -2059,8 +2074,12 @@ static int trace_mark(rgrg_decoder* d, int r0, int tag) {
 // One decode step.  <= 128 token rows: the fused plan above.  More rows (many images, beam rows): tiled MFMA GEMMs
 //   embed+ln1 | per layer: c_attn, attention, attn_proj (+ residual), ln2, c_fc+gelu, mlp_proj (+ residual),
 //   ln1 of the next layer / ln_f | lm_head, per-32-column arg-max candidates, argmax + bookkeeping
+// `only`: free-running row ranges (rgrg_decoder_generate): enqueue the step of ONE range - rows [only->r0, + rows), its lm_head
+// (arg-max epilogue) and its own arg-max / bookkeeping on the range's state words (d->step_ptr = state, + 1 done length, + 2 ticket)
+// - on d->stream; greedy 16-bit folded step only
+struct RangeSpec { int r0, rows; };
 static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_override = nullptr, const int* src = nullptr,
-                        bool beam = false) {
+                        bool beam = false, const RangeSpec* only = nullptr) {
     if (S <= decode_row_limit(d)) return enqueue_step_fused(d, S, count, tok_override, src, beam);
     if (count) { d->gemm_bytes_per_step = 0; d->gemm_flops_per_step = 0.0; d->gemm_launches_per_step = 0; }
     hipStream_t st = d->stream;
@@ -2098,7 +2117,7 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
         prod_r.Yb16 = xn16r; prod_r.stats_out = statr; cons_r.ln_stats = statr;
         const GemmLnFold* pfr = fold ? &prod_r : nullptr;
         const GemmLnFold* cfr = fold ? &cons_r : nullptr;
-        hipLaunchKernelGGL(embed_ln_kernel, dim3(rows), dim3(256), 0, rs, d->wte, d->ids + (size_t)r0 * d->max_len, d->max_len, d->step,
+        hipLaunchKernelGGL(embed_ln_kernel, dim3(rows), dim3(256), 0, rs, d->wte, d->ids + (size_t)r0 * d->max_len, d->max_len, d->step_ptr,
                            d->layers[0].ln1_g, d->layers[0].ln1_b, x, xn, D, tok_override ? tok_override + r0 : nullptr, xn16r, d->f16(),
                            d->pos_override_cur ? d->pos_override_cur + r0 : nullptr, fold ? statr : (float*)nullptr);
         RGRG_LAUNCH_CHECK();
@@ -2130,6 +2149,19 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
         }
         return RGRG_OK;
     };
+    if (only) {
+        if (beam || tok_override || src || !fold || !lm_head_cand_path(d, S)) { set_error("decoder: a row-range step needs the greedy 16-bit folded path"); return RGRG_EINVAL; }
+        if ((rc = run_rows(only->r0, only->rows))) return rc;
+        const int nt = (d->lm_head.N + 255) / 256;
+        const size_t o = (size_t)only->r0 * D;
+        GemmLnFold ce{};
+        ce.cand_val = d->cand_val + (size_t)only->r0 * nt; ce.cand_idx = d->cand_idx + (size_t)only->r0 * nt;
+        if ((rc = linear(d, d->lm_head, d->xn + o, nullptr, nullptr, only->rows, d->ld_logits, RGRG_ACT_NONE, count, xn16 + o, nullptr, &ce))) return rc;
+        hipLaunchKernelGGL(argmax_update_kernel, dim3(only->rows), dim3(256), 0, st, ce.cand_val, ce.cand_idx, nt, d->ids + (size_t)only->r0 * d->max_len,
+                           d->max_len, d->finished + only->r0, d->step_ptr, d->step_ptr + 1, d->step_ptr + 2, only->rows);
+        RGRG_LAUNCH_CHECK();
+        return RGRG_OK;
+    }
     if ((rc = run_row_ranges(d, S, step_chains(d, S, !beam && !tok_override && !src, fold), run_rows))) return rc;
     if (!beam && xn16 && lm_head_cand_path(d, S)) {
         // greedy: the 256 x 256 lm_head leaves one (maximum, column) pair per row and column tile; no logits, no candidates pass
@@ -2228,6 +2260,13 @@ extern "C" int rgrg_decoder_create_with_cache(const rgrg_decoder_weights* w, int
         }
     }
     if (hipHostMalloc((void**)&d->h_id_error, sizeof(int), 0) == hipSuccess) *d->h_id_error = 0;
+    if (const char* e = getenv("RGRG_DECODE_FREE")) d->free_ranges = atoi(e) != 0;
+    {
+        bool ok = hipHostMalloc((void**)&d->h_rdone, 3 * MAX_CHAINS * sizeof(int), 0) == hipSuccess;
+        for (int a = 0; ok && a < 2; ++a)
+            for (int i = 0; ok && i < MAX_CHAINS; ++i) ok = hipEventCreateWithFlags(&d->ev_rpoll[a][i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { set_error("decoder: pinned memory / event creation failed"); rgrg_decoder_destroy(d); return RGRG_EHIP; }
+    }
     if (hipHostMalloc((void**)&d->h_done, 4 * sizeof(int), 0) != hipSuccess ||
         hipEventCreateWithFlags(&d->ev_poll[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&d->ev_poll[1], hipEventDisableTiming) != hipSuccess) {
@@ -2280,6 +2319,8 @@ extern "C" int rgrg_decoder_create_with_cache(const rgrg_decoder_weights* w, int
     TRY(dmalloc(d, (void**)&d->next, R * 4, true));
     TRY(dmalloc(d, (void**)&d->finished, R * 4, true));
     TRY(dmalloc(d, (void**)&d->step, 4, true));
+    d->step_ptr = d->step;
+    TRY(dmalloc(d, (void**)&d->range_state, MAX_CHAINS * 4 * sizeof(int), true));
     TRY(dmalloc(d, (void**)&d->done_len, 4, true));
     TRY(dmalloc(d, (void**)&d->sync, 64, true));
     TRY(dmalloc(d, (void**)&d->id_error, 8, true));
@@ -2382,6 +2423,10 @@ extern "C" void rgrg_decoder_destroy(rgrg_decoder* d) {
     tr_free(d);
     if (d->a16_scratch) (void)hipFree(d->a16_scratch);
     if (d->h_done) (void)hipHostFree(d->h_done);
+    if (d->h_rdone) (void)hipHostFree(d->h_rdone);
+    for (auto& a : d->ev_rpoll)
+        for (hipEvent_t e : a)
+            if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : d->ev_poll)
         if (e) (void)hipEventDestroy(e);
     if (d->h_id_error) (void)hipHostFree(d->h_id_error);
@@ -2407,6 +2452,94 @@ extern "C" int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S,
     int rc = enqueue_prefill(d, feats, S);
     if (rc) return rc;
 
+    // Free-running row ranges (round 6, OPT-IN: RGRG_DECODE_FREE=1): in the many-sequence 16-bit greedy mode every kernel of a step
+    // is row-local - embedding, the 24 layers, ln_f, lm_head (arg-max epilogue), arg-max and the EOS bookkeeping - so each row range
+    // can own a step graph, a stream and state words and replay its steps without ever meeting the other ranges (no join in front
+    // of the lm_head, nobody waits for the slowest chain).  Same kernels per row: ids identical (tests).  Measured
+    // (profiles/r06_free_ranges_ab.log): 3 free ranges 2.725 ms per step against 2.764 for 4 joined ranges - the step is bound by
+    // what its kernels consume together, not by the order they run in - and 4 free ranges on this process's 4 hardware queues
+    // 4.08 ms: a HIP stream is bound to one of GPU_MAX_HW_QUEUES (4) hardware queues, a process holds more streams than that
+    // (torch's, the decoder's; RCCL adds its own), and two ranges that land on one queue serialise - the joined step's graph lets
+    // the runtime place its branches.  Not the default for that reason.
+    {
+        int bounds[MAX_CHAINS + 1];
+        const bool xn16 = kv_is_bf16(d, S) && d->xn16;
+        const bool fold = xn16 && d->ln_fold && d->ln_stat && d->layers[0].c_attn.wb_ln && d->D == 1024;
+        const int want = step_chains(d, S, true, fold);
+        const int nr = (use_graph && d->free_ranges && want > 1 && fold && lm_head_cand_path(d, S) && d->h_rdone) ? range_bounds(S, want, bounds) : 1;
+        if (nr > 1) {
+            hipGraphExec_t ex[MAX_CHAINS] = {};
+            hipStream_t rs[MAX_CHAINS];
+            for (int i = 0; i < nr; ++i) rs[i] = i ? d->streams_x[i - 1] : d->stream;
+            for (int i = 0; i < nr; ++i) {
+                for (auto& g : d->graphs)
+                    if (g.S == S && g.key2 == 100 + i && g.key3 == nr) ex[i] = g.exec;
+                if (ex[i]) continue;
+                hipGraph_t graph = nullptr;
+                const RangeSpec spec{bounds[i], bounds[i + 1] - bounds[i]};
+                std::swap(d->stream, rs[i]);       // (i == 0: a swap with itself)
+                d->step_ptr = d->range_state + 4 * i;
+                hipError_t e = hipStreamBeginCapture(d->stream, hipStreamCaptureModeThreadLocal);
+                if (e == hipSuccess) {
+                    rc = enqueue_step(d, S, false, nullptr, nullptr, false, &spec);
+                    e = hipStreamEndCapture(d->stream, &graph);
+                }
+                d->step_ptr = d->step;
+                std::swap(d->stream, rs[i]);
+                if (rc) return rc;
+                if (e != hipSuccess) { set_error("range step capture: %s", hipGetErrorString(e)); return RGRG_EHIP; }
+                RGRG_HIP(hipGraphInstantiate(&ex[i], graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+                d->graphs.push_back({S, ex[i], 100 + i, nr});
+            }
+            const int steps = limit - 1;
+            RGRG_HIP(hipMemsetAsync(d->range_state, 0, MAX_CHAINS * 4 * sizeof(int), d->stream));
+            RGRG_HIP(hipEventRecord(d->ev_fork, d->stream));
+            for (int i = 1; i < nr; ++i) RGRG_HIP(hipStreamWaitEvent(rs[i], d->ev_fork, 0));
+            int polls = 0;
+            for (int t = 0; t < steps; ++t) {
+                for (int i = 0; i < nr; ++i) RGRG_HIP(hipGraphLaunch(ex[i], rs[i]));
+                if ((t & 15) == 15 && t + 1 < steps) {   // "every row has emitted EOS", polled 16 steps late (see the joined loop below)
+                    if (polls > 0) {
+                        const int prev = (polls - 1) & 1;
+                        bool all = true;
+                        for (int i = 0; i < nr; ++i) {
+                            RGRG_HIP(hipEventSynchronize(d->ev_rpoll[prev][i]));
+                            all = all && d->h_rdone[prev * MAX_CHAINS + i] != 0;
+                        }
+                        if (all) break;
+                    }
+                    const int cur = polls & 1;
+                    for (int i = 0; i < nr; ++i) {
+                        RGRG_HIP(hipMemcpyAsync(d->h_rdone + cur * MAX_CHAINS + i, d->range_state + 4 * i + 1, sizeof(int), hipMemcpyDeviceToHost, rs[i]));
+                        RGRG_HIP(hipEventRecord(d->ev_rpoll[cur][i], rs[i]));
+                    }
+                    ++polls;
+                }
+            }
+            for (int i = 1; i < nr; ++i) {
+                RGRG_HIP(hipEventRecord(d->ev_join[i - 1], rs[i]));
+                RGRG_HIP(hipStreamWaitEvent(d->stream, d->ev_join[i - 1], 0));
+            }
+            for (int i = 0; i < nr; ++i)
+                RGRG_HIP(hipMemcpyAsync(d->h_rdone + 2 * MAX_CHAINS + i, d->range_state + 4 * i + 1, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+            RGRG_HIP(hipMemcpy2DAsync(out_ids, (size_t)out_ld * sizeof(int64_t), d->ids, (size_t)d->max_len * sizeof(long long),
+                                      (size_t)limit * sizeof(int64_t), S, hipMemcpyDeviceToDevice, d->stream));
+            RGRG_HIP(hipStreamSynchronize(d->stream));
+            // the single-process done length = the first length at which EVERY row is finished = the latest of the ranges'
+            int done = 0;
+            bool all = true;
+            for (int i = 0; i < nr; ++i) {
+                const int v = d->h_rdone[2 * MAX_CHAINS + i];
+                all = all && v != 0;
+                done = v > done ? v : done;
+            }
+            *out_len = (all && done > 0 && done < limit) ? done : limit;
+            d->logits_stale_rows = S;
+            d->logits_valid = true;
+            return RGRG_OK;
+        }
+    }
     hipGraphExec_t exec = nullptr;
     if (use_graph) {
         for (auto& g : d->graphs)
