@@ -302,13 +302,13 @@ def test_many_sequence_step_in_row_ranges_is_bit_identical_to_one_range():
     res = {}
     with tempfile.TemporaryDirectory() as tmp:
         for name, env_add in (("one", {"RGRG_DECODE_CHAINS": "1"}), ("default", {}), ("two", {"RGRG_DECODE_CHAINS": "2"}),
-                              ("four", {"RGRG_DECODE_CHAINS": "4"})):
+                              ("four", {"RGRG_DECODE_CHAINS": "4"}), ("free", {"RGRG_DECODE_FREE": "1", "RGRG_DECODE_CHAINS": "3"})):
             path = os.path.join(tmp, name + ".pt")
             env = {k: v for k, v in os.environ.items() if k != "RGRG_DECODE_CHAINS"}
             r = subprocess.run([sys.executable, "-c", code, path], env=dict(env, **env_add), capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             res[name] = torch.load(path)
-    for name in ("default", "two", "four"):
+    for name in ("default", "two", "four", "free"):   # free: round 6, every range replays its own step graph on its own stream (opt-in)
         for (ids1, lg1), (ids0, lg0) in zip(res[name], res["one"]):
             assert torch.equal(ids1, ids0), name
             assert torch.equal(lg1, lg0), name
