@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--cold", action="store_true",
                     help="cycle through enough weight copies (> 600 MB) that no launch finds its W in the 256 MB Infinity Cache: the "
                          "regime of a decode step, which streams 0.7 GB of weights between two uses of the same matrix")
+    ap.add_argument("--copies-mb", type=int, default=600,
+                    help="--cold: total size of the weight copies cycled through (600: past the 256 MB Infinity Cache; ~150: past the 32 MB of L2 "
+                         "but inside the Infinity Cache - what a weight prefetch into it would give)")
     args = ap.parse_args()
     M = args.M
     lib = _hip.load()
@@ -62,7 +65,7 @@ def main():
         A = torch.rand((M, K), device="cuda") * 2 - 1
         W = (torch.rand((N, K), device="cuda") * 2 - 1) / K ** 0.5
         A16 = torch.empty((M, K), dtype=torch.int16, device="cuda")
-        ncopy = max(1, -(-600_000_000 // (N * K * 2))) if args.cold else 1
+        ncopy = max(1, -(-args.copies_mb * 1_000_000 // (N * K * 2))) if args.cold else 1
         Wb = torch.empty((ncopy, N, K), dtype=torch.int16, device="cuda")
         b = torch.randn((N,), device="cuda")
         Y = torch.zeros((M, N), device="cuda")
