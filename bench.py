@@ -72,7 +72,8 @@ def rooflines(eng, S_dec, dtype, max_length):
     # ranges' attention), so there is no per-launch duration to take from it.  The roofline times every kernel ALONE on the GPU at
     # the step's full row count (one_range) - the figure a serialising profiler gives for a 1-range step (profiles/
     # r06_kernel_trace_summary_b32_bf16_one_range.md) - and quotes the as-launched (concurrent) family times next to it.
-    many = S_dec > (128 if dtype == "f32" else 32)   # the many-sequence path: > 128 rows, or > 32 under autocast (decoder.hip decode_row_limit)
+    many = S_dec > eng.fused_row_limit()   # the many-sequence path: > 128 rows, or > 64 under autocast (decoder.hip decode_row_limit)
+    w16 = not many and dtype != "f32" and S_dec > 32   # 33-64 rows under autocast: the fused plan on 16-bit weights
     ranged = S_dec >= 512 and dtype != "f32"
     p = eng.time_step_parts(S_dec, nkeys, iters=10, one_range=ranged)   # (3 replays read 3-6 % slow: the first one runs on ramping clocks)
     p_conc = eng.time_step_parts(S_dec, nkeys, iters=10) if ranged else None
@@ -81,10 +82,10 @@ def rooflines(eng, S_dec, dtype, max_length):
     a_traffic, a_src = pmc_traffic("attn", S_dec, dtype)
     if not many:
         ach = p["gemm_weight_bytes"] / (p["ms_gemm"] * 1e-3) / 1e9
-        gemm = {"bound": "hbm", "kernel": "rgrg_skinny_direct_f32 (+ _half, rgrg_lm_head_wave_f32)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        gemm = {"bound": "hbm", "kernel": "rgrg_skinny_direct_f32<.., W16> (16-bit weights)" if w16 else "rgrg_skinny_direct_f32 (+ _half, rgrg_lm_head_wave_f32)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": g_traffic, "traffic_source": g_src, "launches_per_decode_step": n,
                 "avg_launch_us": 1e3 * p["ms_gemm"] / n, "algorithmic_bytes_per_launch": p["gemm_weight_bytes"] / n,
-                "note": "achieved = fp32 weight bytes of the GEMM launches of one decode step (each weight read once) / their duration "
+                "note": "achieved = " + ("16-bit" if w16 else "fp32") + " weight bytes of the GEMM launches of one decode step (each weight read once) / their duration "
                         "between two HIP events on the decoder stream, launched back to back in step order"}
     else:
         peak = MFMA_PEAK_TFS["f32" if dtype == "f32" else "bf16"]
@@ -285,7 +286,7 @@ def generate_leg(model, synth, batch, dtype, max_length, steps, warmup, dev, num
     if with_rooflines:
         try:
             rows = S * num_beams
-            res["roofline"], res["roofline_secondary"] = rooflines(model.engine(), max(rows, 1), dtype if (dtype != "f32" and rows > 32) else "f32", max_length)
+            res["roofline"], res["roofline_secondary"] = rooflines(model.engine(), max(rows, 1), dtype if (dtype != "f32" and rows > 32) else "f32", max_length)   # <= 32 rows: bit-exact fp32 whatever the autocast state
             res["roofline_detector"], res["roofline_roialign"] = detector_rooflines(model.engine(), images, dtype != "f32")
         except Exception as e:  # noqa: BLE001
             res["roofline"] = {"error": str(e)}
@@ -592,7 +593,7 @@ def main():
             res["beam4"] = dict(generate_leg(model, synth, 1, "f16", 300, 3, 1, dev, num_beams=4, early_stopping=True),
                                 workload="generate_reports_for_images.py:108-114 mode: 1 image, num_beams=4 (116 beam rows), max_length=300, "
                                          "early_stopping=True, torch.autocast(float16): 16-bit detector, and - round 6 - the 116 beam rows on the 16-bit "
-                                         "many-sequence decode path (> 32 rows under autocast; the fp32 fused plan before)",
+                                         "many-sequence decode path (> 64 rows under autocast; the fp32 fused plan before)",
                                 metric="images/sec full 29-region report gen, 512x512 CXR, beam search num_beams=4 max_len=300")
         except Exception as e:  # noqa: BLE001
             res["beam4"] = {"error": str(e)}

@@ -434,6 +434,10 @@ int rgrg_decoder_trace_step(rgrg_decoder* d, int S, int nkeys, int iters, float*
 /* Measurement hook: `iters` x n_layer single-query attention launches (GPT2PseudoAttention, language_model.py:124-180) of the
  * many-sequence step at `nkeys` keys, asynchronously on `stream` (state of the last generate() of S sequences). */
 int rgrg_decoder_attention_only(rgrg_decoder* d, int S, int nkeys, int iters, void* stream);
+/* Token rows (sequences x beams) up to which a decode step of d runs the fused fragment-direct plan in its CURRENT precision mode
+ * (128 in fp32; under autocast 64: <= 32 rows bit-exact fp32, 33-64 on 16-bit weights); more rows take the many-sequence path.
+ * -1 for a null handle.  (No reference counterpart: the reference has one code path, HF GPT-2 modules under torch.autocast.) */
+int rgrg_decoder_row_limit(rgrg_decoder* d);
 
 /* Measurement helper (tools/microbench.py; not on the product path): host wall
  * microseconds per kernel of a dependent chain of n trivial kernels; mode 0 = eager on a

@@ -1474,6 +1474,11 @@ struct Lin {
     // the LayerNorm this GEMM consumes when lnf is set; c1 / c2 are the folded vectors of that LayerNorm
     bool direct = false, lnf = false;
     float *c1 = nullptr, *c2 = nullptr;
+    // 16-bit-weight variant of the fused plan (33-128 rows under autocast, round 6): `packed` rounded to the autocast type, and
+    // the column sums of those ROUNDED values (lnf)
+    void* packed16 = nullptr;
+    float* c1_16 = nullptr;
+    int packed16_f16 = -1;
 };
 
 struct LayerW {
@@ -1562,6 +1567,8 @@ struct rgrg_decoder {
     // rgrg_decoder_trace_step: one hipEvent after every launch of an eagerly enqueued step, on the stream it was launched on
     struct TraceMark { hipEvent_t ev; int r0; int tag; };
     std::vector<TraceMark>* trace = nullptr;
+    bool w16_fused = true;      // under autocast 33-128 rows run the fused plan on 16-bit weights (skinny_direct.inc W16); RGRG_W16_FUSED=0: the
+                                // many-sequence 16-bit path from 33 rows on (A/B)
     int kp_gemms = 2;           // ... and run on the K-parity ping-pong kernel (gemm_kp.inc, round 6): RGRG_GEMM_KP = 0 none (the LDS-DMA kernel), 1 all four,
                                 // 2 (default) the producers only (attn_proj / mlp_proj, N = 1024), 3 the consumers only (c_attn / c_fc, 128 x 128 row-split kernel).
                                 // Measured per mode: profiles/r06_step_trace_v3.log
@@ -1693,22 +1700,26 @@ static int init_skinny_attrs() {
 
 // bf16 K/V cache: with the bf16 GEMMs, i.e. on the many-sequence path of the opt-in bf16 mode.  `rows` is the
 // number of token rows of the decode steps (sequences x beams), the same for every launch of one generate call.
-// Rows up to which a decode step runs the fused fp32 plan (fragment-direct skinny kernels, bit-exact): 128 without autocast.
-// Round 6: under torch.autocast (16-bit mode) only up to 32 rows (RGRG_SKINNY_MAX_ROWS_16) - one row tile, i.e. batch-1 greedy
-// decoding stays on the bit-exact path - and anything larger takes the many-sequence 16-bit path: the reference computes these
-// GEMMs in 16 bit under autocast anyway, and the exact-fp32 MFMA is 1/16 of the 16-bit rate - the scripts' own mode (1 image,
-// 4 beams = 116 rows, fp16 autocast) went from 914 to 584 ms per image, greedy batch 4 from 11.4 to 20.1 images/s
-// (profiles/r06_small_batch_16bit_threshold.log).
-static int skinny_max_rows16() {
-    static const int v = [] {
+// Rows up to which a decode step runs the fused plan (fragment-direct skinny kernels): 128 without autocast (fp32, bit-exact).
+// Under torch.autocast (16-bit mode), round 6:
+//   * one row tile (<= 32 rows, batch-1 greedy decoding) stays on the bit-exact fp32 kernels;
+//   * 33-64 rows run the SAME plan on 16-bit weights (skinny_direct.inc W16: half the weight stream, one 16-bit MFMA per k chunk):
+//     greedy batch 2 (58 rows) 193 -> 166 ms per generate() call;
+//   * anything larger takes the many-sequence 16-bit path: every workgroup of the fused plan reads ALL rows of its K slice for a
+//     16-column tile, and from 3 row tiles on that L2 traffic (116 rows: ~360 MB per layer) costs more than the tiled 16-bit GEMMs'
+//     launch chain - 1 image x 4 beams (116 rows, fp16): 914 ms on the fp32 plan, 724 ms on W16, 576 ms on the many-sequence path;
+//     greedy batch 4: 352 / 273 / 199 ms (profiles/r06_small_batch_16bit_threshold.log, profiles/r06_w16_fused_ab.log).
+// RGRG_SKINNY_MAX_ROWS_16 moves the boundary (32..128), RGRG_W16_FUSED=0 drops the 16-bit-weight copies (boundary 32).
+static int skinny_max_rows16(bool w16) {
+    static const int env = [] {
         const char* e = getenv("RGRG_SKINNY_MAX_ROWS_16");
-        int n = e ? atoi(e) : 32;
-        n = n < 32 ? 32 : n;
-        return n > skinny_max_rows() ? skinny_max_rows() : n;
+        return e ? atoi(e) : 0;
     }();
-    return v;
+    int n = env ? env : (w16 ? 64 : 32);
+    n = n < 32 ? 32 : n;
+    return n > skinny_max_rows() ? skinny_max_rows() : n;
 }
-static int decode_row_limit(const rgrg_decoder* d) { return d->bf16_gemms ? skinny_max_rows16() : skinny_max_rows(); }
+static int decode_row_limit(const rgrg_decoder* d) { return d->bf16_gemms ? skinny_max_rows16(d->w16_fused) : skinny_max_rows(); }
 static bool kv_is_bf16(const rgrg_decoder* d, int rows) { return d->bf16_gemms && rows > decode_row_limit(d); }
 
 // Measurement builds: the stamp block of the next launch of the fused decode step (null in the product build / without
@@ -1839,6 +1850,9 @@ static int direct_linear(rgrg_decoder* d, const Lin& l, DirectArgs a, int mode, 
     if (l.KS > 1) a.part_out = d->part;
     if (cand) { a.cand_val = d->cand_val; a.cand_idx = d->cand_idx; }
     const int mt = (M + PAD_ROWS - 1) / PAD_ROWS;
+    // under autocast, more than one row tile: the 16-bit-weight kernels (one row tile - batch-1 greedy decoding - stays bit-exact fp32)
+    const int w16 = (d->bf16_gemms && d->w16_fused && mt > 1 && l.packed16 && l.packed16_f16 == d->f16() && (!l.lnf || l.c1_16)) ? (d->f16() ? 2 : 1) : 0;
+    if (w16) { a.P = reinterpret_cast<const float*>(l.packed16); if (l.lnf) a.c1 = l.c1_16; }
     const dim3 grid(l.NT, l.KS), blk(64 * SK_WAVES);
     hipStream_t st = d->stream;
     if (l.lnf && mode == DX_COMBINE4 && l.NT > 512 && mt == 1 && l.K == DK_SLICE) {  // lm_head, one row tile: a wave per column tile
@@ -1850,7 +1864,14 @@ static int direct_linear(rgrg_decoder* d, const Lin& l, DirectArgs a, int mode, 
         hipLaunchKernelGGL(rgrg_skinny_direct_half_f32, dim3(l.NT, 2), blk, 0, st, a);
     } else {
         a.stamps = stamp_slot(d, l.N == 3 * d->D ? "c_attn'" : l.KS > 1 ? "mlp_proj" : l.N == 4 * d->D ? "c_fc'" : "skinny_direct", l.NT * l.KS);
-#define DX_LAUNCH(MT_, MODE_, LNF_) hipLaunchKernelGGL((rgrg_skinny_direct_f32<MT_, MODE_, LNF_>), grid, blk, 0, st, a)
+#define DX_LAUNCH(MT_, MODE_, LNF_)                                                                                          \
+    do {                                                                                                                      \
+        if constexpr (MT_ > 1) {                                                                                              \
+            if (w16 == 1) { hipLaunchKernelGGL((rgrg_skinny_direct_f32<MT_, MODE_, LNF_, 1>), grid, blk, 0, st, a); break; }  \
+            if (w16 == 2) { hipLaunchKernelGGL((rgrg_skinny_direct_f32<MT_, MODE_, LNF_, 2>), grid, blk, 0, st, a); break; }  \
+        }                                                                                                                     \
+        hipLaunchKernelGGL((rgrg_skinny_direct_f32<MT_, MODE_, LNF_>), grid, blk, 0, st, a);                                  \
+    } while (0)
 #define DX_MODES(MT_)                                                                        \
     do {                                                                                     \
         if (!l.lnf && mode == DX_PLAIN) DX_LAUNCH(MT_, DX_PLAIN, false);                     \
@@ -1871,7 +1892,7 @@ static int direct_linear(rgrg_decoder* d, const Lin& l, DirectArgs a, int mode, 
     }
     RGRG_LAUNCH_CHECK();
     if (count) {
-        d->gemm_bytes_per_step += (size_t)l.N * l.K * sizeof(float);
+        d->gemm_bytes_per_step += (size_t)l.N * l.K * (w16 ? 2 : sizeof(float));
         d->gemm_flops_per_step += 2.0 * M * l.N * l.K;
         d->gemm_launches_per_step += 1;
     }
@@ -2244,6 +2265,7 @@ extern "C" int rgrg_decoder_create_with_cache(const rgrg_decoder_weights* w, int
         return RGRG_EHIP;
     }
     if (const char* e = getenv("RGRG_GEMM_KP")) d->kp_gemms = atoi(e);
+    if (const char* e = getenv("RGRG_W16_FUSED")) d->w16_fused = atoi(e) != 0;
     if (const char* e = getenv("RGRG_DECODE_CHAINS")) {
         const int v = atoi(e);
         d->chains = (v >= -MAX_CHAINS && v <= MAX_CHAINS && v != 0 && v != -1) ? v : 1;
@@ -3612,6 +3634,27 @@ static int set_precision_impl(rgrg_decoder* d, int mode) {
         for (auto& w : d->layers) {
             if ((rc2 = mk(w.c_attn)) || (rc2 = mk(w.attn_proj)) || (rc2 = mk(w.c_fc)) || (rc2 = mk(w.mlp_proj))) return rc2;
         }
+        // the fragment-packed weights of the fused plan rounded to the autocast type (33-128 rows, skinny_direct.inc W16), and for the
+        // GEMMs behind a LayerNorm the column sums of the ROUNDED values (the folded mean term must match what the MFMA multiplies)
+        if (d->w16_fused) {
+            auto mk16 = [&](Lin& l) -> int {
+                if (!l.direct || !l.packed || (l.packed16 && l.packed16_f16 == d->f16())) return RGRG_OK;
+                const size_t n = (size_t)l.NT * 16 * l.K;
+                int r;
+                if (!l.packed16 && (r = dmalloc(d, &l.packed16, n * 2, false))) return r;
+                if (l.lnf && !l.c1_16 && (r = dmalloc(d, (void**)&l.c1_16, (size_t)l.NT * 16 * sizeof(float), false))) return r;
+                if ((r = convert_f32_to_bf16(l.packed, l.packed16, n, d->stream, d->f16()))) return r;
+                if (l.lnf)
+                    hipLaunchKernelGGL(packed16_colsum_kernel, dim3(l.NT), dim3(64), 0, d->stream, (const unsigned short*)l.packed16, l.c1_16, l.NT * 16, l.K,
+                                       d->f16());
+                l.packed16_f16 = d->f16();
+                return RGRG_OK;
+            };
+            if ((rc2 = mk16(d->lm_head))) return rc2;
+            for (auto& w : d->layers) {
+                if ((rc2 = mk16(w.c_attn)) || (rc2 = mk16(w.attn_proj)) || (rc2 = mk16(w.c_fc)) || (rc2 = mk16(w.mlp_proj))) return rc2;
+            }
+        }
         // the gain-scaled copies of the GEMMs that sit behind a LayerNorm (c_attn: ln_1, c_fc: ln_2, lm_head: ln_f)
         if (const char* e = getenv("RGRG_LN_FOLD")) d->ln_fold = atoi(e) != 0;
         if (d->ln_fold && d->D == 1024) {
@@ -3681,6 +3724,10 @@ extern "C" int rgrg_decoder_copy_last_logits(rgrg_decoder* d, float* dst, int S,
 //     (fused fragment-direct kernels <= 128 rows, tiled fp32 / bf16-weight MFMA GEMMs above);
 //   * the single-query attention at `nkeys` keys per sequence (the step counter is set to nkeys - 2 for the timing).
 // Token / cache contents are whatever the last generate() left: timing only.
+// Token rows (sequences x beams) up to which a decode step of `d` runs the fused fragment-direct plan IN ITS CURRENT precision mode
+// (128 in fp32; 64 under autocast - 33-64 on 16-bit weights; decode_row_limit above); more rows take the many-sequence path.
+extern "C" int rgrg_decoder_row_limit(rgrg_decoder* d) { return d ? decode_row_limit(d) : -1; }
+
 // Measurement hook (tools/overlap_probe.py): `iters` x n_layer attention launches of the many-sequence step at `nkeys` keys on the
 // caller's stream (asynchronous; the state of the last generate() of S sequences) - the HBM-bound half of a decode step as a
 // background load beside other work.

@@ -1000,6 +1000,10 @@ class HipEngine:
                    "rgrg_decoder_time_train_gemms")
         return {"ms_gemm": ms.value, "gemm_flops": fl.value, "gemm_launches": n.value}
 
+    def fused_row_limit(self) -> int:
+        """Token rows up to which the decoder of the last generate() runs the fused plan in its precision mode (above: many-sequence path)."""
+        return int(self.lib.rgrg_decoder_row_limit(self._decoder))
+
     def time_step_parts(self, S: int, nkeys: int, iters: int = 3, one_range: bool = False) -> Dict[str, float]:
         """Per decode step, measured with HIP events on the decoder's stream (bench.py roofline): ms spent in the
         projection GEMM launches and in the 24 attention launches (at ``nkeys`` keys), with the algorithmic flops /

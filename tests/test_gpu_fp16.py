@@ -30,12 +30,12 @@ S, L = {S}, {L}
 g = torch.Generator().manual_seed(35)
 feats = torch.randn((S, 1024), generator=g)
 m = gpu_model("bench")
-with torch.autocast("cuda", dtype=torch.float16):
+with torch.autocast("cuda", dtype=torch.{d1}):
     ids = m.language_model.generate(feats.to("cuda:0"), max_length=L)
 hip = m.engine().last_logits(S).cpu()
-with torch.autocast("cuda", dtype=torch.bfloat16):      # switching the 16-bit type re-converts the weight copies
+with torch.autocast("cuda", dtype=torch.{d2}):      # switching the 16-bit type re-converts the weight copies
     ids_b = m.language_model.generate(feats.to("cuda:0"), max_length=L)
-with torch.autocast("cuda", dtype=torch.float16):       # ... and back: bit-identical to the first fp16 run
+with torch.autocast("cuda", dtype=torch.{d1}):       # ... and back: bit-identical to the first run
     ids_again = m.language_model.generate(feats.to("cuda:0"), max_length=L)
 ids = ids.cpu()
 sd = synth_sd("bench")
@@ -43,7 +43,7 @@ T = ids.shape[1] - 1
 pos = torch.arange(T)[None, :]
 am = torch.ones((S, T), dtype=torch.int64)
 with torch.no_grad():
-    lo16, _ = o_lm.lm_forward(sd, ids[:, :T], am, feats, None, pos, bf16=2)
+    lo16, _ = o_lm.lm_forward(sd, ids[:, :T], am, feats, None, pos, bf16={ob})
     lo32, _ = o_lm.lm_forward(sd, ids[:, :T], am, feats, None, pos, bf16=False)
 lo16, lo32 = lo16[:, -1], lo32[:, -1]
 rng = lo32.abs().max().item()
@@ -61,7 +61,7 @@ def test_fp16_decode_100_steps_against_fp16_oracle():
     attn_decode_kv16_wave_kernel) for 100 tokens against the ORACLE doing the same fp16 arithmetic, teacher-forced on the
     token history the HIP path chose.  RGRG_SKINNY_MAX_ROWS = 32 in a child process so that 40 rows take the 16-bit path."""
     env = dict(os.environ, RGRG_SKINNY_MAX_ROWS="32")
-    res = subprocess.run([sys.executable, "-c", _SCRIPT.format(repo=REPO, S=40, L=100)], env=env, capture_output=True, text=True, timeout=1500)
+    res = subprocess.run([sys.executable, "-c", _SCRIPT.format(repo=REPO, S=40, L=100, d1="float16", d2="bfloat16", ob=2)], env=env, capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0, res.stderr[-2000:]
     r = json.loads(res.stdout.strip().splitlines()[-1])
     assert r["len"] == 100 and r["keys"] == 100
@@ -70,6 +70,27 @@ def test_fp16_decode_100_steps_against_fp16_oracle():
     assert r["err_vs_fp16_oracle"] <= 4e-3 * r["range"], r
     assert r["err_vs_fp32_oracle"] <= 5e-3 * r["range"], r
     assert r["argmax_agree_fp16_oracle"] >= 0.95 - 1e-6 and r["next_token_is_argmax"] == 1.0, r
+    assert r["same_after_switching"] and r["differs_from_bf16"], r
+
+
+@pytest.mark.parametrize("S,L,dtype", [(40, 64, "float16"), (64, 40, "float16"), (58, 48, "bfloat16")])
+def test_fused_plan_on_16bit_weights_33_to_64_rows(S, L, dtype):
+    """33-64 rows under autocast (greedy batch 2; round 6): the fused fragment-direct plan on 16-bit weight fragments
+    (skinny_direct.inc W16: v_mfma_f32_16x16x16_{f16,bf16} on weights rounded once and activations rounded on their way into the
+    matrix core; fp32 K/V cache, attention, LayerNorm statistics and residual stream) against the oracle in the same 16-bit type,
+    teacher-forced on the tokens the HIP path chose.  Same noise-level bounds as the many-sequence path of that type (fp16: above;
+    bf16: tests/test_gpu_parity_r03.py); 64 rows = the last row count on this plan."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RGRG_SKINNY_MAX_ROWS", "RGRG_SKINNY_MAX_ROWS_16", "RGRG_W16_FUSED")}
+    f16 = dtype == "float16"
+    script = _SCRIPT.format(repo=REPO, S=S, L=L, d1=dtype, d2="bfloat16" if f16 else "float16", ob=2 if f16 else "True")
+    res = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stderr[-2000:]
+    r = json.loads(res.stdout.strip().splitlines()[-1])
+    assert r["len"] == L and r["keys"] == L
+    tol16, tol32, agree = (4e-3, 5e-3, 0.95) if f16 else (2e-2, 3e-2, 0.85)
+    assert r["err_vs_fp16_oracle"] <= tol16 * r["range"], r
+    assert r["err_vs_fp32_oracle"] <= tol32 * r["range"], r
+    assert r["argmax_agree_fp16_oracle"] >= agree - 1e-6 and r["next_token_is_argmax"] == 1.0, r
     assert r["same_after_switching"] and r["differs_from_bf16"], r
 
 
