@@ -438,6 +438,9 @@ int rgrg_decoder_attention_only(rgrg_decoder* d, int S, int nkeys, int iters, vo
  * (128 in fp32; under autocast 64: <= 32 rows bit-exact fp32, 33-64 on 16-bit weights); more rows take the many-sequence path.
  * -1 for a null handle.  (No reference counterpart: the reference has one code path, HF GPT-2 modules under torch.autocast.) */
 int rgrg_decoder_row_limit(rgrg_decoder* d);
+/* Measurement hook (tools/attn_confine_probe.py): where the hardware placed each of n_wgs one-wave workgroups - out[2 i] = HW_ID
+ * (wave / SIMD / CU / SH / SE fields), out[2 i + 1] = XCC_ID of workgroup i.  No reference counterpart. */
+int rgrg_debug_hw_ids(unsigned* out, int n_wgs, void* stream);
 
 /* Measurement helper (tools/microbench.py; not on the product path): host wall
  * microseconds per kernel of a dependent chain of n trivial kernels; mode 0 = eager on a

@@ -16,7 +16,7 @@ c_float_p = C.c_void_p  # device pointers travel as void*
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p
 
 ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
-ABI_VERSION = 19  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
+ABI_VERSION = 20  # must equal rgrg_abi_version() of the loaded library; bump both on ANY signature change
 
 
 class RgrgHipError(RuntimeError):
@@ -92,6 +92,7 @@ SIGNATURES = {
     "rgrg_decoder_trace_step": (_i, [_p, _i, _i, _i, _p, _i, C.POINTER(_i)]),
     "rgrg_decoder_attention_only": (_i, [_p, _i, _i, _i, _p]),
     "rgrg_decoder_row_limit": (_i, [_p]),
+    "rgrg_debug_hw_ids": (_i, [_p, _i, _p]),
     "rgrg_decoder_set_lm_positions": (_i, [_p, _p, C.c_int64]),
     "rgrg_decoder_time_step_parts": (_i, [_p, _i, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),

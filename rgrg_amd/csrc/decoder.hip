@@ -783,6 +783,21 @@ __global__ __launch_bounds__(256) void attn_decode_kv16_wave_kernel(const float*
     }   // items
 }
 
+// Measurement hook kernel: where the hardware put every workgroup - HW_ID (wave / SIMD / CU / SH / SE fields) and XCC_ID
+__global__ __launch_bounds__(64) void hw_ids_kernel(unsigned* __restrict__ out) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    __builtin_amdgcn_s_sleep(64);
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = hwid; out[2 * blockIdx.x + 1] = xcc; }
+}
+extern "C" int rgrg_debug_hw_ids(unsigned* out, int n_wgs, void* stream) {
+    RGRG_CHECK_ARG(out && n_wgs > 0);
+    hipLaunchKernelGGL(hw_ids_kernel, dim3(n_wgs), dim3(64), 0, as_stream(stream), out);
+    RGRG_LAUNCH_CHECK();
+    return RGRG_OK;
+}
+
 // image key/value (uk/uv outputs) -> cache slot 0 of every layer
 template <typename KV>  // float, or u16 (bf16 cache)
 __global__ __launch_bounds__(256) void kv_slot0_kernel(const float* __restrict__ ukv, int ld, KV* __restrict__ kv_all,

@@ -15,7 +15,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace rgrg
 
 extern "C" const char* rgrg_last_error(void) { return rgrg::g_err; }
-extern "C" int rgrg_abi_version(void) { return 19; }  // keep in step with rgrg_amd/_hip.py ABI_VERSION
+extern "C" int rgrg_abi_version(void) { return 20; }  // keep in step with rgrg_amd/_hip.py ABI_VERSION
 extern "C" int rgrg_device_arch(int dev, char* buf, int buflen) {
     RGRG_CHECK_ARG(buf && buflen > 1);
     hipDeviceProp_t prop;
