@@ -184,7 +184,8 @@ int rgrg_decoder_generate(rgrg_decoder* d, const float* feats, int S, int max_le
                           int out_ld, int* out_len, int use_graph, void* stream);
 /* Beam search (LanguageModel.generate num_beams > 1 -> beam_search, language_model.py:450-475,
  * :529-607, with transformers 4.19.2 BeamSearchScorer semantics; 1 <= num_return_sequences <= num_beams).
- * The decoder must have been created with max_seqs >= S*num_beams; num_beams <= 16.
+ * The decoder must have been created with max_seqs >= S*num_beams.  Any num_beams, as in the reference (up to 16 the row / item
+ * rankings keep per-thread candidate lists in registers; wider beams rank in 2*num_beams rounds over the row - same winners).
  * Device side: one decode step over the S*num_beams beam rows (KV cache never re-ordered:
  * per-slot ancestor table), per-row log-sum-exp + top-2*num_beams, per-item merge.  Host
  * side (one small D2H/H2D per step, like the reference's scorer): hypothesis bookkeeping.

@@ -1050,6 +1050,97 @@ __global__ __launch_bounds__(BEAM_MERGE_THREADS) void beam_merge_kernel(const fl
     }
 }
 
+// ---- more than 16 beams (round 6: the reference's loop has no bound, language_model.py:450-475).  The per-thread sorted lists of the
+// kernels above hold 32 candidates in registers; wider beams take K = 2 num_beams rounds of a block-wide arg-max over the elements
+// that come AFTER the previous winner in the same total order (value desc, index asc) - K scans of the row from L2 instead of one,
+// the same winners.  top_val / top_tok rows are K wide here (ldk).
+__device__ __forceinline__ void beam_block_argmax(float& bv, long long& bi, float* wv, long long* wi, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const long long oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { wv[wave] = bv; wi[wave] = bi; }
+    __syncthreads();
+    bv = wv[0]; bi = wi[0];
+    for (int w = 1; w < 4; ++w)
+        if (wv[w] > bv || (wv[w] == bv && wi[w] < bi)) { bv = wv[w]; bi = wi[w]; }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void beam_row_topk_wide_kernel(const float* __restrict__ logits, int ld, int V, int K,
+                                                                 float* __restrict__ row_max, float* __restrict__ row_logsum,
+                                                                 float* __restrict__ top_val, int* __restrict__ top_tok) {
+    __shared__ float sh[4];
+    __shared__ float wv[4];
+    __shared__ long long wi[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = logits + (size_t)row * ld;
+    float m = -INFINITY;   // max and log-sum-exp: the arithmetic of beam_row_topk_kernel
+    for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i]);
+    m = wave_max(m);
+    if (lane == 0) sh[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    float ssum = 0.f;
+    for (int i = tid; i < V; i += 256) ssum += expf(x[i] - m);
+    ssum = block_sum_256(ssum, sh);
+    float pv = INFINITY;
+    long long pi = -1;
+    for (int round = 0; round < K; ++round) {
+        float bv = -INFINITY;
+        long long bi = 0x7fffffffLL;
+        for (int i = tid; i < V; i += 256) {
+            const float v = x[i];
+            if ((v < pv || (v == pv && i > pi)) && v > bv) { bv = v; bi = i; }   // strided indices ascend: the first of equal values stays
+        }
+        beam_block_argmax(bv, bi, wv, wi, tid);
+        if (tid == 0) {
+            top_val[(size_t)row * K + round] = bv;
+            top_tok[(size_t)row * K + round] = (int)bi;
+        }
+        pv = bv; pi = bi;
+    }
+    if (tid == 0) { row_max[row] = m; row_logsum[row] = logf(ssum); }
+}
+// Per batch item: the nb * K candidate scores (same expression as beam_merge_kernel) into `score` [item][nb * K], then the item's
+// top K in the order (score desc, flat index beam * V + token asc), again by K rounds over what follows the previous winner.
+__global__ __launch_bounds__(256) void beam_merge_wide_kernel(const float* __restrict__ row_max, const float* __restrict__ row_logsum,
+                                                              const float* __restrict__ top_val, const int* __restrict__ top_tok,
+                                                              const float* __restrict__ beam_scores, int nb, int K, int V,
+                                                              float* __restrict__ score, float* __restrict__ out_score,
+                                                              int* __restrict__ out_tok, int* __restrict__ out_beam) {
+    __shared__ float wv[4];
+    __shared__ long long wi[4];
+    const int item = blockIdx.x, tid = threadIdx.x;
+    const int n = nb * K;
+    float* sc = score + (size_t)item * n;
+    for (int c = tid; c < n; c += 256) {
+        const int b = c / K, row = item * nb + b;
+        sc[c] = ((top_val[(size_t)row * K + (c - b * K)] - row_max[row]) - row_logsum[row]) + beam_scores[row];
+    }
+    __syncthreads();
+    float pv = INFINITY;
+    long long pf = -1;
+    for (int round = 0; round < K; ++round) {
+        float bv = -INFINITY;
+        long long bf = 0x7fffffffffffLL;
+        for (int c = tid; c < n; c += 256) {
+            const int b = c / K;
+            const float v = sc[c];
+            const long long flat = (long long)b * V + top_tok[(size_t)(item * nb + b) * K + (c - b * K)];
+            if ((v < pv || (v == pv && flat > pf)) && (v > bv || (v == bv && flat < bf))) { bv = v; bf = flat; }
+        }
+        beam_block_argmax(bv, bf, wv, wi, tid);
+        if (tid == 0) {
+            out_score[item * K + round] = bv;
+            out_tok[item * K + round] = (int)(bf % V);
+            out_beam[item * K + round] = (int)(bf / V);
+        }
+        pv = bv; pf = bf;
+    }
+}
+
 // New ancestor table after the host picked the surviving beams: row r continues beam parent[r];
 // slots 0..t come from the parent's table, slot t+1 (written this step) lives in the parent's row.
 __global__ __launch_bounds__(256) void beam_advance_kernel(const int* __restrict__ src_old, int* __restrict__ src_new,
@@ -1528,6 +1619,9 @@ struct rgrg_decoder {
     // beam search
     int *src_a, *src_b, *beam_tok, *beam_parent, *cand_tok, *cand_beam, *top_tok;
     float *beam_scores, *row_max, *row_logsum, *top_val, *cand_score;
+    float *wide_val = nullptr, *wide_score = nullptr;   // more than 16 beams: [rows][K] row candidates, [items][num_beams * K] scores
+    int* wide_tok = nullptr;
+    size_t wide_cap = 0;                                 // rows * K the wide buffers were sized for
     int* h_done;  // pinned: [0] final read, [1..2] the two in-flight "all finished" polls of the greedy loop
     hipEvent_t ev_poll[2] = {nullptr, nullptr};
     // Token-id validation of the teacher-forced passes, without a host round trip.  id_error[0]: raised by the CURRENT
@@ -2677,11 +2771,22 @@ struct BeamHyps {
 extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int S, int num_beams, int max_length,
                                         int early_stopping, float length_penalty, int num_return_sequences, int64_t* out_ids,
                                         int out_ld, int* out_len, void* stream) {
-    RGRG_CHECK_ARG(d && feats && out_ids && out_len && S > 0 && num_beams > 1 && 2 * num_beams <= BEAM_K);
+    RGRG_CHECK_ARG(d && feats && out_ids && out_len && S > 0 && num_beams > 1 && num_beams <= (1 << 14));
     RGRG_CHECK_ARG(num_return_sequences >= 1 && num_return_sequences <= num_beams);
     const int nb = num_beams, K = 2 * nb, R = S * nb;
     RGRG_CHECK_ARG(R <= d->max_seqs && max_length >= 2 && max_length <= d->max_len && out_ld >= max_length);
     hipStream_t st = d->stream;
+    const bool wide = K > BEAM_K;   // more than 16 beams: the K-round ranking kernels on K-wide candidate rows
+    if (wide && d->wide_cap < (size_t)R * K) {
+        RGRG_HIP(hipStreamSynchronize(st));
+        for (auto& g : d->graphs) (void)hipGraphExecDestroy(g.exec);   // (captured beam steps bake the buffers in)
+        d->graphs.clear();
+        int r;
+        if ((r = dmalloc(d, (void**)&d->wide_val, (size_t)R * K * 4, true)) || (r = dmalloc(d, (void**)&d->wide_tok, (size_t)R * K * 4, true)) ||
+            (r = dmalloc(d, (void**)&d->wide_score, (size_t)R * K * 4, true)))
+            return r;
+        d->wide_cap = (size_t)R * K;
+    }
     RGRG_HIP(hipEventRecord(d->ev_in, as_stream(stream)));
     RGRG_HIP(hipStreamWaitEvent(st, d->ev_in, 0));
     // prefill for the S image features; the image key/value of item s is stored in cache row s*nb (slot 0)
@@ -2717,11 +2822,16 @@ extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int
                 hipGraph_t graph = nullptr;
                 RGRG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
                 rc = enqueue_step(d, R, false, d->beam_tok, src_cur, true);
-                if (!rc) {
+                if (!rc && !wide) {
                     hipLaunchKernelGGL(beam_row_topk_kernel, dim3(R), dim3(256), 0, st, d->logits, d->ld_logits, d->V, K,
                                        d->row_max, d->row_logsum, d->top_val, d->top_tok);
                     hipLaunchKernelGGL(beam_merge_kernel, dim3(S), dim3(BEAM_MERGE_THREADS), 0, st, d->row_max, d->row_logsum, d->top_val,
                                        d->top_tok, d->beam_scores, nb, K, d->V, d->cand_score, d->cand_tok, d->cand_beam);
+                } else if (!rc) {
+                    hipLaunchKernelGGL(beam_row_topk_wide_kernel, dim3(R), dim3(256), 0, st, d->logits, d->ld_logits, d->V, K,
+                                       d->row_max, d->row_logsum, d->wide_val, d->wide_tok);
+                    hipLaunchKernelGGL(beam_merge_wide_kernel, dim3(S), dim3(256), 0, st, d->row_max, d->row_logsum, d->wide_val, d->wide_tok,
+                                       d->beam_scores, nb, K, d->V, d->wide_score, d->cand_score, d->cand_tok, d->cand_beam);
                 }
                 hipError_t e = hipStreamEndCapture(st, &graph);
                 if (rc) return rc;

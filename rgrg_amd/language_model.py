@@ -263,8 +263,6 @@ class LanguageModel(EngineOwner):
                 raise ValueError("'num_return_sequences' has to be smaller or equal to 'num_beams'.")
             if max_length is None:
                 raise ValueError("max_length has to be set for beam generation.")
-            if num_beams > 16:
-                raise NotImplementedError("the HIP beam search supports num_beams <= 16")
             # length_penalty = 1.0 as in the reference (language_model.py:461)
             low = _hip.autocast_mode()
             return self.engine().beam_search(image_hidden_states, max_length, num_beams, early_stopping, 1.0, bf16=low,

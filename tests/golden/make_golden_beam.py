@@ -58,6 +58,22 @@ def main():
     torch.save(wide, os.path.join(HERE, "lm_beam16.pt"))
     print("saved lm_beam16.pt; oracle matches reference:", ok_wide)
     ok_all &= ok_wide
+    # round 6: more than 16 beams (the reference has no bound; the HIP path ranks them with its K-round kernels), 2 regions
+    wider = {"meta": dict(out["meta"], num_beams="20 / 33"), "cases": {}}
+    ok_wider = True
+    for name, nb, max_length, early, nret in (("beams20_len12_early", 20, 12, True, 1), ("beams33_len8_ret5", 33, 8, False, 5)):
+        with torch.no_grad():
+            ref = model.language_model.generate(feats[:2], max_length=max_length, num_beams=nb, early_stopping=early,
+                                                num_return_sequences=nret)
+        ora = o_lm.beam_generate(sd, feats[:2], max_length, nb, early_stopping=early, num_return_sequences=nret)
+        ok = ref.shape == ora.shape and torch.equal(ref, ora)
+        ok_wider &= ok
+        print(f"{name}: reference {tuple(ref.shape)} oracle {tuple(ora.shape)} match={ok}")
+        wider["cases"][name] = {"num_beams": nb, "max_length": max_length, "early_stopping": early, "num_return_sequences": nret, "sequences": ref}
+    wider["meta"]["oracle_matches_reference"] = bool(ok_wider)
+    torch.save(wider, os.path.join(HERE, "lm_beam_wide.pt"))
+    print("saved lm_beam_wide.pt; oracle matches reference:", ok_wider)
+    ok_all &= ok_wider
     return 0 if ok_all else 1
 
 

@@ -110,7 +110,7 @@ def test_generation_mode_errors_match_reference(model):
         lm.generate(f, 8, num_beams=2, num_return_sequences=3)
     with pytest.raises(NotImplementedError):
         lm.generate(f, 8, num_beams=4, num_beam_groups=2)
-    with pytest.raises(NotImplementedError, match="num_beams <= 16"):
+    with pytest.raises(_hip.RgrgHipError, match="no CPU fallback"):   # any beam count reaches the HIP path (round 6: > 16 beams too)
         lm.generate(f, 8, num_beams=17)
 
 

@@ -180,6 +180,30 @@ def test_beam_search_matches_reference_fixture(case):
     assert torch.equal(seq.cpu(), fx["sequences"]), f"rows differ: {(seq.cpu() != fx['sequences']).any(1).nonzero().flatten().tolist()}"
 
 
+@pytest.mark.parametrize("case", ["beams20_len12_early", "beams33_len8_ret5"])
+def test_beam_search_beyond_16_beams_matches_reference_fixture(case):
+    """More than 16 beams (round 6; the reference's loop is unbounded, language_model.py:450-475): the K-round ranking kernels
+    (beam_row_topk_wide_kernel / beam_merge_wide_kernel) against the REAL reference's loop - 20 beams with early stopping, 33 beams
+    (an odd count, 66 candidates per row, 5 returned hypotheses per region)."""
+    m = gpu_model("ragged")
+    fx = load_golden("lm_beam_wide.pt")["cases"][case]
+    seq = m.language_model.generate(_lm_feats()[:2].to(DEV), max_length=fx["max_length"], num_beams=fx["num_beams"],
+                                    early_stopping=fx["early_stopping"], num_return_sequences=fx["num_return_sequences"])
+    assert seq.shape == fx["sequences"].shape and seq.dtype == torch.int64
+    assert torch.equal(seq.cpu(), fx["sequences"]), f"rows differ: {(seq.cpu() != fx['sequences']).any(1).nonzero().flatten().tolist()}"
+
+
+def test_beam_search_17_beams_then_4_then_40_on_one_decoder():
+    """Beam counts on either side of the register-list limit on ONE model (the wide candidate buffers are sized on demand and the
+    captured steps dropped when they grow): 17 beams, the shipped 4, then 40 beams on 3 regions - each against the CPU oracle."""
+    m = gpu_model("ragged")
+    feats = _lm_feats()[:3]
+    for nb, L in ((17, 8), (4, 10), (40, 6)):
+        ref = o_lm.beam_generate(synth_sd("ragged"), feats, L, nb, early_stopping=False)
+        out = m.language_model.generate(feats.to(DEV), max_length=L, num_beams=nb, early_stopping=False)
+        assert out.shape == ref.shape and torch.equal(out.cpu(), ref), nb
+
+
 def test_beam_search_more_regions_vs_oracle():
     """29 regions x 4 beams = 116 beam rows (tiled-GEMM path, ancestor-table KV indexing) vs the CPU oracle."""
     m = gpu_model("ragged")

@@ -88,6 +88,19 @@ def test_beam_search_oracle_matches_reference_loop_at_16_beams(sd_ragged):
         assert torch.equal(seq, c["sequences"])
 
 
+def test_beam_search_oracle_matches_reference_loop_beyond_16_beams(sd_ragged):
+    """lm_beam_wide.pt (round 6: the reference's loop has no bound on num_beams, and neither has the HIP path now): 20 beams with
+    early stopping, 33 beams with 5 returned hypotheses per region."""
+    fx = load_golden("lm_beam_wide.pt")
+    assert fx["meta"]["oracle_matches_reference"] is True
+    g = torch.Generator().manual_seed(99)
+    feats = torch.randn((5, 1024), generator=g)[:2]
+    c = fx["cases"]["beams20_len12_early"]   # (the 33-beam case is the GPU test's; one case keeps the CPU suite short)
+    seq = o_lm.beam_generate(sd_ragged, feats, c["max_length"], c["num_beams"], early_stopping=c["early_stopping"],
+                             num_return_sequences=c["num_return_sequences"])
+    assert torch.equal(seq, c["sequences"])
+
+
 def test_beam_scorer_hand_case():
     """Known-answer test of the restated BeamHypotheses (third-party semantics, unpinned otherwise)."""
     from oracle.beam_scorer import BeamHypotheses
