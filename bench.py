@@ -90,8 +90,11 @@ def rooflines(eng, S_dec, dtype, max_length):
     else:
         peak = MFMA_PEAK_TFS["f32" if dtype == "f32" else "bf16"]
         ach = p["gemm_flops"] / (p["ms_gemm"] * 1e-3) / 1e12
-        gemm = {"bound": "mfma", "kernel": ("gemm_bf16_glds_kernel (c_attn, c_fc) + gemm_bf16_kp_kernel (attn_proj, mlp_proj) + gemm_bf16_pp_kernel (lm_head)"
-                                            if dtype != "f32" else "gemm_f32_kernel"), "achieved": ach, "peak": peak,
+        kname = "gemm_f32_kernel"
+        if dtype != "f32":
+            kname = ("gemm_bf16_glds_kernel (c_attn, c_fc; attn_proj / mlp_proj on 2 / 4 K slices: steps of <= 256 rows) + lm_head" if S_dec <= 256 else
+                     "gemm_bf16_glds_kernel (c_attn, c_fc) + gemm_bf16_kp_kernel (attn_proj, mlp_proj) + gemm_bf16_pp_kernel (lm_head)")
+        gemm = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak,
                 "unit": "TFLOP/s", "frac": ach / peak, "traffic": g_traffic, "traffic_source": g_src, "launches_per_decode_step": n,
                 "avg_launch_us": 1e3 * p["ms_gemm"] / n, "algorithmic_flops_per_launch": p["gemm_flops"] / n,
                 "note": "achieved = 2 M N K of the GEMM launches of one decode step / their duration between two HIP events on the decoder stream, "

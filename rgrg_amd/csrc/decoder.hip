@@ -946,35 +946,59 @@ constexpr int BEAM_K = 32;  // max 2*num_beams candidates per row (num_beams <= 
 
 // Per beam row: max, log-sum-exp and the top-K (value desc, token asc on ties) logits.
 // log_softmax is monotonic within a row, so the row's best continuations are its top logits.
-__global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restrict__ logits, int ld, int V, int K,
-                                                            float* __restrict__ row_max, float* __restrict__ row_logsum,
-                                                            float* __restrict__ top_val, int* __restrict__ top_tok) {
-    __shared__ float sh[4];
-    __shared__ float wv[4];
-    __shared__ int wi[4];
-    __shared__ int winner;
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* x = logits + (size_t)row * ld;
+// Round 6: 1024 threads per row and candidate lists of LIST = 8 / 16 / 32 >= K entries (the scripts' 4 beams need 8): the round-5
+// kernel - 256 threads, lists of 32 - took 204 us per step at 116 beam rows (11 % of the step): a wave runs the whole 31-step
+// insertion chain whenever ONE of its lanes inserts, i.e. for nearly every one of its 196 elements per lane.
+constexpr int BEAM_ROW_THREADS = 1024;
+// max and sum of exp(x - max) of a row, the same value in every thread (fixed order: strided per thread, butterflies per wave, the 16
+// wave sums in wave order)
+template <int THREADS>
+__device__ __forceinline__ void beam_row_max_sumexp(const float* __restrict__ x, int V, float* sh, float& m_out, float& ssum_out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float m = -INFINITY;
-    for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i]);
+    for (int i = tid; i < V; i += THREADS) m = fmaxf(m, x[i]);
     m = wave_max(m);
     if (lane == 0) sh[wave] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    m = sh[0];
+#pragma unroll
+    for (int w = 1; w < THREADS / 64; ++w) m = fmaxf(m, sh[w]);
+    __syncthreads();
     float ssum = 0.f;
-    for (int i = tid; i < V; i += 256) ssum += expf(x[i] - m);
-    ssum = block_sum_256(ssum, sh);
-    // local top-K of this thread's strided elements, sorted (value desc, index asc)
-    float lv[BEAM_K];
-    int li[BEAM_K];
+    for (int i = tid; i < V; i += THREADS) ssum += expf(x[i] - m);
+    ssum = wave_sum(ssum);
+    if (lane == 0) sh[wave] = ssum;
+    __syncthreads();
+    ssum = sh[0];
 #pragma unroll
-    for (int k = 0; k < BEAM_K; ++k) { lv[k] = -INFINITY; li[k] = 0x7fffffff; }
-    for (int i = tid; i < V; i += 256) {
+    for (int w = 1; w < THREADS / 64; ++w) ssum += sh[w];
+    __syncthreads();
+    m_out = m; ssum_out = ssum;
+}
+template <int LIST, int THREADS>   // (8, 1024), (16, 1024), (32, 512): 1024 threads x 32 entries spill
+__global__ __launch_bounds__(THREADS) void beam_row_topk_kernel(const float* __restrict__ logits, int ld, int V, int K,
+                                                                         float* __restrict__ row_max, float* __restrict__ row_logsum,
+                                                                         float* __restrict__ top_val, int* __restrict__ top_tok) {
+    constexpr int NW = THREADS / 64;
+    __shared__ float sh[NW];
+    __shared__ float wv[NW];
+    __shared__ int wi[NW];
+    __shared__ int winner;
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = logits + (size_t)row * ld;
+    float m, ssum;
+    beam_row_max_sumexp<THREADS>(x, V, sh, m, ssum);
+    // local top-LIST of this thread's strided elements, sorted (value desc, index asc)
+    float lv[LIST];
+    int li[LIST];
+#pragma unroll
+    for (int k = 0; k < LIST; ++k) { lv[k] = -INFINITY; li[k] = 0x7fffffff; }
+    for (int i = tid; i < V; i += THREADS) {
         const float v = x[i];
-        if (v > lv[BEAM_K - 1]) {  // strided indices ascend, so an equal value never displaces an earlier one
-            lv[BEAM_K - 1] = v; li[BEAM_K - 1] = i;
+        if (v > lv[LIST - 1]) {  // strided indices ascend, so an equal value never displaces an earlier one
+            lv[LIST - 1] = v; li[LIST - 1] = i;
 #pragma unroll
-            for (int k = BEAM_K - 1; k > 0; --k) {
+            for (int k = LIST - 1; k > 0; --k) {
                 if (lv[k] > lv[k - 1]) {
                     const float tv = lv[k]; lv[k] = lv[k - 1]; lv[k - 1] = tv;
                     const int ti = li[k]; li[k] = li[k - 1]; li[k - 1] = ti;
@@ -994,7 +1018,7 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
         if (lane == 0) { wv[wave] = bv; wi[wave] = bi; }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < 4; ++w)
+            for (int w = 1; w < NW; ++w)
                 if (wv[w] > bv || (wv[w] == bv && wi[w] < bi)) { bv = wv[w]; bi = wi[w]; }
             top_val[(size_t)row * BEAM_K + round] = bv;
             top_tok[(size_t)row * BEAM_K + round] = bi;
@@ -1003,8 +1027,8 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
         __syncthreads();
         if (li[0] == winner) {
 #pragma unroll
-            for (int k = 0; k < BEAM_K - 1; ++k) { lv[k] = lv[k + 1]; li[k] = li[k + 1]; }
-            lv[BEAM_K - 1] = -INFINITY; li[BEAM_K - 1] = 0x7fffffff;
+            for (int k = 0; k < LIST - 1; ++k) { lv[k] = lv[k + 1]; li[k] = li[k + 1]; }
+            lv[LIST - 1] = -INFINITY; li[LIST - 1] = 0x7fffffff;
         }
     }
     if (tid == 0) { row_max[row] = m; row_logsum[row] = logf(ssum); }
@@ -1054,6 +1078,7 @@ __global__ __launch_bounds__(BEAM_MERGE_THREADS) void beam_merge_kernel(const fl
 // kernels above hold 32 candidates in registers; wider beams take K = 2 num_beams rounds of a block-wide arg-max over the elements
 // that come AFTER the previous winner in the same total order (value desc, index asc) - K scans of the row from L2 instead of one,
 // the same winners.  top_val / top_tok rows are K wide here (ldk).
+template <int NW>
 __device__ __forceinline__ void beam_block_argmax(float& bv, long long& bi, float* wv, long long* wi, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     for (int o = 32; o > 0; o >>= 1) {
@@ -1064,37 +1089,31 @@ __device__ __forceinline__ void beam_block_argmax(float& bv, long long& bi, floa
     if (lane == 0) { wv[wave] = bv; wi[wave] = bi; }
     __syncthreads();
     bv = wv[0]; bi = wi[0];
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < NW; ++w)
         if (wv[w] > bv || (wv[w] == bv && wi[w] < bi)) { bv = wv[w]; bi = wi[w]; }
     __syncthreads();
 }
-__global__ __launch_bounds__(256) void beam_row_topk_wide_kernel(const float* __restrict__ logits, int ld, int V, int K,
-                                                                 float* __restrict__ row_max, float* __restrict__ row_logsum,
-                                                                 float* __restrict__ top_val, int* __restrict__ top_tok) {
-    __shared__ float sh[4];
-    __shared__ float wv[4];
-    __shared__ long long wi[4];
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(BEAM_ROW_THREADS) void beam_row_topk_wide_kernel(const float* __restrict__ logits, int ld, int V, int K,
+                                                                              float* __restrict__ row_max, float* __restrict__ row_logsum,
+                                                                              float* __restrict__ top_val, int* __restrict__ top_tok) {
+    constexpr int NW = BEAM_ROW_THREADS / 64;
+    __shared__ float sh[NW];
+    __shared__ float wv[NW];
+    __shared__ long long wi[NW];
+    const int row = blockIdx.x, tid = threadIdx.x;
     const float* x = logits + (size_t)row * ld;
-    float m = -INFINITY;   // max and log-sum-exp: the arithmetic of beam_row_topk_kernel
-    for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i]);
-    m = wave_max(m);
-    if (lane == 0) sh[wave] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
-    float ssum = 0.f;
-    for (int i = tid; i < V; i += 256) ssum += expf(x[i] - m);
-    ssum = block_sum_256(ssum, sh);
+    float m, ssum;
+    beam_row_max_sumexp<BEAM_ROW_THREADS>(x, V, sh, m, ssum);   // the arithmetic of beam_row_topk_kernel
     float pv = INFINITY;
     long long pi = -1;
     for (int round = 0; round < K; ++round) {
         float bv = -INFINITY;
         long long bi = 0x7fffffffLL;
-        for (int i = tid; i < V; i += 256) {
+        for (int i = tid; i < V; i += BEAM_ROW_THREADS) {
             const float v = x[i];
             if ((v < pv || (v == pv && i > pi)) && v > bv) { bv = v; bi = i; }   // strided indices ascend: the first of equal values stays
         }
-        beam_block_argmax(bv, bi, wv, wi, tid);
+        beam_block_argmax<NW>(bv, bi, wv, wi, tid);
         if (tid == 0) {
             top_val[(size_t)row * K + round] = bv;
             top_tok[(size_t)row * K + round] = (int)bi;
@@ -1131,7 +1150,7 @@ __global__ __launch_bounds__(256) void beam_merge_wide_kernel(const float* __res
             const long long flat = (long long)b * V + top_tok[(size_t)(item * nb + b) * K + (c - b * K)];
             if ((v < pv || (v == pv && flat > pf)) && (v > bv || (v == bv && flat < bf))) { bv = v; bf = flat; }
         }
-        beam_block_argmax(bv, bf, wv, wi, tid);
+        beam_block_argmax<4>(bv, bf, wv, wi, tid);
         if (tid == 0) {
             out_score[item * K + round] = bv;
             out_tok[item * K + round] = (int)(bf % V);
@@ -1665,7 +1684,11 @@ struct rgrg_decoder {
     unsigned short *xn16 = nullptr, *att16 = nullptr, *ff16 = nullptr;  // bf16 activations of that path (GEMM inputs)
     float* sk_ws = nullptr;     // split-K work space of the N = 1024 projections of the many-sequence decode step (gemm_bf16.hip)
     unsigned* sk_cnt = nullptr;
-    int sk_attn = 0, sk_mlp = 0; // K slices of attn_proj / mlp_proj there (RGRG_SK_ATTN / RGRG_SK_MLP; 0 or 1 = off)
+    int sk_attn = 0, sk_mlp = 0; // K slices of attn_proj / mlp_proj there (RGRG_SK_ATTN / RGRG_SK_MLP; 1 = off; -1 = automatic: 2 / 4 slices for a
+                                 // step of <= 256 rows - 32-64 output tiles for 256 CUs - and none above)
+    int sk_cons = 1;             // K slices of c_attn / c_fc in a step of <= 256 rows (RGRG_SK_CONS, opt-in: measured slower, r06_small_rows_splitk.log)
+    size_t sk_slabs = 0;         // 64 x 64 fp32 slabs in sk_ws
+    int step_rows = 0;           // token rows of the many-sequence step being enqueued (all row ranges together)
     float* ln_stat = nullptr;   // [rows][16][2]: per-row (sum, sum of squares) slots (one per 64 columns) of the residual stream (folded LayerNorm)
     bool ln_fold = true;        // 16-bit path: LayerNorms folded into the GEMMs around them; RGRG_LN_FOLD=0: ln_rows launches (A/B)
     bool tr_seen_a16 = false, tr_seen_a32 = false, tr_seen_h16 = false, tr_seen_h32 = false, tr_seen_h16_a32 = false;   // tr_reserve: modes seen
@@ -1873,11 +1896,23 @@ static int linear(rgrg_decoder* d, const Lin& l, const float* X, const float* R,
             GemmLnFold f = *ln;
             f.ln_colsum = l.cs16;
             f.kp = (d->kp_gemms == 1 || d->kp_gemms == 3) ? 1 : 0;
+            // opt-in (RGRG_SK_CONS=2), a step of <= 256 rows (no row ranges): c_attn / c_fc on two K slices per tile, the last arriver runs
+            // the folded-LayerNorm epilogue on the sum - 96-128 tiles already keep half the CUs busy and the hand-off costs more than the
+            // 8 K tiles it saves (1 image x 4 beams 500 -> 542 ms)
+            int ks = d->sk_cons;
+            if (ks > 1 && d->sk_ws && d->xn16 && M <= 256 && (size_t)((M + 127) / 128) * 2 * (l.N / 64) * ks <= d->sk_slabs) {
+                const size_t r0 = (size_t)(reinterpret_cast<const unsigned short*>(X16) - d->xn16) / (size_t)d->D;
+                if (r0 == 0) { f.kp = 0; f.ksplit = ks; f.sk_ws = d->sk_ws; f.sk_cnt = d->sk_cnt; }
+            }
             return launch_gemm_bf16w_ex(nullptr, X16, l.wb_ln, l.c2_16, R, Y16 ? nullptr : Y, Y16, M, l.N, l.K, ldy, act, d->stream, d->f16(), &f);
         }
         if (ln && ln->Yb16 && d->sk_ws && M <= d->rows) {
             // a producer of the many-sequence decode step (attn_proj / mlp_proj, N = 1024): split-K with a last-arriver reduce
-            const int ks = l.K >= 2048 ? d->sk_mlp : d->sk_attn;
+            int ks = l.K >= 2048 ? d->sk_mlp : d->sk_attn;
+            // automatic: a step of <= 256 rows has 16 x (1..4) output tiles of 64 x 64 for 256 CUs and a K loop of 16 / 64 tiles - the
+            // hand-off costs less than the idle CUs (116 rows: mlp_proj on 4 slices, attn_proj on 2: 1 image x 4 beams 584 -> 544 ms,
+            // greedy batch 4 200 -> 180 ms, profiles/r06_small_rows_splitk.log); larger steps fill the GPU and lose (r05_splitk_decode_ab.log)
+            if (ks < 0) ks = (d->step_rows > 0 && d->step_rows <= 256) ? (l.K >= 2048 ? 4 : 2) : 1;
             if (ks > 1) {
                 GemmLnFold f = *ln;
                 // slabs and tickets are indexed by the launch-local tile id: a row range (enqueue_step runs several of them
@@ -2212,6 +2247,7 @@ static int enqueue_step(rgrg_decoder* d, int S, bool count, const int* tok_overr
                         bool beam = false, const RangeSpec* only = nullptr) {
     if (S <= decode_row_limit(d)) return enqueue_step_fused(d, S, count, tok_override, src, beam);
     if (count) { d->gemm_bytes_per_step = 0; d->gemm_flops_per_step = 0.0; d->gemm_launches_per_step = 0; }
+    d->step_rows = S;
     hipStream_t st = d->stream;
     const int D = d->D;
     int rc;
@@ -2823,12 +2859,14 @@ extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int
                 RGRG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
                 rc = enqueue_step(d, R, false, d->beam_tok, src_cur, true);
                 if (!rc && !wide) {
-                    hipLaunchKernelGGL(beam_row_topk_kernel, dim3(R), dim3(256), 0, st, d->logits, d->ld_logits, d->V, K,
-                                       d->row_max, d->row_logsum, d->top_val, d->top_tok);
+#define BEAM_TOPK(LIST_, THREADS_) hipLaunchKernelGGL((beam_row_topk_kernel<LIST_, THREADS_>), dim3(R), dim3(THREADS_), 0, st, d->logits, d->ld_logits, d->V, K, \
+                                                      d->row_max, d->row_logsum, d->top_val, d->top_tok)
+                    if (K <= 8) BEAM_TOPK(8, 1024); else if (K <= 16) BEAM_TOPK(16, 1024); else BEAM_TOPK(32, 512);
+#undef BEAM_TOPK
                     hipLaunchKernelGGL(beam_merge_kernel, dim3(S), dim3(BEAM_MERGE_THREADS), 0, st, d->row_max, d->row_logsum, d->top_val,
                                        d->top_tok, d->beam_scores, nb, K, d->V, d->cand_score, d->cand_tok, d->cand_beam);
                 } else if (!rc) {
-                    hipLaunchKernelGGL(beam_row_topk_wide_kernel, dim3(R), dim3(256), 0, st, d->logits, d->ld_logits, d->V, K,
+                    hipLaunchKernelGGL(beam_row_topk_wide_kernel, dim3(R), dim3(BEAM_ROW_THREADS), 0, st, d->logits, d->ld_logits, d->V, K,
                                        d->row_max, d->row_logsum, d->wide_val, d->wide_tok);
                     hipLaunchKernelGGL(beam_merge_wide_kernel, dim3(S), dim3(256), 0, st, d->row_max, d->row_logsum, d->wide_val, d->wide_tok,
                                        d->beam_scores, nb, K, d->V, d->wide_score, d->cand_score, d->cand_tok, d->cand_beam);
@@ -3798,15 +3836,23 @@ static int set_precision_impl(rgrg_decoder* d, int mode) {
             };
             if (!d->ln_stat && (rc2 = dmalloc(d, (void**)&d->ln_stat, (size_t)d->rows * 32 * sizeof(float), true))) return rc2;
             if (!d->sk_ws) {   // split-K of the two N = 1024 projections: up to 4 slabs of 64 x 64 fp32 per tile + a ticket per tile
+                // (c_attn / c_fc of a <= 256-row step use it too: up to 4 row tiles x 64 column tiles x 2 slices)
                 const size_t tiles = (size_t)((d->rows + 63) / 64) * (d->D / 64);
-                if ((rc2 = dmalloc(d, (void**)&d->sk_ws, tiles * 4 * 4096 * sizeof(float), false)) ||
-                    (rc2 = dmalloc(d, (void**)&d->sk_cnt, tiles * sizeof(unsigned), true)))
+                const size_t small_rows = (size_t)((std::min(d->rows, 256) + 127) / 128) * 2;   // (the launcher may pick 128-row tiles)
+                const size_t slabs = std::max(tiles * 4, small_rows * (size_t)(4 * d->D / 64) * 2), tickets = std::max(tiles, small_rows * (size_t)(4 * d->D / 64));
+                if ((rc2 = dmalloc(d, (void**)&d->sk_ws, slabs * 4096 * sizeof(float), false)) ||
+                    (rc2 = dmalloc(d, (void**)&d->sk_cnt, tickets * sizeof(unsigned), true)))
                     return rc2;
+                d->sk_slabs = slabs;
+                if (const char* e3 = getenv("RGRG_SK_CONS")) d->sk_cons = atoi(e3) <= 0 ? 1 : std::min(atoi(e3), 4);
                 const char* e1 = getenv("RGRG_SK_MLP");
                 const char* e2 = getenv("RGRG_SK_ATTN");
-                // measured (profiles/r05_splitk_decode_ab.log): the hand-off costs what the shorter K loop saves - off unless asked for
-                d->sk_mlp = e1 ? atoi(e1) : 1;
-                d->sk_attn = e2 ? atoi(e2) : 1;
+                // measured (profiles/r05_splitk_decode_ab.log): at hundreds of rows the hand-off costs what the shorter K loop saves; unset =
+                // automatic (steps of <= 256 rows only, linear())
+                d->sk_mlp = e1 ? atoi(e1) : -1;
+                d->sk_attn = e2 ? atoi(e2) : -1;
+                if (d->sk_mlp == 0) d->sk_mlp = 1;
+                if (d->sk_attn == 0) d->sk_attn = 1;
                 if (d->sk_mlp > 4) d->sk_mlp = 4;
                 if (d->sk_attn > 4) d->sk_attn = 4;
             }
@@ -3920,6 +3966,7 @@ extern "C" int rgrg_decoder_time_step_parts(rgrg_decoder* d, int S, int nkeys, i
     const int D = d->D;
     const bool fused = d->lm_head.direct && S <= decode_row_limit(d);
     const bool bf = kv_is_bf16(d, S);
+    d->step_rows = S;   // (linear()'s automatic split-K looks at the step's rows)
     unsigned short* xn16 = (bf && d->xn16) ? d->xn16 : nullptr;
     unsigned short* att16 = xn16 ? d->att16 : nullptr;
     unsigned short* ff16 = xn16 ? d->ff16 : nullptr;

@@ -196,7 +196,8 @@ def test_configs2_full_size_properties_batch32_bf16():
 
 @pytest.mark.parametrize("S", [200, 600])
 def test_opt_in_split_k_of_the_decode_projections_matches_the_default_path(S):
-    """VERDICT r04 item 1a was built and measured slower (profiles/r05_splitk_decode_ab.log), so it is opt-in: RGRG_SK_MLP /
+    """VERDICT r04 item 1a was built and measured slower at hundreds of rows (profiles/r05_splitk_decode_ab.log), so there it is opt-in
+    (round 6: automatic for steps of <= 256 rows, where 32-64 output tiles leave most CUs idle - profiles/r06_small_rows_splitk.log): RGRG_SK_MLP /
     RGRG_SK_ATTN = K slices per tile of mlp_proj / attn_proj in the many-sequence 16-bit decode step (write-through slabs, one
     ticket per tile, the last arriver adds the slabs in slice order and runs the LayerNorm-producer epilogue).  Read once per
     process -> child processes: 200 sequences x 6 tokens under bf16 autocast, 2 / 4 slices against the unsplit kernels - the
@@ -221,14 +222,20 @@ def test_opt_in_split_k_of_the_decode_projections_matches_the_default_path(S):
         "torch.save((ids.cpu(), lg.cpu()), sys.argv[1])\n" % (repo, os.path.join(repo, "tests"), S, S))
     res = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for name, env_add in (("off", {}), ("mlp2", {"RGRG_SK_MLP": "2", "RGRG_SK_ATTN": "2"}), ("mlp4", {"RGRG_SK_MLP": "4"})):
+        off = {"RGRG_SK_MLP": "1", "RGRG_SK_ATTN": "1", "RGRG_SK_CONS": "1"}
+        # "auto": nothing set - a step of <= 256 rows splits mlp_proj 4 ways and attn_proj 2 ways by itself (round 6), larger ones do not;
+        # "cons2": c_attn / c_fc on two K slices as well (opt-in, <= 256 rows; measured slower)
+        for name, env_add in (("off", off), ("mlp2", dict(off, RGRG_SK_MLP="2", RGRG_SK_ATTN="2")), ("mlp4", dict(off, RGRG_SK_MLP="4")),
+                              ("auto", {}), ("cons2", {"RGRG_SK_CONS": "2"})):
             path = os.path.join(tmp, name + ".pt")
             r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env_add), capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             res[name] = torch.load(path)
     ids0, lg0 = res["off"]
     span = lg0.abs().max().item()
-    for name in ("mlp2", "mlp4"):
+    if S > 256:   # no automatic split-K above 256 rows: the default step IS the unsplit one
+        assert torch.equal(res["auto"][0], ids0) and torch.equal(res["auto"][1], lg0)
+    for name in ("mlp2", "mlp4", "auto", "cons2"):
         ids1, lg1 = res[name]
         assert ids1.shape == ids0.shape
         same = (ids1 == ids0).all(dim=1)
