@@ -2817,6 +2817,14 @@ extern "C" int rgrg_decoder_beam_search(rgrg_decoder* d, const float* feats, int
         RGRG_HIP(hipStreamSynchronize(st));
         for (auto& g : d->graphs) (void)hipGraphExecDestroy(g.exec);   // (captured beam steps bake the buffers in)
         d->graphs.clear();
+        for (void** q : {(void**)&d->wide_val, (void**)&d->wide_tok, (void**)&d->wide_score}) {   // grown: the smaller buffers go
+            if (!*q) continue;
+            auto it = std::find(d->allocs.begin(), d->allocs.end(), *q);
+            if (it != d->allocs.end()) d->allocs.erase(it);
+            (void)hipFree(*q);
+            *q = nullptr;
+        }
+        d->wide_cap = 0;
         int r;
         if ((r = dmalloc(d, (void**)&d->wide_val, (size_t)R * K * 4, true)) || (r = dmalloc(d, (void**)&d->wide_tok, (size_t)R * K * 4, true)) ||
             (r = dmalloc(d, (void**)&d->wide_score, (size_t)R * K * 4, true)))
