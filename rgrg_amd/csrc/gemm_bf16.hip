@@ -1289,6 +1289,10 @@ static int launch_glds(const GemmBf16Params& p, int tile, hipStream_t st) {
         // 173 us on 128 x 128 tiles (profiles/r05_gemm_big_fc6_v1.log)
         if (p.M >= 512 && p.N >= 32768 && tiles_pp >= 512 && pp_lm_head()) return launch_pp(p, st);
     }
+    if (shape == 0 && p.ln_colsum && p.M <= 320) {   // measurement: RGRG_CONS_TILE_SMALLM = tile code of c_attn / c_fc on a row range (M <= 320)
+        static const int o = [] { const char* e = getenv("RGRG_CONS_TILE_SMALLM"); return e ? atoi(e) : 0; }();
+        if (o) { shape = o & 15; nst = o >> 4; }
+    }
     if (shape == 0) {
         const long tiles_big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
         if (p.N <= 64) { shape = 3; nst = 2; }            // a 64-channel conv: no point in a 128-wide column tile
