@@ -62,3 +62,20 @@ def test_incremental_forward_on_the_16bit_fused_plan_close_to_fp32():
         rng = r.abs().max().item()
         assert (r - l).abs().max().item() <= 5e-3 * rng
         assert (r.argmax(-1) == l.argmax(-1)).float().mean().item() >= 0.90
+
+
+@pytest.mark.parametrize("S", [33, 64, 65])
+def test_row_count_boundaries_of_the_autocast_plans(S):
+    """33 = the first row count on the 16-bit-weight fused plan (32 stay bit-exact fp32), 64 its last, 65 the first on the
+    many-sequence 16-bit path: greedy ids of 10 tokens under bf16 autocast agree with the fp32 ids on most positions (a flipped near-tie
+    changes the rest of that row), deterministic, BOS first; and a 32-row call under autocast IS the fp32 result."""
+    m = gpu_model("bench")
+    feats = _feats(S, 47)
+    ref = m.language_model.generate(feats, max_length=10)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        low = m.language_model.generate(feats, max_length=10)
+        low2 = m.language_model.generate(feats, max_length=10)
+        exact = m.language_model.generate(feats[:32], max_length=10)
+    assert low.shape == ref.shape and (low[:, 0] == 50256).all() and torch.equal(low, low2)
+    assert (low == ref).float().mean().item() >= 0.70
+    assert torch.equal(exact, m.language_model.generate(feats[:32], max_length=10))
