@@ -986,26 +986,53 @@ __global__ __launch_bounds__(THREADS) void beam_row_topk_kernel(const float* __r
     __shared__ int winner;
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* x = logits + (size_t)row * ld;
-    float m, ssum;
-    beam_row_max_sumexp<THREADS>(x, V, sh, m, ssum);
-    // local top-LIST of this thread's strided elements, sorted (value desc, index asc)
+    // ONE pass over the row: the thread's running maximum with the sum of exp(x - maximum) rescaled whenever the maximum moves, and its
+    // local top-LIST, sorted (value desc, index asc).  (Three passes - maximum, sum, candidates - took 50 us per step at the scripts'
+    // 116 beam rows, this form 44: what is left is the insertion chain, which a wave runs whenever one of its lanes inserts, and the
+    // exponentials, on 116 of the 256 CUs - profiles/r06_kernel_trace_summary_beam4_fp16.md.)
+    float tm = -INFINITY, ts = 0.f;
     float lv[LIST];
     int li[LIST];
 #pragma unroll
     for (int k = 0; k < LIST; ++k) { lv[k] = -INFINITY; li[k] = 0x7fffffff; }
-    for (int i = tid; i < V; i += THREADS) {
-        const float v = x[i];
-        if (v > lv[LIST - 1]) {  // strided indices ascend, so an equal value never displaces an earlier one
-            lv[LIST - 1] = v; li[LIST - 1] = i;
+    // (8 loads in flight per thread)
+    for (int i0 = tid; i0 < V; i0 += 8 * THREADS) {
+        float vb[8];
 #pragma unroll
-            for (int k = LIST - 1; k > 0; --k) {
-                if (lv[k] > lv[k - 1]) {
-                    const float tv = lv[k]; lv[k] = lv[k - 1]; lv[k - 1] = tv;
-                    const int ti = li[k]; li[k] = li[k - 1]; li[k - 1] = ti;
+        for (int u = 0; u < 8; ++u) vb[u] = x[min(i0 + u * THREADS, V - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * THREADS;
+            if (i >= V) break;
+            const float v = vb[u];
+            if (v > tm) { ts = ts * expf(tm - v) + 1.0f; tm = v; }   // (first element: 0 * exp(-inf) + 1)
+            else ts += expf(v - tm);
+            if (v > lv[LIST - 1]) {  // strided indices ascend, so an equal value never displaces an earlier one
+                lv[LIST - 1] = v; li[LIST - 1] = i;
+#pragma unroll
+                for (int k = LIST - 1; k > 0; --k) {
+                    if (lv[k] > lv[k - 1]) {
+                        const float tv = lv[k]; lv[k] = lv[k - 1]; lv[k - 1] = tv;
+                        const int ti = li[k]; li[k] = li[k - 1]; li[k - 1] = ti;
+                    }
                 }
             }
         }
     }
+    // row maximum, then every thread's sum brought to it; fixed order (butterflies per wave, the wave sums in wave order)
+    float m = wave_max(tm);
+    if (lane == 0) sh[wave] = m;
+    __syncthreads();
+    m = sh[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, sh[w]);
+    __syncthreads();
+    float ssum = wave_sum(tm == -INFINITY ? 0.f : ts * expf(tm - m));
+    if (lane == 0) sh[wave] = ssum;
+    __syncthreads();
+    ssum = sh[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) ssum += sh[w];
     // K rounds: block-wide arg-max over the threads' current heads; the winner pops its head
     for (int round = 0; round < K; ++round) {
         float bv = lv[0];
@@ -1103,7 +1130,7 @@ __global__ __launch_bounds__(BEAM_ROW_THREADS) void beam_row_topk_wide_kernel(co
     const int row = blockIdx.x, tid = threadIdx.x;
     const float* x = logits + (size_t)row * ld;
     float m, ssum;
-    beam_row_max_sumexp<BEAM_ROW_THREADS>(x, V, sh, m, ssum);   // the arithmetic of beam_row_topk_kernel
+    beam_row_max_sumexp<BEAM_ROW_THREADS>(x, V, sh, m, ssum);
     float pv = INFINITY;
     long long pi = -1;
     for (int round = 0; round < K; ++round) {
