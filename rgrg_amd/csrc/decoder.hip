@@ -3834,7 +3834,7 @@ static int set_precision_impl(rgrg_decoder* d, int mode) {
         }
         // the fragment-packed weights of the fused plan rounded to the autocast type (33-128 rows, skinny_direct.inc W16), and for the
         // GEMMs behind a LayerNorm the column sums of the ROUNDED values (the folded mean term must match what the MFMA multiplies)
-        if (d->w16_fused) {
+        if (d->w16_fused && d->rows > PAD_ROWS) {   // (a decoder of <= 32 rows never leaves the bit-exact fp32 kernels: no copies)
             auto mk16 = [&](Lin& l) -> int {
                 if (!l.direct || !l.packed || (l.packed16 && l.packed16_f16 == d->f16())) return RGRG_OK;
                 const size_t n = (size_t)l.NT * 16 * l.K;
