@@ -47,6 +47,26 @@ def main():
             os.environ["RGRG_PP_DBG"] = str(dbg)
             print(f"   dbg {dbg} {what:24s} {timed(call):7.1f} us", flush=True)
         os.environ["RGRG_PP_DBG"] = "0"
+    # the producers as the decode step launches them (K-parity kernel, LayerNorm-producer epilogue: fp32 residual in, fp32 x + 16-bit
+    # copy + statistics slots out): the whole launch, the launch without its epilogue, and neither main loop nor epilogue
+    for name, N, K in (("attn_proj", 1024, 1024), ("mlp_proj", 1024, 4096)):
+        ncopy = max(1, -(-600_000_000 // (N * K * 2)))
+        A16 = (torch.rand((M, K), device="cuda") * 2 - 1).bfloat16().view(torch.int16)
+        Wb = ((torch.rand((ncopy, N, K), device="cuda") * 2 - 1) / K ** 0.5).bfloat16().view(torch.int16)
+        b = torch.randn((N,), device="cuda")
+        R = torch.randn((M, N), device="cuda")
+        yb, so = torch.empty((M, N), dtype=torch.int16, device="cuda"), torch.zeros((M, 16, 2), device="cuda")
+        it = [0]
+
+        def call():
+            it[0] += 1
+            _hip.check(lib.rgrg_debug_linear_bf16_ln_kp(A16.data_ptr(), Wb[it[0] % ncopy].data_ptr(), b.data_ptr(), R.data_ptr(), R.data_ptr(), None,
+                                                        yb.data_ptr(), so.data_ptr(), None, None, M, N, K, N, 0, 0, 1, st))
+        print(f"{name} M={M} as a LayerNorm producer (kp64x64x4)", flush=True)
+        for dbg, what in ((0, "full"), (8, "no epilogue"), (7, "barriers + epilogue only"), (15, "barriers only, no epilogue")):
+            os.environ["RGRG_PP_DBG"] = str(dbg)
+            print(f"   dbg {dbg:2d} {what:28s} {timed(call):7.1f} us", flush=True)
+        os.environ["RGRG_PP_DBG"] = "0"
 
 
 if __name__ == "__main__":
